@@ -1,0 +1,142 @@
+"""ctypes declarations for libehyb.so (include/ehyb.h, include/spmv.h).
+
+The library is the product; this module only loads it and fails loudly when it is
+missing.  There is no Python or CPU implementation of the multiply to fall back to.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libehyb.so")
+
+
+class MatrixCOO(C.Structure):
+    """matrixCOO of include/spmv.h (layout of reference spmv.h:17-33)."""
+
+    _fields_ = [
+        ("totalNum", C.c_int),
+        ("dimension", C.c_int),
+        ("maxCol", C.c_int),
+        ("nParts", C.c_int),
+        ("vectorCacheSize", C.c_uint16),
+        ("kernelPerPart", C.c_int16),
+        ("rowIdx", C.POINTER(C.c_int)),
+        ("numInRow", C.POINTER(C.c_int)),
+        ("numInRow2", C.POINTER(C.c_int)),
+        ("I", C.POINTER(C.c_int)),
+        ("J", C.POINTER(C.c_int)),
+        ("V", C.POINTER(C.c_double)),
+        ("diag", C.POINTER(C.c_double)),
+        ("partBoundary", C.POINTER(C.c_int)),
+        ("reorderList", C.POINTER(C.c_int)),
+    ]
+
+
+class Config(C.Structure):
+    """ehyb_config of include/ehyb.h."""
+
+    _fields_ = [
+        ("lds_doubles", C.c_int32),
+        ("part_rows", C.c_int32),
+        ("threads", C.c_int32),
+        ("window_mode", C.c_int32),
+        ("items_per_cu", C.c_int32),
+        ("partitioner", C.c_int32),
+        ("er_seg_len", C.c_int32),
+        ("host_threads", C.c_int32),
+        ("verbose", C.c_int32),
+        ("seed", C.c_int32),
+        ("n_top", C.c_int32),
+        ("er_threads", C.c_int32),
+        ("reserved", C.c_int32 * 4),
+    ]
+
+
+_STAT_NAMES = [
+    "nnz", "nnz_ell", "nnz_er", "ell_padding", "size_block_ell", "size_er", "rows_er",
+    "er_segments", "n_rows", "n_cols", "n_parts", "n_slabs", "n_items", "halo_cols",
+    "window_loads", "bytes_format", "bytes_alg", "max_row", "lds_bytes",
+]
+
+
+class Stats(C.Structure):
+    _fields_ = [(n, C.c_int64) for n in _STAT_NAMES] + [("reserved", C.c_int64 * 5)]
+
+    def as_dict(self):
+        return {n: int(getattr(self, n)) for n in _STAT_NAMES}
+
+
+# every symbol include/*.h declares with C linkage: name -> (restype, argtypes)
+_P = C.POINTER
+_vp = C.c_void_p
+_dp = _P(C.c_double)
+_ip = _P(C.c_int)
+_i64p = _P(C.c_int64)
+_cfgp = _P(Config)
+_mp = _P(MatrixCOO)
+SIGNATURES = {
+    # spmv.h
+    "spmvGPuEHYB": (None, [_mp, _dp, _dp, C.c_int, _ip]),
+    "spmvGPuEHYB_status": (C.c_int, [_mp, _dp, _dp, C.c_int, _ip]),
+    # ehyb.h
+    "ehyb_last_error": (C.c_char_p, []),
+    "ehyb_version": (C.c_char_p, []),
+    "ehyb_config_default": (None, [_cfgp]),
+    "ehyb_sizing": (C.c_int, [C.c_int, _cfgp, _ip, _ip, _ip]),
+    "ehyb_partition_graph": (C.c_int, [C.c_int, _i64p, _ip, _ip, C.c_int, C.c_int, _cfgp, _ip, _i64p]),
+    "ehyb_matrix_reorder": (C.c_int, [_mp, C.c_int, _cfgp]),
+    "ehyb_vector_reorder": (None, [C.c_int, _dp, _dp, _ip]),
+    "ehyb_vector_recover": (None, [C.c_int, _dp, _dp, _ip]),
+    "ehyb_top_boundary": (C.c_int, [_mp, _cfgp, C.c_int, _ip]),
+    "ehyb_plan_create_host": (C.c_int, [_mp, C.c_int, C.c_int, _cfgp, _P(_vp)]),
+    "ehyb_plan_upload": (C.c_int, [_vp]),
+    "ehyb_plan_create": (C.c_int, [_mp, _cfgp, _P(_vp)]),
+    "ehyb_plan_destroy": (None, [_vp]),
+    "ehyb_plan_stats": (C.c_int, [_vp, _P(Stats)]),
+    "ehyb_plan_host_array": (C.c_int, [_vp, C.c_int, _P(_vp), _i64p]),
+    "ehyb_spmv": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "ehyb_spmv_phase": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
+    "ehyb_spmv_bench": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _dp, _dp, _dp]),
+    "ehyb_spmv_host": (C.c_int, [_vp, _dp, _dp, C.c_int]),
+    "ehyb_device_count": (C.c_int, [_ip]),
+    "ehyb_device_set": (C.c_int, [C.c_int]),
+    "ehyb_device_name": (C.c_int, [C.c_char_p, C.c_int]),
+    "ehyb_dev_alloc": (C.c_int, [C.c_size_t, _P(_vp)]),
+    "ehyb_dev_free": (C.c_int, [_vp]),
+    "ehyb_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "ehyb_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
+    "ehyb_dev_sync": (C.c_int, []),
+    "ehyb_measure_read_bw": (C.c_int, [C.c_size_t, C.c_int, _dp]),
+    "ehyb_mm_read": (C.c_int, [C.c_char_p, _cfgp, _mp, _ip]),
+    "ehyb_mm_write": (C.c_int, [C.c_char_p, _mp, C.c_int]),
+    "ehyb_matrix_from_csr": (C.c_int, [C.c_int, _i64p, _ip, _dp, _cfgp, _mp]),
+    "ehyb_matrix_free": (None, [_mp]),
+    "ehyb_x_glibc": (None, [C.c_int, _dp]),
+    "ehyb_gen_banded": (C.c_int, [C.c_int, C.c_int, C.c_int, _cfgp, _mp]),
+    "ehyb_gen_fem3d": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _cfgp, _mp]),
+    "ehyb_gen_rmat": (C.c_int, [C.c_int, C.c_int64, C.c_uint64, _cfgp, _mp]),
+    "ehyb_gen_stencil2d": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _cfgp, _mp]),
+    "ehyb_gen_kkt3d": (C.c_int, [C.c_int, _cfgp, _mp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libehyb.so (once) and attach argument types.  Raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build the HIP library first "
+            "(python -c 'import __graft_entry__ as g; g.build()' or make -C ehyb_spmv_gpu_amd/csrc). "
+            "There is no CPU fallback for the EHYB multiply."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib

@@ -1,0 +1,165 @@
+// Error text, configuration defaults, the sizing heuristic and the small vector helpers.
+#include "ehyb_internal.h"
+
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+
+namespace ehyb {
+
+static thread_local char g_err[512] = "";
+
+void set_error(const char* fmt, ...)
+{
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_err, sizeof g_err, fmt, ap);
+    va_end(ap);
+}
+void clear_error() { g_err[0] = '\0'; }
+
+double wall_seconds()
+{
+    using namespace std::chrono;
+    return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+static int round_down(int v, int m) { return v / m * m; }
+
+Config resolve_config(const ehyb_config* in)
+{
+    ehyb_config z;
+    memset(&z, 0, sizeof z);
+    if (in) z = *in;
+    Config c;
+    c.window_mode = z.window_mode == EHYB_WINDOW_REFERENCE ? EHYB_WINDOW_REFERENCE : EHYB_WINDOW_HALO;
+    c.lds_doubles = z.lds_doubles > 0 ? std::min(z.lds_doubles, EHYB_LDS_MAX_DOUBLES) : 10240;
+    c.lds_doubles = std::max(kSlabRows, round_down(c.lds_doubles, 2));
+    // Rows per partition: the whole window in reference mode (convert.c:247 tests against
+    // partStart + vectorCacheSize); 5/8 of it in halo mode, the rest holds gathered columns.
+    int dflt_rows = c.window_mode == EHYB_WINDOW_REFERENCE ? c.lds_doubles : c.lds_doubles * 5 / 8;
+    c.part_rows = z.part_rows > 0 ? std::min(z.part_rows, c.lds_doubles) : dflt_rows;
+    c.part_rows = std::max(kSlabRows, round_down(c.part_rows, kSlabRows));
+    c.threads = z.threads > 0 ? z.threads : 512;
+    c.threads = std::min(1024, std::max(64, round_down(c.threads, 64)));
+    c.items_per_cu = z.items_per_cu > 0 ? z.items_per_cu : 4;
+    c.partitioner = z.partitioner;
+    c.er_seg_len = z.er_seg_len > 0 ? std::max(64, z.er_seg_len) : 4096;
+    c.host_threads = z.host_threads;
+    c.verbose = z.verbose;
+    c.seed = z.seed;
+    c.n_top = z.n_top > 1 ? z.n_top : 1;
+    c.er_threads = z.er_threads > 0 ? std::min(1024, std::max(64, round_down(z.er_threads, 64))) : 256;
+    return c;
+}
+
+}  // namespace ehyb
+
+using namespace ehyb;
+
+extern "C" {
+
+const char* ehyb_last_error(void) { return g_err; }
+const char* ehyb_version(void) { return "ehyb-mi355x 0.1.0 gfx950"; }
+
+void ehyb_config_default(ehyb_config* cfg)
+{
+    if (!cfg) return;
+    memset(cfg, 0, sizeof *cfg);
+    Config c = resolve_config(nullptr);
+    cfg->lds_doubles = c.lds_doubles;
+    cfg->part_rows = c.part_rows;
+    cfg->threads = c.threads;
+    cfg->window_mode = c.window_mode;
+    cfg->items_per_cu = c.items_per_cu;
+    cfg->partitioner = EHYB_PART_AUTO;
+    cfg->er_seg_len = c.er_seg_len;
+    cfg->er_threads = c.er_threads;
+    cfg->n_top = 1;
+}
+
+// Re-derivation of solver_test.c:53-77 / 158-182 for 256 CUs x 160 KiB LDS:
+//   reference: cache = ceil(n/(pf*82*1024))*1024 with the smallest pf whose window fits
+//              93 KiB; small matrices get kernelPerPart blocks per partition.
+//   here:      the window size is a tuning knob (cfg.part_rows), nParts follows from it
+//              with 3 % slack for the partitioner's balance, and kernelPerPart is the
+//              number of ELL work items one partition is cut into.
+int ehyb_sizing(int dimension, const ehyb_config* cfg, int* nParts, int* vectorCacheSize,
+                int* kernelPerPart)
+{
+    if (dimension <= 0) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_sizing: dimension %d", dimension);
+    Config c = resolve_config(cfg);
+    int cache = c.part_rows;
+    int64_t usable = std::max<int64_t>(kSlabRows, (int64_t)(cache * 0.97));
+    int64_t parts = (dimension + usable - 1) / usable;
+    if (c.n_top > 1) parts = (parts + c.n_top - 1) / c.n_top * c.n_top;
+    if (parts < 1) parts = 1;
+    int64_t items = (int64_t)c.items_per_cu * kNumCU;
+    int kpp = (int)std::max<int64_t>(1, (items + parts - 1) / parts);
+    if (nParts) *nParts = (int)parts;
+    if (vectorCacheSize) *vectorCacheSize = cache;
+    if (kernelPerPart) *kernelPerPart = std::min(kpp, 32767);
+    return EHYB_OK;
+}
+
+void ehyb_vector_reorder(int dimension, const double* v_in, double* v_rodr, const int* list)
+{
+    for (int i = 0; i < dimension; ++i) v_rodr[list[i]] = v_in[i];
+}
+
+void ehyb_vector_recover(int dimension, const double* v_rodr, double* v, const int* list)
+{
+    // The reference inverts the list and scatters (reordering.c:386-391); gathering through
+    // the forward list gives the same vector without the temporary.
+    for (int i = 0; i < dimension; ++i) v[i] = v_rodr[list[i]];
+}
+
+void ehyb_x_glibc(int n, double* x)
+{
+    for (int i = 0; i < n; ++i) {
+        srand((unsigned)i);
+        x[i] = (double)(rand() % 200 - 100) / 1000;
+    }
+}
+
+void ehyb_matrix_free(matrixCOO* m)
+{
+    if (!m) return;
+    free(m->rowIdx);
+    free(m->numInRow);
+    free(m->numInRow2);
+    free(m->I);
+    free(m->J);
+    free(m->V);
+    free(m->diag);
+    free(m->partBoundary);
+    free(m->reorderList);
+    memset(m, 0, sizeof *m);
+}
+
+}  // extern "C"
+
+// C++-linkage names of reordering.h (reference reordering.h:6-10).
+#include "reordering.h"
+void vectorReorder(const int dimension, const double* v_in, double* v_rodr, const int* rodr_list)
+{
+    ehyb_vector_reorder(dimension, v_in, v_rodr, rodr_list);
+}
+void vectorRecover(const int dimension, const double* v_rodr, double* v, const int* rodr_list)
+{
+    ehyb_vector_recover(dimension, v_rodr, v, rodr_list);
+}
+void matrixReorder(matrixCOO* m)
+{
+    if (ehyb_matrix_reorder(m, 1, nullptr) != EHYB_OK) {
+        fprintf(stderr, "matrixReorder: %s\n", ehyb_last_error());
+        exit(1);
+    }
+}
+void matrixReorder_unsym(matrixCOO* m)
+{
+    if (ehyb_matrix_reorder(m, 0, nullptr) != EHYB_OK) {
+        fprintf(stderr, "matrixReorder_unsym: %s\n", ehyb_last_error());
+        exit(1);
+    }
+}

@@ -1,0 +1,513 @@
+// HIP kernels for gfx950 (MI355X, CDNA4) and the device half of the C-ABI.
+//
+// Kernels (replace reference kernel.cu:43-284):
+//   ehyb_ell_kernel  one workgroup per work item {partition, slab range}:
+//                      1. stage the partition's x-window into LDS -- contiguous own segment
+//                         (coalesced) + gathered halo columns (the "explicit cache",
+//                         kernel.cu:137-141, grown to <= 160 KiB per workgroup);
+//                      2. each wave64 walks 64-row slabs: per lane one row, per step one
+//                         16-byte value pair (global_load_dwordx4, 1 KiB per wave) and one
+//                         4-byte pair of 16-bit window-local columns, two LDS gathers
+//                         (ds_read_b64) and two fp64 FMAs (kernel.cu:150-163);
+//                      3. y[row] = dot, 512 B coalesced per slab.
+//                    Static slab->wave assignment (slabs of a partition are sorted by width),
+//                    so no work-queue atomics (kernel.cu:142,164-166) and nothing to reset.
+//   ehyb_er_kernel   CSR residual: G lanes per segment (64/16/4 by segment length), strided
+//                    coalesced (col,val) reads, x gathered from global memory (L2/MALL),
+//                    wavefront shuffle reduction, y[row] += sum -- or one fp64 atomic per
+//                    segment for rows split into several segments (the working form of
+//                    kernel.cu:43-67 longRowKernel).  Runs on every multiply (the reference
+//                    skips it after the first launch: SURVEY 8 a-10 item 1).
+// No MFMA: 2 flops per 10-12 streamed bytes, HBM-bound.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <vector>
+
+#include "ehyb_internal.h"
+
+using namespace ehyb;
+
+#define HIP_TRY(expr)                                                                         \
+    do {                                                                                      \
+        hipError_t _e = (expr);                                                               \
+        if (_e != hipSuccess) {                                                               \
+            ::ehyb::set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__, __LINE__); \
+            return _e == hipErrorNoDevice ? EHYB_ERR_NO_DEVICE : EHYB_ERR_HIP;                \
+        }                                                                                     \
+    } while (0)
+
+// ------------------------------------------------------------------ ELL kernel
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
+    const int4* __restrict__ items, const int* __restrict__ part_boundary, const int* __restrict__ win_len,
+    const int* __restrict__ halo_ptr, const int* __restrict__ halo_cols,
+    const uint32_t* __restrict__ slab_pair_ptr, const int* __restrict__ slab_row,
+    const double2* __restrict__ ell_val, const uint32_t* __restrict__ ell_col, const double* __restrict__ x,
+    double* __restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    const int4 it = items[blockIdx.x];
+    const int p = it.x;
+    const int ps = part_boundary[p];
+    const int pe = part_boundary[p + 1];
+    const int wl = win_len[p];
+    const int hb = halo_ptr[p];
+    const int hn = halo_ptr[p + 1] - hb;
+
+    for (int i = threadIdx.x; i < wl; i += THREADS) win[i] = x[ps + i];
+    for (int i = threadIdx.x; i < hn; i += THREADS) win[wl + i] = x[halo_cols[hb + i]];
+    __syncthreads();
+
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int WAVES = THREADS / 64;
+
+    for (int s = it.y + wave; s < it.z; s += WAVES) {
+        const uint32_t p0 = slab_pair_ptr[s];
+        const int np = (int)(slab_pair_ptr[s + 1] - p0);
+        const double2* __restrict__ v = ell_val + (size_t)p0 * 64 + lane;
+        const uint32_t* __restrict__ c = ell_col + (size_t)p0 * 64 + lane;
+        double acc0 = 0.0, acc1 = 0.0;
+        int k = 0;
+        for (; k + 4 <= np; k += 4) {
+            const double2 v0 = v[(k + 0) * 64], v1 = v[(k + 1) * 64], v2 = v[(k + 2) * 64], v3 = v[(k + 3) * 64];
+            const uint32_t c0 = c[(k + 0) * 64], c1 = c[(k + 1) * 64], c2 = c[(k + 2) * 64], c3 = c[(k + 3) * 64];
+            acc0 = fma(v0.x, win[c0 & 0xffffu], acc0);
+            acc1 = fma(v0.y, win[c0 >> 16], acc1);
+            acc0 = fma(v1.x, win[c1 & 0xffffu], acc0);
+            acc1 = fma(v1.y, win[c1 >> 16], acc1);
+            acc0 = fma(v2.x, win[c2 & 0xffffu], acc0);
+            acc1 = fma(v2.y, win[c2 >> 16], acc1);
+            acc0 = fma(v3.x, win[c3 & 0xffffu], acc0);
+            acc1 = fma(v3.y, win[c3 >> 16], acc1);
+        }
+        for (; k < np; ++k) {
+            const double2 v0 = v[k * 64];
+            const uint32_t c0 = c[k * 64];
+            acc0 = fma(v0.x, win[c0 & 0xffffu], acc0);
+            acc1 = fma(v0.y, win[c0 >> 16], acc1);
+        }
+        const int row = slab_row[s] + lane;
+        if (row < pe) y[row] = acc0 + acc1;
+    }
+}
+
+// ------------------------------------------------------------------ residual kernel
+template <int G, int THREADS>
+__device__ __forceinline__ void er_process(int lo, int hi, int blk, const int64_t* __restrict__ seg_ptr,
+                                           const int* __restrict__ seg_row, const int* __restrict__ col,
+                                           const double* __restrict__ val, const double* __restrict__ x,
+                                           double* __restrict__ y)
+{
+    constexpr int SEGS = THREADS / G;
+    const int sub = threadIdx.x % G;
+    const int seg = lo + blk * SEGS + threadIdx.x / G;
+    double acc0 = 0.0, acc1 = 0.0;
+    if (seg < hi) {
+        const int64_t b = seg_ptr[seg], e = seg_ptr[seg + 1];
+        int64_t k = b + sub;
+        for (; k + G < e; k += 2 * G) {
+            const int ca = col[k], cb = col[k + G];
+            const double va = val[k], vb = val[k + G];
+            acc0 = fma(va, x[ca], acc0);
+            acc1 = fma(vb, x[cb], acc1);
+        }
+        if (k < e) acc0 = fma(val[k], x[col[k]], acc0);
+    }
+    double acc = acc0 + acc1;
+#pragma unroll
+    for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, G);
+    if (sub == 0 && seg < hi) {
+        const int r = seg_row[seg];
+        if (r < 0)
+            unsafeAtomicAdd(&y[r & 0x7fffffff], acc);  // row split into several segments
+        else
+            y[r] += acc;  // rows are unique among unsplit segments (kernel.cu:69-77)
+    }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void ehyb_er_kernel(int b0, int b1, int b2, int b3, int nb64, int nb16,
+                                                          const int64_t* __restrict__ seg_ptr,
+                                                          const int* __restrict__ seg_row,
+                                                          const int* __restrict__ col,
+                                                          const double* __restrict__ val,
+                                                          const double* __restrict__ x, double* __restrict__ y)
+{
+    const int blk = blockIdx.x;
+    if (blk < nb64)
+        er_process<64, THREADS>(b0, b1, blk, seg_ptr, seg_row, col, val, x, y);
+    else if (blk < nb64 + nb16)
+        er_process<16, THREADS>(b1, b2, blk - nb64, seg_ptr, seg_row, col, val, x, y);
+    else
+        er_process<4, THREADS>(b2, b3, blk - nb64 - nb16, seg_ptr, seg_row, col, val, x, y);
+}
+
+// streaming-read probe for the on-box bandwidth ceiling
+__global__ __launch_bounds__(256) void ehyb_read_kernel(const double2* __restrict__ src, size_t n2, double* sink)
+{
+    double acc = 0.0;
+    size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n2; i += stride) {
+        double2 v = src[i];
+        acc += v.x + v.y;
+    }
+    if (acc == 123.456) sink[0] = acc;  // keep the loads alive
+}
+
+// ------------------------------------------------------------------ launches
+static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st)
+{
+    const HostLayout& H = P->host;
+    const int n_items = (int)(H.items.size() / 4);
+    if (n_items == 0) return EHYB_OK;
+    const size_t lds = (((size_t)H.lds_doubles * 8) + 15) / 16 * 16;
+#define ELL_ARGS                                                                                            \
+    (const int4*)P->d_items, P->d_part_boundary, P->d_win_len, P->d_halo_ptr, P->d_halo_cols,               \
+        P->d_slab_pair_ptr, P->d_slab_row, (const double2*)P->d_ell_val, (const uint32_t*)P->d_ell_col, x, y
+    switch (P->cfg.threads) {
+        case 256: hipLaunchKernelGGL(ehyb_ell_kernel<256>, dim3(n_items), dim3(256), lds, st, ELL_ARGS); break;
+        case 512: hipLaunchKernelGGL(ehyb_ell_kernel<512>, dim3(n_items), dim3(512), lds, st, ELL_ARGS); break;
+        case 1024: hipLaunchKernelGGL(ehyb_ell_kernel<1024>, dim3(n_items), dim3(1024), lds, st, ELL_ARGS); break;
+        default: EHYB_FAIL(EHYB_ERR_ARG, "ELL workgroup size %d not built (256/512/1024)", P->cfg.threads);
+    }
+#undef ELL_ARGS
+    HIP_TRY(hipGetLastError());
+    return EHYB_OK;
+}
+
+static int launch_er(ehyb_plan* P, const double* x, double* y, hipStream_t st)
+{
+    const HostLayout& H = P->host;
+    const int b0 = H.er_bins[0], b1 = H.er_bins[1], b2 = H.er_bins[2], b3 = H.er_bins[3];
+    if (b3 == 0) return EHYB_OK;
+    constexpr int T = 256;
+    const int nb64 = ((b1 - b0) + T / 64 - 1) / (T / 64);
+    const int nb16 = ((b2 - b1) + T / 16 - 1) / (T / 16);
+    const int nb4 = ((b3 - b2) + T / 4 - 1) / (T / 4);
+    hipLaunchKernelGGL(ehyb_er_kernel<T>, dim3(nb64 + nb16 + nb4), dim3(T), 0, st, b0, b1, b2, b3, nb64, nb16,
+                       P->d_er_seg_ptr, P->d_er_seg_row, P->d_er_col, P->d_er_val, x, y);
+    HIP_TRY(hipGetLastError());
+    return EHYB_OK;
+}
+
+template <class T>
+static int upload(T** dst, const std::vector<T>& src)
+{
+    *dst = nullptr;
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    HIP_TRY(hipMalloc((void**)dst, bytes));
+    if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
+    return EHYB_OK;
+}
+
+static void free_device(ehyb_plan* P)
+{
+    void* ptrs[] = {P->d_part_boundary, P->d_win_len,     P->d_halo_ptr,  P->d_halo_cols, P->d_slab_pair_ptr,
+                    P->d_slab_row,      P->d_ell_val,     P->d_ell_col,   P->d_items,     P->d_er_seg_ptr,
+                    P->d_er_seg_row,    P->d_er_col,      P->d_er_val};
+    for (void* q : ptrs)
+        if (q) (void)hipFree(q);
+    P->d_part_boundary = P->d_win_len = P->d_halo_ptr = P->d_halo_cols = nullptr;
+    P->d_slab_pair_ptr = nullptr;
+    P->d_slab_row = P->d_items = P->d_er_seg_row = P->d_er_col = nullptr;
+    P->d_ell_val = P->d_er_val = nullptr;
+    P->d_ell_col = nullptr;
+    P->d_er_seg_ptr = nullptr;
+    P->uploaded = false;
+}
+
+extern "C" {
+
+int ehyb_device_count(int* count)
+{
+    if (!count) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_device_count: null");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        *count = 0;
+        set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+        return EHYB_ERR_NO_DEVICE;
+    }
+    *count = c;
+    return EHYB_OK;
+}
+
+int ehyb_device_set(int device)
+{
+    HIP_TRY(hipSetDevice(device));
+    return EHYB_OK;
+}
+
+int ehyb_device_name(char* buf, int len)
+{
+    if (!buf || len <= 0) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_device_name: bad buffer");
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    hipDeviceProp_t prop;
+    HIP_TRY(hipGetDeviceProperties(&prop, dev));
+    snprintf(buf, (size_t)len, "%s %s CUs=%d", prop.name, prop.gcnArchName, prop.multiProcessorCount);
+    return EHYB_OK;
+}
+
+int ehyb_dev_alloc(size_t bytes, void** ptr)
+{
+    if (!ptr) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_dev_alloc: null");
+    HIP_TRY(hipMalloc(ptr, std::max<size_t>(bytes, 8)));
+    return EHYB_OK;
+}
+int ehyb_dev_free(void* ptr)
+{
+    if (ptr) HIP_TRY(hipFree(ptr));
+    return EHYB_OK;
+}
+int ehyb_h2d(void* dst, const void* src, size_t bytes)
+{
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyHostToDevice));
+    return EHYB_OK;
+}
+int ehyb_d2h(void* dst, const void* src, size_t bytes)
+{
+    HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return EHYB_OK;
+}
+int ehyb_dev_sync(void)
+{
+    HIP_TRY(hipDeviceSynchronize());
+    return EHYB_OK;
+}
+
+int ehyb_measure_read_bw(size_t bytes, int iters, double* gbps)
+{
+    if (!gbps || iters < 1 || bytes < 4096) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_measure_read_bw: bad arguments");
+    double2* buf = nullptr;
+    double* sink = nullptr;
+    size_t n2 = bytes / sizeof(double2);
+    HIP_TRY(hipMalloc((void**)&buf, n2 * sizeof(double2)));
+    HIP_TRY(hipMalloc((void**)&sink, 8));
+    HIP_TRY(hipMemset(buf, 0x11, n2 * sizeof(double2)));
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    for (int i = 0; i < 3; ++i) hipLaunchKernelGGL(ehyb_read_kernel, dim3(4096), dim3(256), 0, 0, buf, n2, sink);
+    HIP_TRY(hipEventRecord(a, 0));
+    for (int i = 0; i < iters; ++i) hipLaunchKernelGGL(ehyb_read_kernel, dim3(4096), dim3(256), 0, 0, buf, n2, sink);
+    HIP_TRY(hipEventRecord(b, 0));
+    HIP_TRY(hipEventSynchronize(b));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    *gbps = (double)n2 * sizeof(double2) * iters / (ms * 1e-3) / 1e9;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    (void)hipFree(buf);
+    (void)hipFree(sink);
+    return EHYB_OK;
+}
+
+int ehyb_plan_upload(ehyb_plan* P)
+{
+    clear_error();
+    if (!P) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_upload: null plan");
+    if (P->uploaded) return EHYB_OK;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1)
+        EHYB_FAIL(EHYB_ERR_NO_DEVICE, "ehyb_plan_upload: no HIP device visible (the EHYB multiply has no CPU fallback)");
+    HIP_TRY(hipGetDevice(&P->device));
+    const HostLayout& H = P->host;
+    int rc;
+#define UP(dst, src)                           \
+    if ((rc = upload(&P->dst, H.src)) != EHYB_OK) { \
+        free_device(P);                        \
+        return rc;                             \
+    }
+    UP(d_part_boundary, part_boundary)
+    UP(d_win_len, win_len)
+    UP(d_halo_ptr, halo_ptr)
+    UP(d_halo_cols, halo_cols)
+    UP(d_slab_pair_ptr, slab_pair_ptr)
+    UP(d_slab_row, slab_row)
+    UP(d_ell_val, ell_val)
+    UP(d_ell_col, ell_col)
+    UP(d_items, items)
+    UP(d_er_seg_ptr, er_seg_ptr)
+    UP(d_er_seg_row, er_seg_row)
+    UP(d_er_col, er_col)
+    UP(d_er_val, er_val)
+#undef UP
+    // opt in to the full 160 KiB of LDS (the role of cudaFuncSetAttribute at kernel.cu:351,411)
+    const int lds = (int)((((size_t)H.lds_doubles * 8) + 15) / 16 * 16);
+    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    P->uploaded = true;
+    return EHYB_OK;
+}
+
+void ehyb_plan_destroy(ehyb_plan* P)
+{
+    if (!P) return;
+    free_device(P);
+    delete P;
+}
+
+int ehyb_spmv_phase(ehyb_plan* P, const double* x, double* y, void* stream, int phase)
+{
+    if (!P || !x || !y) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_spmv: null argument");
+    if (!P->uploaded) EHYB_FAIL(EHYB_ERR_STATE, "ehyb_spmv: plan not uploaded (no CPU fallback exists)");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = EHYB_OK;
+    if (phase == 0 || phase == 1) rc = launch_ell(P, x, y, st);
+    if (rc == EHYB_OK && (phase == 0 || phase == 2)) rc = launch_er(P, x, y, st);
+    return rc;
+}
+
+int ehyb_spmv(ehyb_plan* P, const double* x, double* y, void* stream)
+{
+    return ehyb_spmv_phase(P, x, y, stream, 0);
+}
+
+int ehyb_spmv_bench(ehyb_plan* P, const double* x, double* y, void* stream, int warmup, int iters,
+                    double* ms_total, double* ms_ell, double* ms_er)
+{
+    if (!P || iters < 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_spmv_bench: bad arguments");
+    hipStream_t st = (hipStream_t)stream;
+    int rc;
+    for (int i = 0; i < warmup; ++i)
+        if ((rc = ehyb_spmv(P, x, y, stream)) != EHYB_OK) return rc;
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    HIP_TRY(hipEventRecord(a, st));
+    for (int i = 0; i < iters; ++i)
+        if ((rc = ehyb_spmv(P, x, y, stream)) != EHYB_OK) return rc;
+    HIP_TRY(hipEventRecord(b, st));
+    HIP_TRY(hipEventSynchronize(b));
+    float ms = 0;
+    HIP_TRY(hipEventElapsedTime(&ms, a, b));
+    if (ms_total) *ms_total = ms;
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    if (ms_ell || ms_er) {
+        const int n = std::min(iters, 200);
+        std::vector<hipEvent_t> ev((size_t)3 * n);
+        for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
+        for (int i = 0; i < n; ++i) {
+            HIP_TRY(hipEventRecord(ev[3 * i + 0], st));
+            if ((rc = launch_ell(P, x, y, st)) != EHYB_OK) return rc;
+            HIP_TRY(hipEventRecord(ev[3 * i + 1], st));
+            if ((rc = launch_er(P, x, y, st)) != EHYB_OK) return rc;
+            HIP_TRY(hipEventRecord(ev[3 * i + 2], st));
+        }
+        HIP_TRY(hipEventSynchronize(ev.back()));
+        double se = 0, sr = 0;
+        for (int i = 0; i < n; ++i) {
+            float t1 = 0, t2 = 0;
+            HIP_TRY(hipEventElapsedTime(&t1, ev[3 * i + 0], ev[3 * i + 1]));
+            HIP_TRY(hipEventElapsedTime(&t2, ev[3 * i + 1], ev[3 * i + 2]));
+            se += t1;
+            sr += t2;
+        }
+        for (auto& e : ev) (void)hipEventDestroy(e);
+        if (ms_ell) *ms_ell = se / n;
+        if (ms_er) *ms_er = sr / n;
+    }
+    return EHYB_OK;
+}
+
+int ehyb_spmv_host(ehyb_plan* P, const double* x_host, double* y_host, int iters)
+{
+    if (!P || !x_host || !y_host || iters < 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_spmv_host: bad arguments");
+    if (!P->uploaded) EHYB_FAIL(EHYB_ERR_STATE, "ehyb_spmv_host: plan not uploaded (no CPU fallback exists)");
+    const size_t n = (size_t)P->host.n_cols;
+    double *dx = nullptr, *dy = nullptr;
+    HIP_TRY(hipMalloc((void**)&dx, n * 8));
+    HIP_TRY(hipMalloc((void**)&dy, n * 8));
+    HIP_TRY(hipMemcpy(dx, x_host, n * 8, hipMemcpyHostToDevice));
+    HIP_TRY(hipMemset(dy, 0, n * 8));
+    int rc = EHYB_OK;
+    for (int i = 0; i < iters && rc == EHYB_OK; ++i) rc = ehyb_spmv(P, dx, dy, nullptr);
+    if (rc == EHYB_OK) {
+        HIP_TRY(hipDeviceSynchronize());
+        HIP_TRY(hipMemcpy(y_host + P->host.row_begin, dy + P->host.row_begin,
+                          (size_t)(P->host.row_end - P->host.row_begin) * 8, hipMemcpyDeviceToHost));
+    }
+    (void)hipFree(dx);
+    (void)hipFree(dy);
+    return rc;
+}
+
+int ehyb_plan_create(const matrixCOO* m, const ehyb_config* cfg, ehyb_plan** plan)
+{
+    if (!m) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_create: null matrix");
+    int rc = ehyb_plan_create_host(m, 0, m->dimension, cfg, plan);
+    if (rc != EHYB_OK) return rc;
+    rc = ehyb_plan_upload(*plan);
+    if (rc != EHYB_OK) {
+        ehyb_plan_destroy(*plan);
+        *plan = nullptr;
+    }
+    return rc;
+}
+
+// The drop-in entry point (reference spmv.cu:61-133).
+int spmvGPuEHYB_status(matrixCOO* localMatrix, const double* vectorIn, double* vectorOut, const int MAXIter,
+                       int* realIter)
+{
+    clear_error();
+    if (!localMatrix || !vectorIn || !vectorOut || MAXIter < 0)
+        EHYB_FAIL(EHYB_ERR_ARG, "spmvGPuEHYB: bad arguments");
+    ehyb_config cfg;
+    ehyb_config_default(&cfg);
+    if (const char* v = getenv("EHYB_VERBOSE")) cfg.verbose = atoi(v);
+    if (const char* v = getenv("EHYB_LDS_DOUBLES")) cfg.lds_doubles = atoi(v);
+    if (const char* v = getenv("EHYB_THREADS")) cfg.threads = atoi(v);
+    if (const char* v = getenv("EHYB_WINDOW_MODE")) cfg.window_mode = atoi(v);
+    if (const char* v = getenv("EHYB_ITEMS_PER_CU")) cfg.items_per_cu = atoi(v);
+    ehyb_plan* P = nullptr;
+    int rc = ehyb_plan_create(localMatrix, &cfg, &P);  // COO2EHYB + upload (spmv.cu:73-81)
+    if (rc != EHYB_OK) return rc;
+    printf("sizeER is %lld\n", (long long)P->host.stats.size_er);  // spmv.cu:82
+    const size_t n = (size_t)localMatrix->dimension;
+    double *dx = nullptr, *dy = nullptr;
+    auto fail = [&](int code) {
+        if (dx) (void)hipFree(dx);
+        if (dy) (void)hipFree(dy);
+        ehyb_plan_destroy(P);
+        return code;
+    };
+    if (hipMalloc((void**)&dx, n * 8) != hipSuccess || hipMalloc((void**)&dy, n * 8) != hipSuccess) {
+        set_error("spmvGPuEHYB: device allocation of the vectors failed");
+        return fail(EHYB_ERR_HIP);
+    }
+    if (hipMemcpy(dx, vectorIn, n * 8, hipMemcpyHostToDevice) != hipSuccess ||
+        hipMemset(dy, 0, n * 8) != hipSuccess) {
+        set_error("spmvGPuEHYB: upload of x failed");
+        return fail(EHYB_ERR_HIP);
+    }
+    double ms = 0;
+    const int iters = std::max(1, MAXIter);
+    rc = ehyb_spmv_bench(P, dx, dy, nullptr, 10, iters, &ms, nullptr, nullptr);  // spmv.cu:100-116
+    if (rc != EHYB_OK) return fail(rc);
+    if (hipMemcpy(vectorOut, dy, n * 8, hipMemcpyDeviceToHost) != hipSuccess) {
+        set_error("spmvGPuEHYB: download of y failed");
+        return fail(EHYB_ERR_HIP);
+    }
+    printf("iter is %d, time is %f ms, GPU Gflops is %f\n ", iters, ms,
+           (1e-9 * ((double)localMatrix->totalNum * 2) * 1000 * iters) / ms);  // spmv.cu:121-122
+    if (realIter) *realIter = iters;
+    fail(EHYB_OK);
+    return EHYB_OK;
+}
+
+void spmvGPuEHYB(matrixCOO* localMatrix, const double* vectorIn, double* vectorOut, const int MAXIter,
+                 int* realIter)
+{
+    int rc = spmvGPuEHYB_status(localMatrix, vectorIn, vectorOut, MAXIter, realIter);
+    if (rc != EHYB_OK) {
+        fprintf(stderr, "spmvGPuEHYB failed (%d): %s\n", rc, ehyb_last_error());
+        exit(rc);
+    }
+}
+
+}  // extern "C"

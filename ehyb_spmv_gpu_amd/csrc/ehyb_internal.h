@@ -1,0 +1,134 @@
+// Internal declarations shared by the host builder, the partitioner and the HIP side.
+// Nothing here is part of the C-ABI (see include/ehyb.h).
+#pragma once
+#include <cstdint>
+#include <cstdarg>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+#include "ehyb.h"
+
+namespace ehyb {
+
+// ---------------------------------------------------------------- errors
+void set_error(const char* fmt, ...);
+void clear_error();
+
+#define EHYB_FAIL(code, ...)            \
+    do {                                \
+        ::ehyb::set_error(__VA_ARGS__); \
+        return (code);                  \
+    } while (0)
+
+// ---------------------------------------------------------------- config
+// Resolved configuration: every field has its final value.
+struct Config {
+    int lds_doubles;
+    int part_rows;
+    int threads;
+    int window_mode;
+    int items_per_cu;
+    int partitioner;
+    int er_seg_len;
+    int host_threads;
+    int verbose;
+    int seed;
+    int n_top;
+    int er_threads;
+};
+Config resolve_config(const ehyb_config* cfg);
+
+constexpr int kSlabRows = EHYB_SLAB_ROWS;  // one row per lane
+constexpr int kNumCU = 256;                // MI355X: 8 XCD x 32 CU
+constexpr int kErBins = 4;                 // lanes per residual segment: 4, 16, 64, 64(atomic)
+
+// ---------------------------------------------------------------- layout
+// Host image of the EHYB layout.  Device arrays mirror these one to one.
+struct HostLayout {
+    int n_cols = 0;       // dimension of the matrix (length of x)
+    int row_begin = 0;    // rows covered: [row_begin, row_end)
+    int row_end = 0;
+    int n_parts = 0;
+    int lds_doubles = 0;  // max over partitions of win_len + halo_len
+
+    // per partition
+    std::vector<int32_t> part_boundary;  // [n_parts+1] first row
+    std::vector<int32_t> win_len;        // [n_parts] contiguous window length (from part start)
+    std::vector<int32_t> halo_ptr;       // [n_parts+1]
+    std::vector<int32_t> halo_cols;      // gathered columns (global ids), ascending per part
+
+    // per slab (64 rows, one wave)
+    std::vector<uint32_t> slab_pair_ptr;  // [n_slabs+1] prefix of (width/2)
+    std::vector<int32_t> slab_row;        // [n_slabs]
+    std::vector<int32_t> slab_part;       // [n_slabs]
+
+    // ELL payload: element (pair p, lane l, half h) at ((pair_ptr[s]+p)*64 + l)*2 + h
+    std::vector<double> ell_val;
+    std::vector<uint16_t> ell_col;
+
+    // ELL work items {part, slab_begin, slab_end, 0}
+    std::vector<int32_t> items;
+
+    // residual (CSR segments sorted by length, descending)
+    std::vector<int64_t> er_seg_ptr;  // [n_seg+1]
+    std::vector<int32_t> er_seg_row;  // [n_seg] row | 0x80000000 if the row is split
+    std::vector<int32_t> er_col;
+    std::vector<double> er_val;
+    int32_t er_bins[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // seg_begin of bins 0..3, then end, pad
+
+    ehyb_stats stats{};
+};
+
+int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* out);
+
+// ---------------------------------------------------------------- partitioner
+int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vwgt, int nparts,
+                    int max_part_w, const Config& cfg, int* part, int64_t* edgecut);
+
+// Optional mt-metis backend: resolved at run time from the process image (weak symbol) --
+// see INTEGRATION.md.  Returns false when not linked.
+bool mtmetis_available();
+int mtmetis_partition(int n, const int64_t* xadj, const int* adjncy, int nparts, int nthreads,
+                      int* part, int64_t* edgecut);
+
+// ---------------------------------------------------------------- misc
+double wall_seconds();
+inline uint64_t splitmix64(uint64_t& s)
+{
+    uint64_t z = (s += 0x9E3779B97F4A7C15ull);
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+inline uint64_t mix64(uint64_t z)
+{
+    z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+    z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+    return z ^ (z >> 31);
+}
+
+}  // namespace ehyb
+
+// The plan object behind the opaque handle.
+struct ehyb_plan {
+    ehyb::Config cfg;
+    ehyb::HostLayout host;
+    bool uploaded = false;
+    int device = -1;
+    // device arrays (same names as HostLayout)
+    int32_t* d_part_boundary = nullptr;
+    int32_t* d_win_len = nullptr;
+    int32_t* d_halo_ptr = nullptr;
+    int32_t* d_halo_cols = nullptr;
+    uint32_t* d_slab_pair_ptr = nullptr;
+    int32_t* d_slab_row = nullptr;
+    double* d_ell_val = nullptr;
+    uint16_t* d_ell_col = nullptr;
+    int32_t* d_items = nullptr;
+    int64_t* d_er_seg_ptr = nullptr;
+    int32_t* d_er_seg_row = nullptr;
+    int32_t* d_er_col = nullptr;
+    double* d_er_val = nullptr;
+};

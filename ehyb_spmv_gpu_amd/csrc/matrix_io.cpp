@@ -1,0 +1,515 @@
+// Harness-side matrix sources: Matrix Market reader/writer and deterministic synthetic
+// generators.  The reader restates what matrixRead_unsym / matrixRead_sym build
+// (reference solver_test.c:31-126, 127-265) without the x/y side effects; the banner and
+// size-line grammar is the subset of mmio.c:96-217 the reference uses.
+#include "ehyb_internal.h"
+
+#include <omp.h>
+
+#include <algorithm>
+#include <cctype>
+#include <cmath>
+#include <numeric>
+
+namespace ehyb {
+namespace {
+
+int alloc_matrix(int n, int64_t nnz, matrixCOO* m)
+{
+    memset(m, 0, sizeof *m);
+    if (nnz > 0x7FFFFFFFll) EHYB_FAIL(EHYB_ERR_ARG, "matrix with %lld entries does not fit matrixCOO's int counts", (long long)nnz);
+    m->dimension = n;
+    m->totalNum = (int)nnz;
+    size_t e = (size_t)std::max<int64_t>(nnz, 1);
+    m->rowIdx = (int*)calloc((size_t)n + 1, sizeof(int));
+    m->numInRow = (int*)calloc((size_t)n + 1, sizeof(int));
+    m->numInRow2 = (int*)calloc((size_t)n + 1, sizeof(int));
+    m->partBoundary = (int*)calloc((size_t)n + 1, sizeof(int));
+    m->reorderList = (int*)calloc((size_t)n + 1, sizeof(int));
+    m->diag = (double*)calloc((size_t)n + 1, sizeof(double));
+    m->I = (int*)malloc(e * sizeof(int));
+    m->J = (int*)malloc(e * sizeof(int));
+    m->V = (double*)malloc(e * sizeof(double));
+    if (!m->rowIdx || !m->numInRow || !m->numInRow2 || !m->partBoundary || !m->reorderList || !m->diag ||
+        !m->I || !m->J || !m->V) {
+        ehyb_matrix_free(m);
+        EHYB_FAIL(EHYB_ERR_ALLOC, "out of memory for a %d-row, %lld-entry matrix", n, (long long)nnz);
+    }
+    return EHYB_OK;
+}
+
+// rowIdx from numInRow, maxCol, sizing (solver_test.c:105-124 / 208-226 and 53-77 / 158-182)
+int finish_matrix(matrixCOO* m, const ehyb_config* cfg)
+{
+    const int n = m->dimension;
+    int maxc = 0;
+    m->rowIdx[0] = 0;
+    for (int i = 0; i < n; ++i) {
+        m->rowIdx[i + 1] = m->rowIdx[i] + m->numInRow[i];
+        maxc = std::max(maxc, m->numInRow[i]);
+    }
+    m->maxCol = maxc;
+    int np = 1, cache = 0, kpp = 1;
+    int rc = ehyb_sizing(n, cfg, &np, &cache, &kpp);
+    if (rc != EHYB_OK) return rc;
+    m->nParts = np;
+    m->vectorCacheSize = (uint16_t)std::min(cache, 65535);
+    m->kernelPerPart = (int16_t)kpp;
+    m->partBoundary[0] = 0;
+    return EHYB_OK;
+}
+
+inline double hash_value(uint64_t a, uint64_t b)
+{
+    // ((31*i + 17*j) mod 200 - 100)/1000, an exact 0 replaced by 0.001
+    int64_t h = (int64_t)((31 * a + 17 * b) % 200) - 100;
+    return h == 0 ? 0.001 : (double)h / 1000.0;
+}
+inline double hash_value_mixed(uint64_t a, uint64_t b, uint64_t seed)
+{
+    int64_t h = (int64_t)(mix64(a * 0x9E3779B97F4A7C15ull ^ mix64(b + seed)) % 200) - 100;
+    return h == 0 ? 0.001 : (double)h / 1000.0;
+}
+
+}  // namespace
+}  // namespace ehyb
+
+using namespace ehyb;
+
+extern "C" {
+
+// ------------------------------------------------------------------ Matrix Market
+int ehyb_mm_read(const char* path, const ehyb_config* cfg, matrixCOO* out, int* is_symmetric)
+{
+    clear_error();
+    if (!path || !out) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_mm_read: null argument");
+    FILE* f = fopen(path, "r");
+    if (!f) EHYB_FAIL(EHYB_ERR_IO, "file read error: %s", path);
+    char line[1100];
+    if (!fgets(line, sizeof line, f)) {
+        fclose(f);
+        EHYB_FAIL(EHYB_ERR_FORMAT, "Could not process Matrix Market banner.");
+    }
+    char banner[64], object[64], format[64], field[64], symm[64];
+    if (sscanf(line, "%63s %63s %63s %63s %63s", banner, object, format, field, symm) != 5) {
+        fclose(f);
+        EHYB_FAIL(EHYB_ERR_FORMAT, "Could not process Matrix Market banner.");
+    }
+    auto lower = [](char* s) {
+        for (; *s; ++s) *s = (char)tolower((unsigned char)*s);
+    };
+    lower(object), lower(format), lower(field), lower(symm);
+    if (strcmp(banner, "%%MatrixMarket") != 0 || strcmp(object, "matrix") != 0) {
+        fclose(f);
+        EHYB_FAIL(EHYB_ERR_FORMAT, "Could not process Matrix Market banner.");
+    }
+    if (strcmp(format, "coordinate") != 0) {
+        fclose(f);
+        EHYB_FAIL(EHYB_ERR_FORMAT, "only coordinate (sparse) Matrix Market files are supported, got '%s'", format);
+    }
+    const bool pattern = strcmp(field, "pattern") == 0;
+    if (!pattern && strcmp(field, "real") != 0 && strcmp(field, "integer") != 0 && strcmp(field, "double") != 0) {
+        fclose(f);  // solver_test.c:339-345 rejects complex
+        EHYB_FAIL(EHYB_ERR_FORMAT, "Sorry, this application does not support Market Market type: [%s %s %s %s]", object, format, field, symm);
+    }
+    const bool sym = strcmp(symm, "symmetric") == 0;
+    const bool skew = strcmp(symm, "skew-symmetric") == 0;
+    if (!sym && !skew && strcmp(symm, "general") != 0) {
+        fclose(f);
+        EHYB_FAIL(EHYB_ERR_FORMAT, "unsupported Matrix Market symmetry '%s'", symm);
+    }
+    // size line: first non-comment, non-blank line (mmio.c:189-217)
+    long M = 0, N = 0, stored = 0;
+    for (;;) {
+        if (!fgets(line, sizeof line, f)) {
+            fclose(f);
+            EHYB_FAIL(EHYB_ERR_FORMAT, "premature end of file before the size line");
+        }
+        if (line[0] == '%') continue;
+        if (sscanf(line, "%ld %ld %ld", &M, &N, &stored) == 3) break;
+    }
+    if (M <= 0 || M != N || stored < 0 || M > 0x7FFFFFF0l) {
+        fclose(f);
+        EHYB_FAIL(EHYB_ERR_FORMAT, "size line %ld x %ld with %ld entries: a square matrix is required", M, N, stored);
+    }
+    const int n = (int)M;
+    std::vector<int> fi((size_t)stored), fj((size_t)stored);
+    std::vector<double> fv((size_t)stored);
+    for (long k = 0; k < stored; ++k) {
+        int a = 0, b = 0;
+        double v = 1.0;
+        int got = pattern ? fscanf(f, "%d %d", &a, &b) : fscanf(f, "%d %d %lg", &a, &b, &v);
+        if (got != (pattern ? 2 : 3) || a < 1 || b < 1 || a > n || b > n) {
+            fclose(f);
+            EHYB_FAIL(EHYB_ERR_FORMAT, "bad entry %ld of %ld in %s", k + 1, stored, path);
+        }
+        fi[k] = a - 1;  // 1-based -> 0-based (solver_test.c:98-99, 198-199)
+        fj[k] = b - 1;
+        fv[k] = v;
+    }
+    fclose(f);
+
+    const bool mirror = sym || skew;
+    int64_t total = stored;
+    if (mirror)
+        for (long k = 0; k < stored; ++k) total += fi[k] != fj[k];
+    int rc = alloc_matrix(n, total, out);
+    if (rc != EHYB_OK) return rc;
+    for (long k = 0; k < stored; ++k) {
+        out->numInRow[fi[k]]++;
+        if (mirror && fi[k] != fj[k]) out->numInRow[fj[k]]++;
+    }
+    rc = finish_matrix(out, cfg);
+    if (rc != EHYB_OK) {
+        ehyb_matrix_free(out);
+        return rc;
+    }
+    // placement in file order, the mirrored entry right after its original
+    // (solver_test.c:235-255); for general files this groups rows stably, which leaves the
+    // per-row accumulation order of solver_test.c:102 unchanged.
+    std::vector<int> fill((size_t)n, 0);
+    for (long k = 0; k < stored; ++k) {
+        int a = fi[k], b = fj[k];
+        int64_t at = (int64_t)out->rowIdx[a] + fill[a]++;
+        out->I[at] = a;
+        out->J[at] = b;
+        out->V[at] = fv[k];
+        if (a == b) out->diag[a] = fv[k];
+        if (mirror && a != b) {
+            int64_t at2 = (int64_t)out->rowIdx[b] + fill[b]++;
+            out->I[at2] = b;
+            out->J[at2] = a;
+            out->V[at2] = skew ? -fv[k] : fv[k];
+        }
+    }
+    if (is_symmetric) *is_symmetric = mirror ? 1 : 0;
+    return EHYB_OK;
+}
+
+int ehyb_mm_write(const char* path, const matrixCOO* m, int symmetric_lower_only)
+{
+    if (!path || !m) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_mm_write: null argument");
+    FILE* f = fopen(path, "w");
+    if (!f) EHYB_FAIL(EHYB_ERR_IO, "cannot write %s", path);
+    int64_t cnt = 0;
+    for (int k = 0; k < m->totalNum; ++k) cnt += !symmetric_lower_only || m->I[k] >= m->J[k];
+    fprintf(f, "%%%%MatrixMarket matrix coordinate real %s\n", symmetric_lower_only ? "symmetric" : "general");
+    fprintf(f, "%d %d %lld\n", m->dimension, m->dimension, (long long)cnt);
+    for (int k = 0; k < m->totalNum; ++k)
+        if (!symmetric_lower_only || m->I[k] >= m->J[k]) fprintf(f, "%d %d %.17g\n", m->I[k] + 1, m->J[k] + 1, m->V[k]);
+    fclose(f);
+    return EHYB_OK;
+}
+
+int ehyb_matrix_from_csr(int n, const int64_t* rowptr, const int* cols, const double* vals,
+                         const ehyb_config* cfg, matrixCOO* out)
+{
+    clear_error();
+    if (!out || n <= 0 || !rowptr || rowptr[0] != 0 || rowptr[n] < 0 || (rowptr[n] > 0 && (!cols || !vals)))
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_from_csr: bad arguments");
+    int rc = alloc_matrix(n, rowptr[n], out);
+    if (rc != EHYB_OK) return rc;
+    for (int i = 0; i < n; ++i) {
+        if (rowptr[i + 1] < rowptr[i]) {
+            ehyb_matrix_free(out);
+            EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_from_csr: rowptr not monotone at %d", i);
+        }
+        out->numInRow[i] = (int)(rowptr[i + 1] - rowptr[i]);
+    }
+    rc = finish_matrix(out, cfg);
+    if (rc != EHYB_OK) return rc;
+    for (int i = 0; i < n; ++i)
+        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; ++k) {
+            if ((unsigned)cols[k] >= (unsigned)n) {
+                ehyb_matrix_free(out);
+                EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_from_csr: column %d outside [0,%d)", cols[k], n);
+            }
+            out->I[k] = i;
+            out->J[k] = cols[k];
+            out->V[k] = vals[k];
+            if (cols[k] == i) out->diag[i] = vals[k];
+        }
+    return EHYB_OK;
+}
+
+// ------------------------------------------------------------------ generators
+int ehyb_gen_banded(int n, int band, int block, const ehyb_config* cfg, matrixCOO* out)
+{
+    clear_error();
+    if (!out || n <= 0 || band <= 0 || block <= 0 || band > block || n % block != 0)
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_banded: need n %% block == 0 and band <= block");
+    int rc = alloc_matrix(n, (int64_t)n * band, out);
+    if (rc != EHYB_OK) return rc;
+    for (int i = 0; i < n; ++i) out->numInRow[i] = band;
+    rc = finish_matrix(out, cfg);
+    if (rc != EHYB_OK) return rc;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        int base = i / block * block, r = i % block;
+        int64_t at = (int64_t)i * band;
+        for (int d = 0; d < band; ++d) {
+            int j = base + ((r + d - band / 2) % block + block) % block;
+            out->I[at + d] = i;
+            out->J[at + d] = j;
+            out->V[at + d] = hash_value((uint64_t)i, (uint64_t)j);
+            if (i == j) out->diag[i] = out->V[at + d];
+        }
+    }
+    return EHYB_OK;
+}
+
+int ehyb_gen_fem3d(int n, int dof, int nx, int ny, int extra_ppm, int scramble, uint64_t seed,
+                   const ehyb_config* cfg, matrixCOO* out)
+{
+    clear_error();
+    if (!out || n <= 0 || dof <= 0 || nx <= 0 || ny <= 0 || n % dof != 0 || extra_ppm < 0)
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_fem3d: need n %% dof == 0 and positive grid sizes");
+    const int N = n / dof;
+    const int64_t layer = (int64_t)nx * ny;
+    const int nz = (int)((N + layer - 1) / layer);
+    std::vector<int> perm(N);
+    std::iota(perm.begin(), perm.end(), 0);
+    if (scramble) {
+        uint64_t s = seed ^ 0xABCDEF12345ull;
+        for (int i = N - 1; i > 0; --i) std::swap(perm[i], perm[(int)(splitmix64(s) % (uint64_t)(i + 1))]);
+    }
+    const uint64_t thr = (uint64_t)extra_ppm;
+    // neighbours of grid node g (grid numbering), including g itself
+    auto neighbours = [&](int g, int* nb) {
+        int ix = (int)(g % nx), iy = (int)((g / nx) % ny), iz = (int)(g / layer);
+        int c = 0;
+        for (int dz = -2; dz <= 2; ++dz)
+            for (int dy = -2; dy <= 2; ++dy)
+                for (int dx = -2; dx <= 2; ++dx) {
+                    int x = ix + dx, y = iy + dy, z = iz + dz;
+                    if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) continue;
+                    int64_t h = (int64_t)z * layer + (int64_t)y * nx + x;
+                    if (h >= N) continue;
+                    bool near = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+                    if (!near) {
+                        if (thr == 0) continue;
+                        uint64_t lo = std::min<int64_t>(g, h), hi = std::max<int64_t>(g, h);
+                        if (mix64(lo * 0x100000001B3ull + hi + seed) % 1000000ull >= thr) continue;
+                    }
+                    nb[c++] = (int)h;
+                }
+        return c;
+    };
+    // pass 1: row counts
+    std::vector<int> cnt(N);
+#pragma omp parallel for schedule(static, 1024)
+    for (int g = 0; g < N; ++g) {
+        int nb[125];
+        cnt[perm[g]] = neighbours(g, nb);
+    }
+    int64_t pairs = 0;
+    for (int a = 0; a < N; ++a) pairs += cnt[a];
+    int rc = alloc_matrix(n, pairs * dof * dof, out);
+    if (rc != EHYB_OK) return rc;
+    for (int a = 0; a < N; ++a)
+        for (int d = 0; d < dof; ++d) out->numInRow[a * dof + d] = cnt[a] * dof;
+    rc = finish_matrix(out, cfg);
+    if (rc != EHYB_OK) return rc;
+    // pass 2: fill, columns ascending within a row
+#pragma omp parallel for schedule(static, 1024)
+    for (int g = 0; g < N; ++g) {
+        int nb[125];
+        int c = neighbours(g, nb);
+        for (int k = 0; k < c; ++k) nb[k] = perm[nb[k]];
+        std::sort(nb, nb + c);
+        const int a = perm[g];
+        for (int d = 0; d < dof; ++d) {
+            const int i = a * dof + d;
+            int64_t at = out->rowIdx[i];
+            for (int k = 0; k < c; ++k)
+                for (int e = 0; e < dof; ++e) {
+                    const int j = nb[k] * dof + e;
+                    out->I[at] = i;
+                    out->J[at] = j;
+                    double v = hash_value_mixed((uint64_t)std::min(i, j), (uint64_t)std::max(i, j), seed);
+                    out->V[at] = v;
+                    if (i == j) out->diag[i] = v;
+                    ++at;
+                }
+        }
+    }
+    return EHYB_OK;
+}
+
+int ehyb_gen_rmat(int scale, int64_t edges, uint64_t seed, const ehyb_config* cfg, matrixCOO* out)
+{
+    clear_error();
+    if (!out || scale < 1 || scale > 30 || edges < 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_rmat: bad arguments");
+    const int n = 1 << scale;
+    std::vector<int> ei((size_t)edges), ej((size_t)edges);
+    // (a,b,c,d) = (0.57,0.19,0.19,0.05); every edge has its own generator state, so the
+    // result does not depend on the thread count
+#pragma omp parallel for schedule(static, 65536)
+    for (int64_t e = 0; e < edges; ++e) {
+        uint64_t s = mix64(seed * 0x9E3779B97F4A7C15ull + (uint64_t)e);
+        int i = 0, j = 0;
+        for (int l = 0; l < scale; ++l) {
+            uint32_t r = (uint32_t)(splitmix64(s) >> 40) % 100;  // percent
+            int bi, bj;
+            if (r < 57) bi = 0, bj = 0;
+            else if (r < 76) bi = 0, bj = 1;
+            else if (r < 95) bi = 1, bj = 0;
+            else bi = 1, bj = 1;
+            i = (i << 1) | bi;
+            j = (j << 1) | bj;
+        }
+        ei[e] = i;
+        ej[e] = j;
+    }
+    // group by row, sort + unique the columns of each row
+    std::vector<int64_t> rp((size_t)n + 1, 0);
+    for (int64_t e = 0; e < edges; ++e) rp[ei[e] + 1]++;
+    for (int i = 0; i < n; ++i) rp[i + 1] += rp[i];
+    std::vector<int> cols((size_t)edges);
+    {
+        std::vector<int64_t> fill(rp.begin(), rp.end() - 1);
+        for (int64_t e = 0; e < edges; ++e) cols[fill[ei[e]]++] = ej[e];
+    }
+    std::vector<int>().swap(ei);
+    std::vector<int>().swap(ej);
+    std::vector<int> ucnt(n);
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int i = 0; i < n; ++i) {
+        auto b = cols.begin() + rp[i], e = cols.begin() + rp[i + 1];
+        std::sort(b, e);
+        ucnt[i] = (int)(std::unique(b, e) - b);
+    }
+    int64_t nnz = 0;
+    for (int i = 0; i < n; ++i) nnz += ucnt[i];
+    int rc = alloc_matrix(n, nnz, out);
+    if (rc != EHYB_OK) return rc;
+    for (int i = 0; i < n; ++i) out->numInRow[i] = ucnt[i];
+    rc = finish_matrix(out, cfg);
+    if (rc != EHYB_OK) return rc;
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int i = 0; i < n; ++i) {
+        int64_t at = out->rowIdx[i];
+        for (int k = 0; k < ucnt[i]; ++k) {
+            int j = cols[rp[i] + k];
+            out->I[at + k] = i;
+            out->J[at + k] = j;
+            out->V[at + k] = hash_value_mixed((uint64_t)i, (uint64_t)j, seed);
+            if (i == j) out->diag[i] = out->V[at + k];
+        }
+    }
+    return EHYB_OK;
+}
+
+int ehyb_gen_stencil2d(int nx, int ny, int points, int extra, uint64_t seed, const ehyb_config* cfg,
+                       matrixCOO* out)
+{
+    clear_error();
+    if (!out || nx <= 0 || ny <= 0 || (points != 5 && points != 9) || extra < 0)
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_stencil2d: bad arguments");
+    const int n = nx * ny;
+    std::vector<std::vector<int>> adj(n);
+    for (int y = 0; y < ny; ++y)
+        for (int x = 0; x < nx; ++x) {
+            int i = y * nx + x;
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    if (points == 5 && dx != 0 && dy != 0) continue;
+                    int xx = x + dx, yy = y + dy;
+                    if (xx < 0 || yy < 0 || xx >= nx || yy >= ny) continue;
+                    adj[i].push_back(yy * nx + xx);
+                }
+        }
+    uint64_t s = seed + 77;
+    for (int k = 0; k < extra; ++k) {
+        int a = (int)(splitmix64(s) % (uint64_t)n), b = (int)(splitmix64(s) % (uint64_t)n);
+        if (a == b) continue;
+        adj[a].push_back(b);
+        adj[b].push_back(a);
+    }
+    int64_t nnz = 0;
+    for (int i = 0; i < n; ++i) {
+        std::sort(adj[i].begin(), adj[i].end());
+        adj[i].erase(std::unique(adj[i].begin(), adj[i].end()), adj[i].end());
+        nnz += (int64_t)adj[i].size();
+    }
+    int rc = alloc_matrix(n, nnz, out);
+    if (rc != EHYB_OK) return rc;
+    for (int i = 0; i < n; ++i) out->numInRow[i] = (int)adj[i].size();
+    rc = finish_matrix(out, cfg);
+    if (rc != EHYB_OK) return rc;
+    for (int i = 0; i < n; ++i) {
+        int64_t at = out->rowIdx[i];
+        for (int j : adj[i]) {
+            out->I[at] = i;
+            out->J[at] = j;
+            out->V[at] = hash_value_mixed((uint64_t)std::min(i, j), (uint64_t)std::max(i, j), seed);
+            if (i == j) out->diag[i] = out->V[at];
+            ++at;
+        }
+    }
+    return EHYB_OK;
+}
+
+// KKT-like saddle point system [H A^T; A 0] on an nx^3 grid: H = 7-point stencil, A couples a
+// constraint to the 19 primal unknowns within one face/edge step; the zero block keeps an
+// explicit zero diagonal, as nlpkkt200 stores it.
+int ehyb_gen_kkt3d(int nx, const ehyb_config* cfg, matrixCOO* out)
+{
+    clear_error();
+    if (!out || nx < 2 || (int64_t)nx * nx * nx * 2 > 0x7FFFFFF0ll) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_kkt3d: bad size");
+    const int n1 = nx * nx * nx, n = 2 * n1;
+    auto id = [&](int x, int y, int z) { return (z * nx + y) * nx + x; };
+    auto inside = [&](int x, int y, int z) { return x >= 0 && y >= 0 && z >= 0 && x < nx && y < nx && z < nx; };
+    auto row_cols = [&](int i, int* c) {
+        int k = 0;
+        const bool primal = i < n1;
+        const int g = primal ? i : i - n1;
+        const int x = g % nx, y = (g / nx) % nx, z = g / (nx * nx);
+        for (int dz = -1; dz <= 1; ++dz)
+            for (int dy = -1; dy <= 1; ++dy)
+                for (int dx = -1; dx <= 1; ++dx) {
+                    int man = abs(dx) + abs(dy) + abs(dz);
+                    if (man == 3 || !inside(x + dx, y + dy, z + dz)) continue;
+                    int h = id(x + dx, y + dy, z + dz);
+                    if (primal) {
+                        if (man <= 1) c[k++] = h;  // H
+                        c[k++] = n1 + h;           // A^T
+                    } else {
+                        c[k++] = h;  // A
+                    }
+                }
+        if (!primal) c[k++] = i;  // explicit zero diagonal
+        std::sort(c, c + k);
+        return k;
+    };
+    std::vector<int> cnt(n);
+#pragma omp parallel for schedule(static, 4096)
+    for (int i = 0; i < n; ++i) {
+        int c[64];
+        cnt[i] = row_cols(i, c);
+    }
+    int64_t nnz = 0;
+    for (int i = 0; i < n; ++i) nnz += cnt[i];
+    int rc = alloc_matrix(n, nnz, out);
+    if (rc != EHYB_OK) return rc;
+    for (int i = 0; i < n; ++i) out->numInRow[i] = cnt[i];
+    rc = finish_matrix(out, cfg);
+    if (rc != EHYB_OK) return rc;
+#pragma omp parallel for schedule(static, 4096)
+    for (int i = 0; i < n; ++i) {
+        int c[64];
+        int k = row_cols(i, c);
+        int64_t at = out->rowIdx[i];
+        for (int q = 0; q < k; ++q) {
+            int j = c[q];
+            out->I[at + q] = i;
+            out->J[at + q] = j;
+            double v = (i >= n1 && j == i) ? 0.0 : hash_value_mixed((uint64_t)std::min(i, j), (uint64_t)std::max(i, j), 7);
+            out->V[at + q] = v;
+            if (i == j) out->diag[i] = v;
+        }
+    }
+    return EHYB_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,284 @@
+// Host pre-step: partition, renumber, permute (the role of reference reordering.c).
+//
+//   reference                                   here
+//   matrixReorder        reordering.c:231-378   ehyb_matrix_reorder(m, 1, cfg)
+//   matrixReorder_unsym  reordering.c:41-228    ehyb_matrix_reorder(m, 0, cfg)
+//   sortRordrList        reordering.c:18-39     stable per-partition sort below
+//
+// Same observable contract: reorderList[old] = new, partition-contiguous numbering, rows of
+// a partition ordered by their in-partition entry count (descending), I/J/V replaced by the
+// permuted row-grouped arrays, numInRow2 = entries inside [partStart, partStart+cache).
+// Differences: the partitioner is built in (mt-metis optional, see mtmetis_* below); ties in
+// the row sort keep the old order (qsort leaves them unspecified); all scratch is zeroed
+// (reordering.c:55,60 reads an un-initialised counter array) and freed.
+#include "ehyb_internal.h"
+
+#include <dlfcn.h>
+
+#include <algorithm>
+#include <numeric>
+
+namespace ehyb {
+
+// ------------------------------------------------------------------ mt-metis (optional)
+// Types as built by default in mtmetis.h:52-82 (32-bit ids, float reals).
+typedef int (*mtmetis_kway_fn)(const uint32_t* nvtxs, const uint32_t* ncon, const uint32_t* xadj,
+                               const uint32_t* adjncy, const int32_t* vwgt, const uint32_t* vsize,
+                               const int32_t* adjwgt, const uint32_t* nparts, const float* tpwgts,
+                               const float* ubvec, const double* options, int32_t* r_edgecut,
+                               uint32_t* where);
+typedef double* (*mtmetis_opts_fn)(void);
+
+static mtmetis_kway_fn g_kway = nullptr;
+static mtmetis_opts_fn g_opts = nullptr;
+static bool g_mtmetis_probed = false;
+
+bool mtmetis_available()
+{
+    if (!g_mtmetis_probed) {
+        g_mtmetis_probed = true;
+        void* h = RTLD_DEFAULT;
+        if (const char* lib = getenv("EHYB_MTMETIS_LIB")) {
+            void* dl = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
+            if (dl) h = dl;
+        }
+        g_kway = (mtmetis_kway_fn)dlsym(h, "MTMETIS_PartGraphKway");
+        g_opts = (mtmetis_opts_fn)dlsym(h, "mtmetis_init_options");
+    }
+    return g_kway && g_opts;
+}
+
+// Same call as reordering.c:270-293: ncon 1, no weights, ubvec 1.001, NTHREADS option.
+int mtmetis_partition(int n, const int64_t* xadj, const int* adjncy, int nparts, int nthreads,
+                      int* part, int64_t* edgecut)
+{
+    if (!mtmetis_available()) EHYB_FAIL(EHYB_ERR_STATE, "mt-metis is not linked into this process");
+    if (xadj[n] > 0xFFFFFFFFll) EHYB_FAIL(EHYB_ERR_ARG, "mt-metis (32-bit build): too many edges");
+    std::vector<uint32_t> x32(n + 1), a32((size_t)xadj[n]);
+    for (int i = 0; i <= n; ++i) x32[i] = (uint32_t)xadj[i];
+    for (int64_t e = 0; e < xadj[n]; ++e) a32[e] = (uint32_t)adjncy[e];
+    uint32_t nv = (uint32_t)n, ncon = 1, np = (uint32_t)nparts;
+    float ub = 1.001f;
+    double* opts = g_opts();
+    opts[2 /* MTMETIS_OPTION_NTHREADS, mtmetis.h:101 */] = nthreads > 0 ? nthreads : 1;
+    int32_t cut = 0;
+    std::vector<uint32_t> where(n);
+    int rc = g_kway(&nv, &ncon, x32.data(), a32.data(), nullptr, nullptr, nullptr, &np, nullptr, &ub,
+                    opts, &cut, where.data());
+    free(opts);
+    if (rc != 1 /* MTMETIS_SUCCESS */) EHYB_FAIL(EHYB_ERR_INTERNAL, "MTMETIS_PartGraphKway returned %d", rc);
+    for (int i = 0; i < n; ++i) part[i] = (int)where[i];
+    if (edgecut) *edgecut = cut;
+    return EHYB_OK;
+}
+
+// ------------------------------------------------------------------ adjacency
+// Undirected pattern of the matrix without self loops.  symmetric_pattern: every (i,j) has its
+// (j,i) stored, so the entries are the adjacency; otherwise both directions are added for
+// every entry, as reordering.c:56-89 does (duplicates are harmless: they become edge weight).
+static void build_adjacency(const matrixCOO* m, bool symmetric_pattern, std::vector<int64_t>* xadj,
+                            std::vector<int>* adj)
+{
+    const int n = m->dimension;
+    const int64_t nnz = m->totalNum;
+    xadj->assign((size_t)n + 1, 0);
+    for (int64_t k = 0; k < nnz; ++k) {
+        int i = m->I[k], j = m->J[k];
+        if (i == j) continue;
+        (*xadj)[i + 1]++;
+        if (!symmetric_pattern) (*xadj)[j + 1]++;
+    }
+    for (int i = 0; i < n; ++i) (*xadj)[i + 1] += (*xadj)[i];
+    adj->assign((size_t)(*xadj)[n], 0);
+    std::vector<int64_t> fill(xadj->begin(), xadj->end() - 1);
+    for (int64_t k = 0; k < nnz; ++k) {
+        int i = m->I[k], j = m->J[k];
+        if (i == j) continue;
+        (*adj)[fill[i]++] = j;
+        if (!symmetric_pattern) (*adj)[fill[j]++] = i;
+    }
+}
+
+}  // namespace ehyb
+
+using namespace ehyb;
+
+extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const ehyb_config* cfg)
+{
+    clear_error();
+    if (!m || m->dimension <= 0 || m->totalNum < 0 || !m->I || !m->J || !m->V || !m->rowIdx ||
+        !m->numInRow || !m->numInRow2 || !m->partBoundary || !m->reorderList)
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_reorder: incomplete matrixCOO");
+    Config c = resolve_config(cfg);
+    const int n = m->dimension;
+    const int64_t nnz = m->totalNum;
+    int nparts = m->nParts;
+    if (nparts < 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_reorder: nParts = %d (call ehyb_sizing first)", nparts);
+    for (int64_t k = 0; k < nnz; ++k)
+        if ((unsigned)m->I[k] >= (unsigned)n || (unsigned)m->J[k] >= (unsigned)n)
+            EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_reorder: entry %lld (%d,%d) outside a %d x %d matrix",
+                      (long long)k, m->I[k], m->J[k], n, n);
+    if (c.verbose) printf("nParts is %d\n", nparts);
+
+    int cache = m->vectorCacheSize > 0 ? (int)m->vectorCacheSize : c.part_rows;
+    int cap = std::max<int64_t>(cache, ((int64_t)n + nparts - 1) / nparts);
+
+    // ---- partition (reordering.c:116-139 / 270-293)
+    std::vector<int> part(n, 0);
+    {
+        std::vector<int64_t> xadj;
+        std::vector<int> adj;
+        build_adjacency(m, symmetric_pattern != 0, &xadj, &adj);
+        const double t0 = wall_seconds();
+        int64_t cut = 0;
+        int rc;
+        if (c.partitioner == EHYB_PART_MTMETIS) {
+            rc = mtmetis_partition(n, xadj.data(), adj.data(), nparts, symmetric_pattern ? 1 : 6, part.data(), &cut);
+        } else {
+            rc = partition_graph(n, xadj.data(), adj.data(), nullptr, nparts, cap, c, part.data(), &cut);
+        }
+        if (rc != EHYB_OK) return rc;
+        if (c.verbose)
+            printf("partition time is %ld us, edge cut %lld\n", (long)((wall_seconds() - t0) * 1e6), (long long)cut);
+    }
+
+    // ---- partition-contiguous numbering in old order (reordering.c:301-321)
+    std::vector<int> part_size(nparts, 0);
+    for (int i = 0; i < n; ++i) {
+        if ((unsigned)part[i] >= (unsigned)nparts) EHYB_FAIL(EHYB_ERR_INTERNAL, "partitioner returned part %d", part[i]);
+        part_size[part[i]]++;
+    }
+    int* pb = m->partBoundary;
+    pb[0] = 0;
+    for (int p = 0; p < nparts; ++p) pb[p + 1] = pb[p] + part_size[p];
+
+    // in-partition entry count per old row (reordering.c:327-331)
+    std::vector<int> inpart(n, 0);
+    for (int64_t k = 0; k < nnz; ++k)
+        if (part[m->I[k]] == part[m->J[k]]) inpart[m->I[k]]++;
+
+    // rows of each partition, old order, then stable sort by inpart descending (reordering.c:334)
+    std::vector<int> rows_of(n);
+    {
+        std::vector<int> fill(pb, pb + nparts);
+        for (int i = 0; i < n; ++i) rows_of[fill[part[i]]++] = i;
+    }
+    if (c.window_mode == EHYB_WINDOW_HALO) {
+        // The sort key is "entries the ELL kernel will take".  With a halo window that is the
+        // in-partition count plus the entries whose column is among the partition's most
+        // referenced outside columns (same selection rule as build_layout).
+#pragma omp parallel
+        {
+            std::vector<int> cand;
+            std::vector<std::pair<int, int>> uniq;
+#pragma omp for schedule(dynamic, 4)
+            for (int p = 0; p < nparts; ++p) {
+                const int own = pb[p + 1] - pb[p];
+                const int hcap = c.lds_doubles - own;
+                if (hcap <= 0) continue;
+                cand.clear();
+                for (int q = pb[p]; q < pb[p + 1]; ++q) {
+                    int i = rows_of[q];
+                    for (int k = m->rowIdx[i]; k < m->rowIdx[i + 1]; ++k)
+                        if (m->I[k] == i && part[m->J[k]] != p) cand.push_back(m->J[k]);
+                }
+                if (cand.empty()) continue;
+                std::sort(cand.begin(), cand.end());
+                uniq.clear();
+                for (size_t a = 0; a < cand.size();) {
+                    size_t b = a;
+                    while (b < cand.size() && cand[b] == cand[a]) ++b;
+                    uniq.push_back({(int)(b - a), cand[a]});
+                    a = b;
+                }
+                if ((int)uniq.size() > hcap) {
+                    std::nth_element(uniq.begin(), uniq.begin() + hcap, uniq.end(),
+                                     [](const std::pair<int, int>& x, const std::pair<int, int>& y) {
+                                         return x.first != y.first ? x.first > y.first : x.second < y.second;
+                                     });
+                    uniq.resize(hcap);
+                }
+                cand.resize(uniq.size());
+                for (size_t a = 0; a < uniq.size(); ++a) cand[a] = uniq[a].second;
+                std::sort(cand.begin(), cand.end());
+                for (int q = pb[p]; q < pb[p + 1]; ++q) {
+                    int i = rows_of[q];
+                    for (int k = m->rowIdx[i]; k < m->rowIdx[i + 1]; ++k)
+                        if (m->I[k] == i && part[m->J[k]] != p && std::binary_search(cand.begin(), cand.end(), m->J[k]))
+                            inpart[i]++;
+                }
+            }
+        }
+    }
+#pragma omp parallel for schedule(dynamic, 8)
+    for (int p = 0; p < nparts; ++p)
+        std::stable_sort(rows_of.begin() + pb[p], rows_of.begin() + pb[p + 1],
+                         [&](int a, int b) { return inpart[a] > inpart[b]; });
+    int* list = m->reorderList;
+    for (int pos = 0; pos < n; ++pos) list[rows_of[pos]] = pos;
+
+    // ---- permuted CSR (reordering.c:335-362)
+    int* num = m->numInRow;
+    int* num2 = m->numInRow2;
+    int* rp = m->rowIdx;
+    std::fill(num, num + n, 0);
+    std::fill(num2, num2 + n, 0);
+    for (int64_t k = 0; k < nnz; ++k) num[list[m->I[k]]]++;
+    rp[0] = 0;
+    int maxcol = 0;
+    for (int i = 0; i < n; ++i) {
+        rp[i + 1] = rp[i] + num[i];
+        maxcol = std::max(maxcol, num[i]);
+    }
+    int* nI = (int*)malloc(sizeof(int) * (size_t)std::max<int64_t>(nnz, 1));
+    int* nJ = (int*)malloc(sizeof(int) * (size_t)std::max<int64_t>(nnz, 1));
+    double* nV = (double*)malloc(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1));
+    if (!nI || !nJ || !nV) {
+        free(nI);
+        free(nJ);
+        free(nV);
+        EHYB_FAIL(EHYB_ERR_ALLOC, "ehyb_matrix_reorder: out of memory for %lld entries", (long long)nnz);
+    }
+    std::vector<int> fill(n, 0);
+    for (int64_t k = 0; k < nnz; ++k) {
+        int oi = m->I[k];
+        int ti = list[oi], tj = list[m->J[k]];
+        int64_t dst = (int64_t)rp[ti] + fill[ti]++;
+        nI[dst] = ti;
+        nJ[dst] = tj;
+        nV[dst] = m->V[k];
+        int ps = pb[part[oi]];
+        if (tj >= ps && tj < ps + cache) num2[ti]++;
+    }
+    free(m->I);
+    free(m->J);
+    free(m->V);
+    m->I = nI;
+    m->J = nJ;
+    m->V = nV;
+    m->maxCol = maxcol;
+    return EHYB_OK;
+}
+
+extern "C" int ehyb_top_boundary(const matrixCOO* m, const ehyb_config* cfg, int n_top, int* part_of_block)
+{
+    if (!m || !part_of_block || n_top < 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_top_boundary: bad arguments");
+    (void)cfg;
+    // Blocks are runs of whole partitions with (nearly) equal entry counts.
+    const int np = m->nParts;
+    std::vector<int64_t> w(np + 1, 0);
+    for (int p = 0; p < np; ++p)
+        w[p + 1] = w[p] + (m->rowIdx[m->partBoundary[p + 1]] - m->rowIdx[m->partBoundary[p]]);
+    part_of_block[0] = 0;
+    int p = 0;
+    for (int b = 1; b < n_top; ++b) {
+        int64_t target = w[np] * b / n_top;
+        while (p < np && w[p] < target) ++p;
+        // keep at least one partition per block when possible
+        p = std::max(p, part_of_block[b - 1] + (np >= n_top ? 1 : 0));
+        p = std::min(p, np - (np >= n_top ? (n_top - b) : 0));
+        part_of_block[b] = p;
+    }
+    part_of_block[n_top] = np;
+    return EHYB_OK;
+}

@@ -1,0 +1,360 @@
+"""Python mirror of the reference's host interface for the EHYB path.
+
+Names follow the reference (solver_test.c / spmv.h / reordering.h): a `Matrix` is a
+`matrixCOO`, `matrix_reorder` is `matrixReorder[_unsym]`, `vector_reorder` /
+`vector_recover` are `vectorReorder` / `vectorRecover`, `spmv_gpu_ehyb` is `spmvGPuEHYB`.
+Everything is a thin call into libehyb.so; numpy is used only to hand buffers over.
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import Config, MatrixCOO, Stats
+
+EHYB_WINDOW_REFERENCE = 1
+EHYB_WINDOW_HALO = 2
+EHYB_PART_AUTO, EHYB_PART_CONTIGUOUS, EHYB_PART_MULTILEVEL, EHYB_PART_MTMETIS = 0, 1, 2, 3
+
+ARRAYS = {
+    "part_boundary": (0, np.int32), "win_len": (1, np.int32), "halo_ptr": (2, np.int32),
+    "halo_cols": (3, np.int32), "slab_pair_ptr": (4, np.uint32), "slab_row": (5, np.int32),
+    "slab_part": (6, np.int32), "ell_val": (7, np.float64), "ell_col": (8, np.uint16),
+    "items": (9, np.int32), "er_seg_ptr": (10, np.int64), "er_seg_row": (11, np.int32),
+    "er_col": (12, np.int32), "er_val": (13, np.float64), "er_bins": (14, np.int32),
+}
+
+
+class EhybError(RuntimeError):
+    def __init__(self, code, where):
+        msg = _lib.load().ehyb_last_error().decode(errors="replace")
+        super().__init__(f"{where} failed with status {code}: {msg}")
+        self.code = code
+
+
+def _check(code, where):
+    if code != 0:
+        raise EhybError(code, where)
+
+
+def make_config(**kw):
+    """ehyb_config with defaults, overridden by keyword (field names of ehyb.h)."""
+    cfg = Config()
+    _lib.load().ehyb_config_default(C.byref(cfg))
+    explicit_rows = "part_rows" in kw
+    for k, v in kw.items():
+        if not hasattr(cfg, k):
+            raise TypeError(f"unknown ehyb_config field {k!r}")
+        setattr(cfg, k, int(v))
+    if not explicit_rows and ("lds_doubles" in kw or "window_mode" in kw):
+        cfg.part_rows = 0  # re-derive from the window size / mode
+    return cfg
+
+
+def _ptr(a, ctype):
+    return a.ctypes.data_as(C.POINTER(ctype))
+
+
+def _view(ptr, count, dtype):
+    if count == 0:
+        return np.zeros(0, dtype=dtype)
+    buf = (C.c_char * (count * np.dtype(dtype).itemsize)).from_address(C.addressof(ptr.contents))
+    return np.frombuffer(buf, dtype=dtype, count=count)
+
+
+def x_glibc(n):
+    """x[i]: srand(i); (rand()%200-100)/1000 -- solver_test.c:89-92, 228-231."""
+    x = np.empty(n, dtype=np.float64)
+    _lib.load().ehyb_x_glibc(n, _ptr(x, C.c_double))
+    return x
+
+
+def sizing(dimension, cfg=None):
+    """(nParts, vectorCacheSize, kernelPerPart) -- solver_test.c:53-77 re-derived."""
+    a, b, c = C.c_int(), C.c_int(), C.c_int()
+    _check(_lib.load().ehyb_sizing(dimension, C.byref(cfg) if cfg else None, C.byref(a), C.byref(b), C.byref(c)),
+           "ehyb_sizing")
+    return a.value, b.value, c.value
+
+
+class Matrix:
+    """Owner of a matrixCOO whose arrays live in the C heap (the reorder step frees and
+    replaces I/J/V exactly like reordering.c:363-369)."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.c = MatrixCOO()
+        self.symmetric = False
+        self._alive = False
+
+    # ---- constructors
+    @classmethod
+    def from_csr(cls, indptr, indices, data, cfg=None, symmetric=False):
+        m = cls()
+        indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+        indices = np.ascontiguousarray(indices, dtype=np.int32)
+        data = np.ascontiguousarray(data, dtype=np.float64)
+        n = len(indptr) - 1
+        _check(m.lib.ehyb_matrix_from_csr(n, _ptr(indptr, C.c_int64), _ptr(indices, C.c_int), _ptr(data, C.c_double),
+                                          C.byref(cfg) if cfg else None, C.byref(m.c)), "ehyb_matrix_from_csr")
+        m._alive = True
+        m.symmetric = symmetric
+        return m
+
+    @classmethod
+    def read_mtx(cls, path, cfg=None):
+        m = cls()
+        sym = C.c_int(0)
+        _check(m.lib.ehyb_mm_read(str(path).encode(), C.byref(cfg) if cfg else None, C.byref(m.c), C.byref(sym)),
+               "ehyb_mm_read")
+        m._alive = True
+        m.symmetric = bool(sym.value)
+        return m
+
+    @classmethod
+    def generate(cls, kind, *args, cfg=None):
+        m = cls()
+        cp = C.byref(cfg) if cfg else None
+        if kind == "banded":
+            n, band, block = args
+            rc = m.lib.ehyb_gen_banded(n, band, block, cp, C.byref(m.c))
+        elif kind == "fem3d":
+            n, dof, nx, ny, ppm, scramble, seed = args
+            rc = m.lib.ehyb_gen_fem3d(n, dof, nx, ny, ppm, scramble, seed, cp, C.byref(m.c))
+            m.symmetric = True
+        elif kind == "rmat":
+            scale, edges, seed = args
+            rc = m.lib.ehyb_gen_rmat(scale, edges, seed, cp, C.byref(m.c))
+        elif kind == "stencil2d":
+            nx, ny, points, extra, seed = args
+            rc = m.lib.ehyb_gen_stencil2d(nx, ny, points, extra, seed, cp, C.byref(m.c))
+            m.symmetric = True
+        elif kind == "kkt3d":
+            (nx,) = args
+            rc = m.lib.ehyb_gen_kkt3d(nx, cp, C.byref(m.c))
+            m.symmetric = True
+        else:
+            raise ValueError(f"unknown generator {kind!r}")
+        _check(rc, f"ehyb_gen_{kind}")
+        m._alive = True
+        return m
+
+    # ---- views (valid until reorder()/free())
+    @property
+    def n(self):
+        return self.c.dimension
+
+    @property
+    def nnz(self):
+        return self.c.totalNum
+
+    def _arr(self, name, count, dtype):
+        return _view(getattr(self.c, name), count, dtype)
+
+    @property
+    def I(self):
+        return self._arr("I", self.nnz, np.int32)
+
+    @property
+    def J(self):
+        return self._arr("J", self.nnz, np.int32)
+
+    @property
+    def V(self):
+        return self._arr("V", self.nnz, np.float64)
+
+    @property
+    def row_idx(self):
+        return self._arr("rowIdx", self.n + 1, np.int32)
+
+    @property
+    def num_in_row(self):
+        return self._arr("numInRow", self.n, np.int32)
+
+    @property
+    def num_in_row2(self):
+        return self._arr("numInRow2", self.n, np.int32)
+
+    @property
+    def part_boundary(self):
+        return self._arr("partBoundary", self.c.nParts + 1, np.int32)
+
+    @property
+    def reorder_list(self):
+        return self._arr("reorderList", self.n, np.int32)
+
+    def to_scipy(self):
+        import scipy.sparse as sp
+
+        return sp.csr_matrix((self.V.copy(), self.J.copy(), self.row_idx.astype(np.int64)), shape=(self.n, self.n))
+
+    # ---- the pre-step (solver_test.c:369-376)
+    def reorder(self, cfg=None, symmetric=None):
+        """matrixReorder / matrixReorder_unsym (reordering.c:231-378 / 41-228), in place."""
+        sym = self.symmetric if symmetric is None else symmetric
+        _check(self.lib.ehyb_matrix_reorder(C.byref(self.c), 1 if sym else 0, C.byref(cfg) if cfg else None),
+               "ehyb_matrix_reorder")
+        return self
+
+    def write_mtx(self, path, symmetric_lower_only=False):
+        _check(self.lib.ehyb_mm_write(str(path).encode(), C.byref(self.c), int(symmetric_lower_only)), "ehyb_mm_write")
+
+    def free(self):
+        if self._alive:
+            self.lib.ehyb_matrix_free(C.byref(self.c))
+            self._alive = False
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+
+def vector_reorder(v, reorder_list):
+    """vectorReorder (reordering.c:380-384): out[list[i]] = v[i]."""
+    v = np.ascontiguousarray(v, dtype=np.float64)
+    lst = np.ascontiguousarray(reorder_list, dtype=np.int32)
+    out = np.empty_like(v)
+    _lib.load().ehyb_vector_reorder(len(v), _ptr(v, C.c_double), _ptr(out, C.c_double), _ptr(lst, C.c_int))
+    return out
+
+
+def vector_recover(v_rodr, reorder_list):
+    """vectorRecover (reordering.c:386-391): out[i] = v_rodr[list[i]]."""
+    v = np.ascontiguousarray(v_rodr, dtype=np.float64)
+    lst = np.ascontiguousarray(reorder_list, dtype=np.int32)
+    out = np.empty_like(v)
+    _lib.load().ehyb_vector_recover(len(v), _ptr(v, C.c_double), _ptr(out, C.c_double), _ptr(lst, C.c_int))
+    return out
+
+
+def partition_graph(indptr, indices, nparts, max_part_rows=0, vwgt=None, cfg=None):
+    """ehyb_partition_graph: stands in for MTMETIS_PartGraphKway (reordering.c:280-293)."""
+    indptr = np.ascontiguousarray(indptr, dtype=np.int64)
+    indices = np.ascontiguousarray(indices, dtype=np.int32)
+    n = len(indptr) - 1
+    part = np.empty(n, dtype=np.int32)
+    cut = C.c_int64(0)
+    vw = None if vwgt is None else _ptr(np.ascontiguousarray(vwgt, dtype=np.int32), C.c_int)
+    _check(_lib.load().ehyb_partition_graph(n, _ptr(indptr, C.c_int64), _ptr(indices, C.c_int), vw, nparts,
+                                            max_part_rows, C.byref(cfg) if cfg else None, _ptr(part, C.c_int),
+                                            C.byref(cut)), "ehyb_partition_graph")
+    return part, cut.value
+
+
+class Plan:
+    """ehyb_plan: the device-resident EHYB layout of one (permuted) matrix."""
+
+    def __init__(self, matrix, cfg=None, rows=None, upload=True):
+        self.lib = _lib.load()
+        self.h = C.c_void_p()
+        self.n = matrix.n
+        r0, r1 = (0, matrix.n) if rows is None else rows
+        self.rows = (r0, r1)
+        _check(self.lib.ehyb_plan_create_host(C.byref(matrix.c), r0, r1, C.byref(cfg) if cfg else None,
+                                              C.byref(self.h)), "ehyb_plan_create_host")
+        if upload:
+            self.upload()
+
+    def upload(self):
+        _check(self.lib.ehyb_plan_upload(self.h), "ehyb_plan_upload")
+        return self
+
+    @property
+    def stats(self):
+        st = Stats()
+        _check(self.lib.ehyb_plan_stats(self.h, C.byref(st)), "ehyb_plan_stats")
+        return st.as_dict()
+
+    def array(self, name):
+        which, dtype = ARRAYS[name]
+        p = C.c_void_p()
+        cnt = C.c_int64()
+        _check(self.lib.ehyb_plan_host_array(self.h, which, C.byref(p), C.byref(cnt)), "ehyb_plan_host_array")
+        if cnt.value == 0 or not p.value:
+            return np.zeros(0, dtype=dtype)
+        buf = (C.c_char * (cnt.value * np.dtype(dtype).itemsize)).from_address(p.value)
+        return np.frombuffer(buf, dtype=dtype, count=cnt.value).copy()
+
+    def spmv(self, x_dev, y_dev, stream=0, phase=0):
+        """Asynchronous y = A x on device pointers (ints)."""
+        _check(self.lib.ehyb_spmv_phase(self.h, C.c_void_p(x_dev), C.c_void_p(y_dev), C.c_void_p(stream), phase),
+               "ehyb_spmv")
+
+    def spmv_host(self, x, iters=1):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        assert x.shape == (self.n,)
+        y = np.zeros(self.n, dtype=np.float64)
+        _check(self.lib.ehyb_spmv_host(self.h, _ptr(x, C.c_double), _ptr(y, C.c_double), iters), "ehyb_spmv_host")
+        return y
+
+    def bench(self, x_dev, y_dev, stream=0, warmup=10, iters=100, per_kernel=True):
+        t, e, r = C.c_double(), C.c_double(), C.c_double()
+        _check(self.lib.ehyb_spmv_bench(self.h, C.c_void_p(x_dev), C.c_void_p(y_dev), C.c_void_p(stream), warmup, iters,
+                                        C.byref(t), C.byref(e) if per_kernel else None,
+                                        C.byref(r) if per_kernel else None), "ehyb_spmv_bench")
+        return {"ms_total": t.value, "ms_ell_avg": e.value, "ms_er_avg": r.value}
+
+    def destroy(self):
+        if self.h:
+            self.lib.ehyb_plan_destroy(self.h)
+            self.h = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+
+def spmv_gpu_ehyb(matrix, vector_in, max_iter):
+    """spmvGPuEHYB (spmv.cu:61-133): y = A_perm * x on the GPU, 10 warm-ups + max_iter runs."""
+    lib = _lib.load()
+    x = np.ascontiguousarray(vector_in, dtype=np.float64)
+    y = np.zeros(matrix.n, dtype=np.float64)
+    it = C.c_int(0)
+    _check(lib.spmvGPuEHYB_status(C.byref(matrix.c), _ptr(x, C.c_double), _ptr(y, C.c_double), max_iter, C.byref(it)),
+           "spmvGPuEHYB")
+    return y, it.value
+
+
+def device_count():
+    c = C.c_int(0)
+    _lib.load().ehyb_device_count(C.byref(c))
+    return c.value
+
+
+class DeviceBuffer:
+    """hipMalloc'ed array of doubles (tests / CLI plumbing; bench.py uses torch tensors)."""
+
+    def __init__(self, n):
+        self.lib = _lib.load()
+        self.n = n
+        self.p = C.c_void_p()
+        _check(self.lib.ehyb_dev_alloc(n * 8, C.byref(self.p)), "ehyb_dev_alloc")
+
+    @property
+    def ptr(self):
+        return self.p.value
+
+    def upload(self, a):
+        a = np.ascontiguousarray(a, dtype=np.float64)
+        _check(self.lib.ehyb_h2d(self.p, a.ctypes.data_as(C.c_void_p), a.nbytes), "ehyb_h2d")
+        return self
+
+    def download(self):
+        out = np.empty(self.n, dtype=np.float64)
+        _check(self.lib.ehyb_d2h(out.ctypes.data_as(C.c_void_p), self.p, out.nbytes), "ehyb_d2h")
+        return out
+
+    def free(self):
+        if self.p:
+            self.lib.ehyb_dev_free(self.p)
+            self.p = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass

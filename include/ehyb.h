@@ -1,0 +1,284 @@
+/*
+ * ehyb.h -- C-ABI of the MI355X-native Explicit-Caching HYB (EHYB) fp64 SpMV.
+ *
+ * Plain C: pointers, sizes and an opaque plan handle; no C++ or torch types cross
+ * this boundary.  One shared library (libehyb.so) exports everything declared here
+ * and in spmv.h / reordering.h.  Each entry point names the reference interface it
+ * stands in for (paths are into the reference repository).
+ *
+ *   reference symbol / code                         replaced by
+ *   ---------------------------------------------   --------------------------------------
+ *   spmvGPuEHYB                 spmv.cu:61-133      spmvGPuEHYB (spmv.h) = plan_create +
+ *                                                   10 warm-ups + MAXIter x ehyb_spmv
+ *   COO2EHYB + helpers          convert.c:61-369    ehyb_plan_create_host (layout builder)
+ *   cudaMallocTransDataEHYB     spmv.cu:6-60        ehyb_plan_upload
+ *   matrixVectorEHYB[_small]    kernel.cu:490-552   ehyb_spmv / ehyb_spmv_phase
+ *     kernelCachedBlockedELL*   kernel.cu:110-284     -> ehyb_ell_kernel   (HIP, gfx950)
+ *     ER loop + vecReorderER    kernel.cu:169-194,69-77 -> ehyb_er_kernel  (HIP, gfx950)
+ *     longRowKernel             kernel.cu:43-67       -> long segments of ehyb_er_kernel
+ *   matrixReorder[_unsym]       reordering.c:41-378 ehyb_matrix_reorder (+ C++ names in
+ *                                                   reordering.h)
+ *   vectorReorder/vectorRecover reordering.c:380-391 ehyb_vector_reorder / _recover
+ *   sizing heuristic            solver_test.c:53-77,158-182  ehyb_sizing
+ *   matrixRead_sym/_unsym       solver_test.c:31-265 ehyb_mm_read (+ ehyb_x_glibc)
+ *   MTMETIS_PartGraphKway       reordering.c:126-139,280-293  ehyb_partition_graph
+ *                                                   (built-in multilevel k-way; an
+ *                                                   mt-metis build can be plugged in,
+ *                                                   see INTEGRATION.md)
+ */
+#ifndef EHYB_H
+#define EHYB_H
+
+#include <stdint.h>
+#include <stddef.h>
+#include "spmv.h"
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ status */
+typedef enum ehyb_status {
+    EHYB_OK            = 0,
+    EHYB_ERR_ARG       = 1,  /* null pointer, negative size, inconsistent matrixCOO   */
+    EHYB_ERR_ALLOC     = 2,  /* host allocation failed                                */
+    EHYB_ERR_HIP       = 3,  /* a HIP runtime call failed (message via ehyb_last_error) */
+    EHYB_ERR_NO_DEVICE = 4,  /* no gfx950-capable device visible                      */
+    EHYB_ERR_IO        = 5,  /* file missing / unreadable                             */
+    EHYB_ERR_FORMAT    = 6,  /* Matrix Market content not supported or malformed      */
+    EHYB_ERR_INTERNAL  = 7,  /* layout self-check failed (the reference exit()s here:
+                                convert.c:122-125,226-263,287-303)                    */
+    EHYB_ERR_STATE     = 8   /* plan not uploaded / wrong call order                  */
+} ehyb_status;
+
+/* Thread-local text of the last failure ("" if none). Never NULL. */
+const char* ehyb_last_error(void);
+/* "ehyb-mi355x <version> gfx950" */
+const char* ehyb_version(void);
+
+/* ------------------------------------------------------------------ config */
+enum { EHYB_WINDOW_DEFAULT = 0, EHYB_WINDOW_REFERENCE = 1, EHYB_WINDOW_HALO = 2 };
+enum { EHYB_PART_AUTO = 0, EHYB_PART_CONTIGUOUS = 1, EHYB_PART_MULTILEVEL = 2, EHYB_PART_MTMETIS = 3 };
+
+#define EHYB_LDS_MAX_DOUBLES 20480   /* 160 KiB of LDS per workgroup on gfx950 */
+#define EHYB_SLAB_ROWS       64      /* one row per lane of a wave64           */
+
+/*
+ * Tuning knobs.  They take the place of the reference's compile-time constants
+ * (kernel.h:20-28: warpSize 32, smSize 82, maxSharedMem 93 KiB, threadELL 1024,
+ * threadLongVec 512).  Zero in any field means "use the default".
+ */
+typedef struct ehyb_config {
+    int32_t lds_doubles;   /* x-window capacity per workgroup (own rows + halo), <= 20480 */
+    int32_t part_rows;     /* upper bound of rows per partition, <= lds_doubles           */
+    int32_t threads;       /* ELL workgroup size: multiple of 64, <= 1024                 */
+    int32_t window_mode;   /* EHYB_WINDOW_REFERENCE: window = [start, start+cache) exactly
+                              as convert.c:247; EHYB_WINDOW_HALO: own rows + the most
+                              referenced outside columns gathered into LDS                */
+    int32_t items_per_cu;  /* ELL work items per CU (load-balance granularity)            */
+    int32_t partitioner;   /* EHYB_PART_*                                                 */
+    int32_t er_seg_len;    /* residual rows longer than this are split into segments      */
+    int32_t host_threads;  /* OpenMP threads of the host builder (0 = runtime default)    */
+    int32_t verbose;       /* 1: print the reference's format metrics (toER, waste, ...)  */
+    int32_t seed;          /* partitioner tie-breaking seed (deterministic per seed)      */
+    int32_t n_top;         /* top-level row blocks (one per GPU); 0/1 = single GPU        */
+    int32_t er_threads;    /* residual workgroup size                                     */
+    int32_t reserved[4];
+} ehyb_config;
+
+void ehyb_config_default(ehyb_config* cfg);
+
+/* ------------------------------------------------- host pre-step (a-7, a-9) */
+
+/*
+ * Partition/window sizing for an n-row matrix: the MI355X re-derivation of
+ * solver_test.c:53-77 / 158-182 (82 SMs x 93 KiB -> 256 CUs x 160 KiB, wave64).
+ * Outputs may be NULL.  vectorCacheSize is the window the partitions are sized for,
+ * kernelPerPart the number of work items one partition is cut into.
+ */
+int ehyb_sizing(int dimension, const ehyb_config* cfg,
+                int* nParts, int* vectorCacheSize, int* kernelPerPart);
+
+/*
+ * k-way partition of an undirected graph in CSR form (xadj has n+1 entries; adjncy may
+ * contain self loops, they are ignored).  Stands in for MTMETIS_PartGraphKway as called
+ * at reordering.c:126-139 / 280-293 (unit vertex weights, ubvec 1.001): every part gets
+ * at most max_part_rows vertices (<= 0: ceil(1.001*n/nparts)).  part[v] in [0,nparts).
+ * If vwgt is non-NULL parts are balanced on it instead (used for the per-GPU blocks).
+ */
+int ehyb_partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vwgt,
+                         int nparts, int max_part_rows, const ehyb_config* cfg,
+                         int* part, int64_t* edgecut);
+
+/*
+ * In-place symmetric permutation P*A*P^T of a row-grouped COO matrix, as
+ * matrixReorder (symmetric_pattern != 0, reordering.c:231-378) or matrixReorder_unsym
+ * (== 0: the pattern is symmetrised first, reordering.c:41-228):
+ *   - k-way partition into m->nParts parts (m->nParts and m->vectorCacheSize must be set,
+ *     e.g. by ehyb_sizing);
+ *   - new numbering: partition-contiguous, rows of a partition sorted by their number of
+ *     in-partition entries, descending (reordering.c:312-334) -- ties keep the old order,
+ *     so the permutation is deterministic here;
+ *   - I/J/V are replaced (old arrays freed with free()), rowIdx/numInRow/numInRow2/
+ *     partBoundary/reorderList are filled (reordering.c:335-362).
+ * partBoundary and reorderList must be caller-allocated with >= nParts+1 and
+ * >= dimension entries (the reference harness callocs `dimension` ints for both).
+ */
+int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const ehyb_config* cfg);
+
+/* v_rodr[list[i]] = v_in[i]  (reordering.c:380-384) */
+void ehyb_vector_reorder(int dimension, const double* v_in, double* v_rodr, const int* list);
+/* v[i] = v_rodr[list[i]]     (reordering.c:386-391) */
+void ehyb_vector_recover(int dimension, const double* v_rodr, double* v, const int* list);
+
+/* With n_top > 1: first partition of every top-level block, n_top+1 entries. */
+int ehyb_top_boundary(const matrixCOO* m, const ehyb_config* cfg, int n_top, int* part_of_block);
+
+/* ------------------------------------------------------------------- plan */
+typedef struct ehyb_plan ehyb_plan;
+
+/*
+ * Build the EHYB layout on the host from a permuted matrix (COO2EHYB, convert.c:316-369).
+ * No GPU needed.  Rows [row_begin,row_end) only (whole matrix: 0, dimension); the range
+ * must start and end on partition boundaries.  The plan keeps no pointer into m.
+ */
+int ehyb_plan_create_host(const matrixCOO* m, int row_begin, int row_end,
+                          const ehyb_config* cfg, ehyb_plan** plan);
+/* Allocate device arrays and copy the layout (cudaMallocTransDataEHYB, spmv.cu:6-60). */
+int ehyb_plan_upload(ehyb_plan* plan);
+/* create_host + upload */
+int ehyb_plan_create(const matrixCOO* m, const ehyb_config* cfg, ehyb_plan** plan);
+void ehyb_plan_destroy(ehyb_plan* plan);
+
+/* Format metrics; the first five are the ones the reference prints
+ * (convert.c:140,310; spmv.cu:82). */
+typedef struct ehyb_stats {
+    int64_t nnz;            /* stored entries in the plan's rows                      */
+    int64_t nnz_ell;        /* entries multiplied from the LDS window ("kernel calculation") */
+    int64_t nnz_er;         /* entries in the residual ("toER")                       */
+    int64_t ell_padding;    /* zero fill in the ELL slabs ("wasteElement")            */
+    int64_t size_block_ell; /* stored ELL elements incl. padding ("sizeBlockELL")     */
+    int64_t size_er;        /* stored residual elements ("sizeER")                    */
+    int64_t rows_er;        /* rows with a residual part ("numOfRowER")               */
+    int64_t er_segments;    /* residual segments (long rows are split)                */
+    int64_t n_rows;         /* rows covered by the plan                               */
+    int64_t n_cols;         /* dimension                                              */
+    int64_t n_parts;
+    int64_t n_slabs;
+    int64_t n_items;        /* ELL workgroups per multiply                            */
+    int64_t halo_cols;      /* gathered window entries over all partitions            */
+    int64_t window_loads;   /* doubles staged into LDS per multiply (all items)       */
+    int64_t bytes_format;   /* bytes the kernels must move per multiply in this format */
+    int64_t bytes_alg;      /* 12*nnz + 4*(rows+1) + 8*cols + 8*rows      */
+    int64_t max_row;        /* longest row                                            */
+    int64_t lds_bytes;      /* dynamic LDS per ELL workgroup                          */
+    int64_t reserved[5];
+} ehyb_stats;
+int ehyb_plan_stats(const ehyb_plan* plan, ehyb_stats* out);
+
+/* Read-only views of the host layout, for invariant tests (i-iv). */
+enum {
+    EHYB_ARR_PART_BOUNDARY = 0, /* int32  [n_parts+1]  first row of each partition            */
+    EHYB_ARR_WIN_LEN       = 1, /* int32  [n_parts]    contiguous window length               */
+    EHYB_ARR_HALO_PTR      = 2, /* int32  [n_parts+1]  into HALO_COLS                         */
+    EHYB_ARR_HALO_COLS     = 3, /* int32  [halo_cols]  global column of each gathered entry   */
+    EHYB_ARR_SLAB_PAIR_PTR = 4, /* uint32 [n_slabs+1]  prefix of slab widths / 2              */
+    EHYB_ARR_SLAB_ROW      = 5, /* int32  [n_slabs]    first row of the slab                  */
+    EHYB_ARR_SLAB_PART     = 6, /* int32  [n_slabs]    partition of the slab                  */
+    EHYB_ARR_ELL_VAL       = 7, /* double [size_block_ell]  [pair][lane][2]                   */
+    EHYB_ARR_ELL_COL       = 8, /* uint16 [size_block_ell]  window-local column, same order   */
+    EHYB_ARR_ITEMS         = 9, /* int32  [n_items*4]  {partition, slab_begin, slab_end, 0}   */
+    EHYB_ARR_ER_SEG_PTR    = 10,/* int64  [er_segments+1]                                     */
+    EHYB_ARR_ER_SEG_ROW    = 11,/* int32  [er_segments] bit31 set: row has several segments   */
+    EHYB_ARR_ER_COL        = 12,/* int32  [size_er]    global column                          */
+    EHYB_ARR_ER_VAL        = 13,/* double [size_er]                                           */
+    EHYB_ARR_ER_BINS       = 14 /* int32  [8]  {seg_begin[4 bins] .. } see DESIGN.md          */
+};
+int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int64_t* count);
+
+/* ------------------------------------------------------------ multiply (GPU) */
+
+/*
+ * y = A*x on `stream` (a hipStream_t passed as void*; NULL = the null stream).
+ * x and y are DEVICE pointers to full-length vectors in the permuted numbering
+ * (x: n_cols doubles; y: rows [row_begin,row_end) of it are written).  Asynchronous.
+ * Two launches: ehyb_ell_kernel then ehyb_er_kernel (skipped when the residual is
+ * empty).  Replaces matrixVectorEHYB / matrixVectorEHYB_small (kernel.cu:490-552).
+ */
+int ehyb_spmv(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream);
+
+/* phase 1: ELL part only (needs only window columns);  phase 2: residual only
+ * (y += ...);  phase 0: both.  Lets a multi-GPU caller overlap the x exchange. */
+int ehyb_spmv_phase(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream, int phase);
+
+/*
+ * Timed loop on device-resident vectors: `warmup` untimed multiplies, then `iters`
+ * multiplies bracketed by HIP events on `stream` (no copies inside, residual recomputed
+ * every time: SURVEY 8d "Timing protocol").  ms_total = whole loop.  If ms_ell / ms_er
+ * are non-NULL a second pass of `iters` multiplies brackets every launch with its own
+ * event pair and returns the SUM of the kernel durations (divide by iters for the
+ * average launch).
+ */
+int ehyb_spmv_bench(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream,
+                    int warmup, int iters, double* ms_total, double* ms_ell, double* ms_er);
+
+/* Convenience: host vectors in, host vector out (H2D, `iters` multiplies, D2H). */
+int ehyb_spmv_host(ehyb_plan* plan, const double* x_host, double* y_host, int iters);
+
+/* Device plumbing for callers without their own allocator (tests, the CLI). */
+int ehyb_device_count(int* count);
+int ehyb_device_set(int device);
+int ehyb_device_name(char* buf, int len);
+int ehyb_dev_alloc(size_t bytes, void** ptr);
+int ehyb_dev_free(void* ptr);
+int ehyb_h2d(void* dst_dev, const void* src_host, size_t bytes);
+int ehyb_d2h(void* dst_host, const void* src_dev, size_t bytes);
+int ehyb_dev_sync(void);
+/* Streaming-read ceiling of this device: sums `bytes` of doubles `iters` times, returns GB/s. */
+int ehyb_measure_read_bw(size_t bytes, int iters, double* gbps);
+
+/* -------------------------------------------- harness pieces (solver_test.c) */
+
+/*
+ * Read ./path as Matrix Market coordinate real/integer/pattern, general or symmetric,
+ * into a row-grouped COO exactly as matrixRead_unsym (solver_test.c:31-126: file order
+ * kept) or matrixRead_sym (solver_test.c:127-265: lower triangle mirrored, totalNum =
+ * 2*stored - dimension) build it, including rowIdx/numInRow/maxCol.  nParts,
+ * vectorCacheSize and kernelPerPart are filled by ehyb_sizing.  pattern entries get 1.0.
+ * All arrays are malloc()ed; release with ehyb_matrix_free.
+ */
+int ehyb_mm_read(const char* path, const ehyb_config* cfg, matrixCOO* out, int* is_symmetric);
+int ehyb_mm_write(const char* path, const matrixCOO* m, int symmetric_lower_only);
+/* Copy a CSR matrix (rowptr[n+1], cols, vals; 0-based) into a freshly malloc()ed row-grouped
+ * matrixCOO, entry order preserved; sizing fields filled by ehyb_sizing. */
+int ehyb_matrix_from_csr(int n, const int64_t* rowptr, const int* cols, const double* vals,
+                         const ehyb_config* cfg, matrixCOO* out);
+void ehyb_matrix_free(matrixCOO* m);
+
+/* x[i]: srand(i); (rand()%200-100)/1000.0  -- solver_test.c:89-92, 228-231 (glibc rand). */
+void ehyb_x_glibc(int n, double* x);
+
+/*
+ * Synthetic matrices (no .mtx files exist offline).  All deterministic,
+ * integer-hash values v = ((h mod 200) - 100)/1000 with 0 replaced by 0.001.
+ * Each fills a row-grouped, column-sorted matrixCOO like ehyb_mm_read does.
+ */
+/* config 3: block-circulant band, `band` entries per row inside blocks of `block` rows */
+int ehyb_gen_banded(int n, int band, int block, const ehyb_config* cfg, matrixCOO* out);
+/* audikw_1-like: nodes of a 3-D grid (truncated to n/dof nodes), dof unknowns per node,
+ * 27-point node coupling plus hashed second-shell couplings with probability extra_ppm/1e6,
+ * symmetric values; scramble != 0 applies a random relabelling of the nodes.            */
+int ehyb_gen_fem3d(int n, int dof, int nx, int ny, int extra_ppm, int scramble, uint64_t seed,
+                   const ehyb_config* cfg, matrixCOO* out);
+/* R-MAT (a,b,c,d)=(.57,.19,.19,.05), 2^scale rows, `edges` samples, duplicates merged */
+int ehyb_gen_rmat(int scale, int64_t edges, uint64_t seed, const ehyb_config* cfg, matrixCOO* out);
+/* 2-D 5/9-point stencil plus `extra` random symmetric couplings (small test inputs) */
+int ehyb_gen_stencil2d(int nx, int ny, int points, int extra, uint64_t seed,
+                       const ehyb_config* cfg, matrixCOO* out);
+/* nlpkkt-like 3-D KKT system: [H A^T; A 0] on an nx^3 grid */
+int ehyb_gen_kkt3d(int nx, const ehyb_config* cfg, matrixCOO* out);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* EHYB_H */

@@ -1,0 +1,163 @@
+/*
+ * ehyb_oracle.c -- CPU restatement of the reference's results path.  TEST INFRASTRUCTURE ONLY.
+ *
+ * Only tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py may load this
+ * file's library; nothing under ehyb_spmv_gpu_amd/ links, imports or calls it, and the product
+ * has no CPU fallback.
+ *
+ * PARITY STATUS: "parity unpinned" against the reference itself.  The reference ships no
+ * tests, golden vectors or fixtures, and every first-party source on the
+ * path includes kernel.h, which needs cublas_v2.h / cusparse_v2.h / cuda_runtime.h
+ * (kernel.h:14-18) -- CUDA toolkit headers this image does not have -- so the reference is
+ * unbuildable here without writing stand-ins.  What IS pinned:
+ *   - the x rule against glibc known answers (x[0..7], x[1000], x[10973], x[943694], and
+ *     sum x[0..10973] = -10.854, recorded in SURVEY.md section 4);
+ *   - the products against scipy.sparse (an independent implementation) on every test matrix;
+ *   - the Matrix Market banner/size parsing of the product's reader against the reference's
+ *     own mmio.c, which is stand-alone C and IS compiled from where it lies (oracle/Makefile
+ *     -> oracle/_ref/libmmio_ref.so).
+ *
+ * Each function cites the reference lines it restates (paths into the reference repository).
+ */
+#include <math.h>
+#include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <time.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* solver_test.c:89-92 (general) and 228-231 (symmetric): per-element reseeded glibc rand. */
+void oracle_x_glibc(int n, double* x)
+{
+    for (int i = 0; i < n; i++) {
+        srand(i);
+        x[i] = (double)(rand() % 200 - 100) / 1000;
+    }
+}
+
+/* solver_test.c:96-103: one pass over the entries in storage order, y[I] += V * x[J].
+ * y must be zeroed by the caller (the reference forgets to: solver_test.c:38). */
+void oracle_spmv_coo(int64_t nnz, const int* I, const int* J, const double* V, const double* x, double* y)
+{
+    for (int64_t k = 0; k < nnz; k++) y[I[k]] += V[k] * x[J[k]];
+}
+
+/* solver_test.c:235-255: stored lower-triangular entries, each off-diagonal one applied twice
+ * (y[i] += v*x[j]; y[j] += v*x[i]) in file order. */
+void oracle_spmv_sym_lower(int64_t stored, const int* I, const int* J, const double* V, const double* x,
+                           double* y)
+{
+    for (int64_t k = 0; k < stored; k++) {
+        int i = I[k], j = J[k];
+        y[i] += V[k] * x[j];
+        if (i != j) y[j] += V[k] * x[i];
+    }
+}
+
+/* CSR fp64 row loop, one thread.  Same sums as oracle_spmv_coo when
+ * the entries of a row are stored contiguously (rowIdx of spmv.h:23). */
+void oracle_spmv_csr(int n, const int64_t* rowptr, const int* col, const double* val, const double* x,
+                     double* y)
+{
+    for (int i = 0; i < n; i++) {
+        double s = 0.0;
+        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; k++) s += val[k] * x[col[k]];
+        y[i] = s;
+    }
+}
+
+/* the same loop, static row partition over all host cores. */
+void oracle_spmv_csr_omp(int n, const int64_t* rowptr, const int* col, const double* val, const double* x,
+                         double* y)
+{
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; i++) {
+        double s = 0.0;
+        for (int64_t k = rowptr[i]; k < rowptr[i + 1]; k++) s += val[k] * x[col[k]];
+        y[i] = s;
+    }
+}
+
+int oracle_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}
+
+/* sum_j |a_ij * x_j| per row: the scale of the stated tolerance
+ * |y_gpu - y_cpu| <= 1e-12 * sum_j |a_ij x_j|  (BASELINE.md section 4). */
+void oracle_abs_rowsum(int64_t nnz, const int* I, const int* J, const double* V, const double* x, double* s)
+{
+    for (int64_t k = 0; k < nnz; k++) s[I[k]] += fabs(V[k] * x[J[k]]);
+}
+
+/* solver_test.c:7-29 compare(): counts elements with |y - yResult| > threshold*min(|y|,|yResult|),
+ * accumulates diff = sum |d| and ampldiff = sum |d|/min(|a|,|b|).  Returns the offender count. */
+int64_t oracle_compare(const double* yResult, const double* y, double threshold, int n, double* diff,
+                       double* ampldiff)
+{
+    double d_sum = 0, a_sum = 0;
+    int64_t bad = 0;
+    for (int i = 0; i < n; i++) {
+        double d = fabs(y[i] - yResult[i]);
+        double ampl = fmin(fabs(y[i]), fabs(yResult[i]));
+        if (d > ampl * threshold) bad++;
+        d_sum += d;
+        if (ampl > 0) a_sum += d / ampl;
+    }
+    if (diff) *diff = d_sum;
+    if (ampldiff) *ampldiff = a_sum;
+    return bad;
+}
+
+/* Strict check used by the parity tests: rows with |a-b| > tol * scale[i]; *worst = max |a-b|/scale. */
+int64_t oracle_check_tolerance(const double* a, const double* b, const double* scale, int n, double tol,
+                               double* worst)
+{
+    int64_t bad = 0;
+    double w = 0;
+    for (int i = 0; i < n; i++) {
+        double d = fabs(a[i] - b[i]);
+        if (d > tol * scale[i]) bad++;
+        double r = scale[i] > 0 ? d / scale[i] : (d > 0 ? INFINITY : 0);
+        if (r > w) w = r;
+    }
+    if (worst) *worst = w;
+    return bad;
+}
+
+static double now_s(void)
+{
+    struct timespec t;
+    clock_gettime(CLOCK_MONOTONIC, &t);
+    return t.tv_sec + 1e-9 * t.tv_nsec;
+}
+
+/* Timed baselines for bench.py (cpu_baseline): seconds per multiply, best of `reps`.
+ * kind 0: literal reference path (oracle_spmv_coo, 1 thread)   -- BASELINE.md C0
+ * kind 1: CSR 1 thread                                          -- C1
+ * kind 2: CSR OpenMP all cores                                  -- C2            */
+double oracle_time_spmv(int kind, int n, int64_t nnz, const int64_t* rowptr, const int* I, const int* J,
+                        const double* V, const double* x, double* y, int reps)
+{
+    double best = 1e300;
+    for (int r = 0; r < reps + 1; r++) { /* first pass is the warm-up */
+        double t0 = now_s();
+        if (kind == 0) {
+            memset(y, 0, sizeof(double) * (size_t)n);
+            oracle_spmv_coo(nnz, I, J, V, x, y);
+        } else if (kind == 1) {
+            oracle_spmv_csr(n, rowptr, J, V, x, y);
+        } else {
+            oracle_spmv_csr_omp(n, rowptr, J, V, x, y);
+        }
+        double t = now_s() - t0;
+        if (r > 0 && t < best) best = t;
+    }
+    return best;
+}

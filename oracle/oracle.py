@@ -1,0 +1,187 @@
+"""Loader for oracle/liboracle.so plus numpy helpers.  TEST INFRASTRUCTURE ONLY.
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg import this module
+(see oracle/ehyb_oracle.c for the rules and the parity status).
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = os.path.join(_HERE, "liboracle.so")
+_lib = None
+
+
+def build():
+    subprocess.run(["make", "-C", _HERE, "-s"], check=True)
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(_LIB):
+            build()
+        L = C.CDLL(_LIB)
+        dp, ip, i64p = C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int64)
+        L.oracle_x_glibc.argtypes = [C.c_int, dp]
+        L.oracle_spmv_coo.argtypes = [C.c_int64, ip, ip, dp, dp, dp]
+        L.oracle_spmv_sym_lower.argtypes = [C.c_int64, ip, ip, dp, dp, dp]
+        L.oracle_spmv_csr.argtypes = [C.c_int, i64p, ip, dp, dp, dp]
+        L.oracle_spmv_csr_omp.argtypes = [C.c_int, i64p, ip, dp, dp, dp]
+        L.oracle_max_threads.restype = C.c_int
+        L.oracle_abs_rowsum.argtypes = [C.c_int64, ip, ip, dp, dp, dp]
+        L.oracle_compare.argtypes = [dp, dp, C.c_double, C.c_int, dp, dp]
+        L.oracle_compare.restype = C.c_int64
+        L.oracle_check_tolerance.argtypes = [dp, dp, dp, C.c_int, C.c_double, dp]
+        L.oracle_check_tolerance.restype = C.c_int64
+        L.oracle_time_spmv.argtypes = [C.c_int, C.c_int, C.c_int64, i64p, ip, ip, dp, dp, dp, C.c_int]
+        L.oracle_time_spmv.restype = C.c_double
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(C.POINTER(C.c_double))
+
+
+def _i(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def _l(a):
+    return a.ctypes.data_as(C.POINTER(C.c_int64))
+
+
+def x_glibc(n):
+    x = np.empty(n, dtype=np.float64)
+    lib().oracle_x_glibc(n, _d(x))
+    return x
+
+
+def spmv_coo(n, I, J, V, x):
+    """The reference CPU product (solver_test.c:102): entries in storage order."""
+    I = np.ascontiguousarray(I, dtype=np.int32)
+    J = np.ascontiguousarray(J, dtype=np.int32)
+    V = np.ascontiguousarray(V, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros(n, dtype=np.float64)
+    lib().oracle_spmv_coo(len(V), _i(I), _i(J), _d(V), _d(x), _d(y))
+    return y
+
+
+def spmv_sym_lower(n, I, J, V, x):
+    I = np.ascontiguousarray(I, dtype=np.int32)
+    J = np.ascontiguousarray(J, dtype=np.int32)
+    V = np.ascontiguousarray(V, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    y = np.zeros(n, dtype=np.float64)
+    lib().oracle_spmv_sym_lower(len(V), _i(I), _i(J), _d(V), _d(x), _d(y))
+    return y
+
+
+def spmv_csr(rowptr, col, val, x, omp=False):
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    col = np.ascontiguousarray(col, dtype=np.int32)
+    val = np.ascontiguousarray(val, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = len(rowptr) - 1
+    y = np.zeros(n, dtype=np.float64)
+    fn = lib().oracle_spmv_csr_omp if omp else lib().oracle_spmv_csr
+    fn(n, _l(rowptr), _i(col), _d(val), _d(x), _d(y))
+    return y
+
+
+def abs_rowsum(n, I, J, V, x):
+    I = np.ascontiguousarray(I, dtype=np.int32)
+    J = np.ascontiguousarray(J, dtype=np.int32)
+    V = np.ascontiguousarray(V, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    s = np.zeros(n, dtype=np.float64)
+    lib().oracle_abs_rowsum(len(V), _i(I), _i(J), _d(V), _d(x), _d(s))
+    return s
+
+
+def compare(y_result, y, threshold=0.01):
+    """compare() of solver_test.c:7-29 -> (offenders, diff, ampldiff)."""
+    a = np.ascontiguousarray(y_result, dtype=np.float64)
+    b = np.ascontiguousarray(y, dtype=np.float64)
+    d, ad = C.c_double(), C.c_double()
+    bad = lib().oracle_compare(_d(a), _d(b), threshold, len(a), C.byref(d), C.byref(ad))
+    return int(bad), d.value, ad.value
+
+
+TOLERANCE = 1e-12  # |y_gpu - y_cpu| <= 1e-12 * sum_j |a_ij x_j|  
+
+
+def check_tolerance(a, b, scale, tol=TOLERANCE):
+    """-> (rows violating |a-b| <= tol*scale, worst |a-b|/scale)."""
+    a = np.ascontiguousarray(a, dtype=np.float64)
+    b = np.ascontiguousarray(b, dtype=np.float64)
+    s = np.ascontiguousarray(scale, dtype=np.float64)
+    w = C.c_double()
+    bad = lib().oracle_check_tolerance(_d(a), _d(b), _d(s), len(a), tol, C.byref(w))
+    return int(bad), w.value
+
+
+def time_spmv(kind, rowptr, I, J, V, x, reps=3):
+    """Seconds per multiply (best of reps). kind 0: COO order 1 thread; 1: CSR 1 thread; 2: CSR all cores."""
+    rowptr = np.ascontiguousarray(rowptr, dtype=np.int64)
+    I = np.ascontiguousarray(I, dtype=np.int32)
+    J = np.ascontiguousarray(J, dtype=np.int32)
+    V = np.ascontiguousarray(V, dtype=np.float64)
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    n = len(rowptr) - 1
+    y = np.zeros(n, dtype=np.float64)
+    t = lib().oracle_time_spmv(kind, n, len(V), _l(rowptr), _i(I), _i(J), _d(V), _d(x), _d(y), reps)
+    return t, y
+
+
+def max_threads():
+    return int(lib().oracle_max_threads())
+
+
+# --------------------------------------------------------------------------------------
+# CPU walk of the MI355X layout (include/ehyb.h EHYB_ARR_*), indexing the arrays exactly as
+# ehyb_ell_kernel / ehyb_er_kernel do.  Checks the host builder without a GPU.
+def walk_plan(plan, x):
+    x = np.asarray(x, dtype=np.float64)
+    n = plan.n
+    y = np.zeros(n, dtype=np.float64)
+    pb = plan.array("part_boundary")
+    win_len = plan.array("win_len")
+    halo_ptr = plan.array("halo_ptr")
+    halo_cols = plan.array("halo_cols")
+    spp = plan.array("slab_pair_ptr").astype(np.int64)
+    slab_row = plan.array("slab_row")
+    ell_val = plan.array("ell_val")
+    ell_col = plan.array("ell_col").astype(np.int64)
+    items = plan.array("items").reshape(-1, 4)
+    written = np.zeros(n, dtype=np.int32)
+    for p, s0, s1, _ in items:
+        ps, pe = int(pb[p]), int(pb[p + 1])
+        wl = int(win_len[p])
+        win = np.concatenate([x[ps:ps + wl], x[halo_cols[halo_ptr[p]:halo_ptr[p + 1]]]])
+        for s in range(s0, s1):
+            p0, p1 = spp[s], spp[s + 1]
+            acc = np.zeros(64, dtype=np.float64)
+            if p1 > p0:
+                v = ell_val[p0 * 128:p1 * 128].reshape(p1 - p0, 64, 2)
+                c = ell_col[p0 * 128:p1 * 128].reshape(p1 - p0, 64, 2)
+                assert c.max() < len(win), "window-local column outside the window"
+                acc = (v * win[c]).sum(axis=(0, 2))
+            r0 = int(slab_row[s])
+            cnt = min(64, pe - r0)
+            y[r0:r0 + cnt] = acc[:cnt]
+            written[r0:r0 + cnt] += 1
+    seg_ptr = plan.array("er_seg_ptr")
+    seg_row = plan.array("er_seg_row")
+    er_col = plan.array("er_col")
+    er_val = plan.array("er_val")
+    if len(seg_row):
+        prod = er_val * x[er_col]
+        sums = np.add.reduceat(prod, seg_ptr[:-1]) if len(prod) else np.zeros(0)
+        rows = seg_row & 0x7FFFFFFF
+        np.add.at(y, rows, sums)
+    return y, written
