@@ -1,0 +1,226 @@
+#!/usr/bin/env python3
+"""bench.py -- fp64 EHYB SpMV throughput on MI355X (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+
+A "step" is one SpMV of the whole matrix: y = A x through libehyb.so's HIP kernels (N = 1),
+or, for N > 1, one exchange of the x segments over RCCL followed by each rank's local
+multiply (rows are sharded by top-level partition blocks; strong scaling: the matrix is fixed).
+
+Workload at N = 1 (and by default at every N): BASELINE.json configs[1], audikw_1 -- as a
+statistically matched synthetic, because no .mtx file exists offline: 943,695 rows, 3 unknowns
+per node of a 68x68x69 grid truncated to 314,565 nodes, 27-point node coupling plus hashed
+second-shell couplings tuned to audikw_1's 77.65 M entries (82.3 per row), node labels
+scrambled so that locality has to come from the partitioner.  `data` says so.
+
+Output: ONE JSON line on rank 0 with the contract's keys plus
+  roofline      algorithmic bytes of the dominant kernel / its mean launch time (HIP events)
+  cpu_baseline  the CPU oracle (a port of the reference's CPU product) timed on this host.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X data-sheet peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
+
+WORKLOADS = {
+    # name: (generator, args, symmetric, description)
+    "audikw_1-like": ("fem3d", (943695, 3, 68, 68, 13500, 1, 1),
+                      "synthetic stand-in for audikw_1: 943,695 rows, ~77.7 M entries, 3 dof/node FEM-like, scrambled labels"),
+    "banded-4M": ("banded", (1 << 22, 32, 1024), "config 3: block-circulant band, 4,194,304 rows x 32 entries, zero residual"),
+    "rmat-24": ("rmat", (24, 1 << 27, 1), "config 5: R-MAT 2^24 rows, 2^27 edge samples"),
+    "kkt3d-200": ("kkt3d", (200,), "config 4 stand-in: KKT-like saddle point system on a 200^3 grid"),
+    "small": ("fem3d", (120000, 3, 35, 35, 13500, 1, 1), "reduced-size smoke workload (NOT a valid bench result)"),
+}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--workload", default="audikw_1-like", choices=sorted(WORKLOADS))
+    ap.add_argument("--lds-doubles", type=int, default=0)
+    ap.add_argument("--part-rows", type=int, default=0)
+    ap.add_argument("--threads", type=int, default=0)
+    ap.add_argument("--items-per-cu", type=int, default=0)
+    ap.add_argument("--window-mode", type=int, default=0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--verbose", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+
+    import ehyb_spmv_gpu_amd as E
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the EHYB multiply has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def log(*a):
+        if rank == 0:
+            print(*a, file=sys.stderr, flush=True)
+
+    kw = {}
+    for k, v in (("lds_doubles", args.lds_doubles), ("part_rows", args.part_rows), ("threads", args.threads),
+                 ("items_per_cu", args.items_per_cu), ("window_mode", args.window_mode)):
+        if v:
+            kw[k] = v
+    cfg = E.make_config(n_top=world, verbose=1 if (args.verbose and rank == 0) else 0, **kw)
+
+    gen, gargs, desc = WORKLOADS[args.workload]
+    t0 = time.time()
+    m = E.Matrix.generate(gen, *gargs, cfg=cfg)
+    n, nnz = m.n, m.nnz
+    log(f"[bench] generated {args.workload}: n={n} nnz={nnz} in {time.time() - t0:.1f}s")
+
+    # ---- CPU baseline on the un-permuted matrix (rank 0, N = 1 only): the oracle, timed
+    cpu_baseline = None
+    x = E.x_glibc(n)
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import oracle as O
+
+        rowptr = m.row_idx.astype(np.int64)
+        t_coo, y_cpu = O.time_spmv(0, rowptr, m.I, m.J, m.V, x, reps=3)
+        t_csr1, _ = O.time_spmv(1, rowptr, m.I, m.J, m.V, x, reps=3)
+        t_omp, _ = O.time_spmv(2, rowptr, m.I, m.J, m.V, x, reps=5)
+        cores = O.max_threads()
+        cpu_baseline = {
+            "value": round(2.0 * nnz / t_omp / 1e9, 3), "unit": "GFLOP/s", "cores": cores, "kind": "port",
+            "sample": (f"whole {args.workload} matrix, best of 5 CSR fp64 SpMVs with OpenMP on {cores} threads; "
+                       f"1-thread CSR {2.0 * nnz / t_csr1 / 1e9:.3f} GFLOP/s; literal reference order "
+                       f"(solver_test.c:102, 1 thread) {2.0 * nnz / t_coo / 1e9:.3f} GFLOP/s"),
+        }
+        scale = O.abs_rowsum(n, m.I, m.J, m.V, x)
+        log(f"[bench] cpu baseline: {cpu_baseline['value']} GFLOP/s on {cores} threads")
+    else:
+        y_cpu = scale = None
+
+    # ---- host pre-step: partition + permute (matrixReorder), then this rank's plan
+    t0 = time.time()
+    m.reorder(cfg)
+    log(f"[bench] reorder (partition into {m.c.nParts} parts) {time.time() - t0:.1f}s")
+    perm = m.reorder_list.copy()
+    xp = E.vector_reorder(x, perm)
+    pb = m.part_boundary.copy()
+    if world > 1:
+        import ctypes as C
+
+        blocks = (C.c_int * (world + 1))()
+        E.host._check(E.host._lib.load().ehyb_top_boundary(C.byref(m.c), C.byref(cfg), world, blocks), "ehyb_top_boundary")
+        row_cuts = [int(pb[blocks[b]]) for b in range(world + 1)]
+    else:
+        row_cuts = [0, n]
+    r0, r1 = row_cuts[rank], row_cuts[rank + 1]
+    t0 = time.time()
+    plan = E.Plan(m, cfg, rows=(r0, r1))
+    st = plan.stats
+    log(f"[bench] rank {rank}: rows [{r0},{r1}) plan built+uploaded in {time.time() - t0:.1f}s: "
+        f"ell {st['nnz_ell']} er {st['nnz_er']} pad {st['ell_padding']} items {st['n_items']} lds {st['lds_bytes']}B")
+
+    dev = torch.device("cuda", local_rank)
+    x_d = torch.from_numpy(xp).to(dev)
+    y_d = torch.zeros(n, dtype=torch.float64, device=dev)
+    stream = torch.cuda.current_stream().cuda_stream
+
+    xs = [x_d[row_cuts[b]:row_cuts[b + 1]] for b in range(world)] if world > 1 else None
+
+    def step():
+        if world > 1:
+            # every rank publishes its own x segment, all ranks end with the full x:
+            # all-gatherv over xGMI (ragged segments -> list form).
+            dist.all_gather(xs, xs[rank])
+        plan.spmv(x_d.data_ptr(), y_d.data_ptr(), stream)
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    # ---- parity of what was just timed (rank-local rows) against the CPU oracle
+    parity = None
+    if y_cpu is not None:
+        from oracle import oracle as O
+
+        y = E.vector_recover(y_d.cpu().numpy(), perm)
+        bad, worst = O.check_tolerance(y, y_cpu, scale)
+        parity = {"rows_over_1e-12": bad, "worst_rel": worst}
+        log(f"[bench] parity vs CPU oracle: {bad} rows over 1e-12, worst {worst:.3e}")
+        if bad:
+            raise SystemExit("bench.py: GPU result differs from the CPU oracle; refusing to report a number")
+
+    # ---- per-kernel timing with HIP events on the launch stream (N = 1)
+    roofline = None
+    if world == 1:
+        r = plan.bench(x_d.data_ptr(), y_d.data_ptr(), stream, warmup=5, iters=min(args.steps, 200))
+        ell_ms, er_ms = r["ms_ell_avg"], r["ms_er_avg"]
+        bytes_ell = 12 * st["nnz_ell"] + 4 * (st["n_rows"] + 1) + 8 * st["n_cols"] + 8 * st["n_rows"]
+        achieved = bytes_ell / (ell_ms * 1e-3) / 1e9
+        traffic = None
+        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
+        if os.path.exists(pmc):
+            try:
+                traffic = json.load(open(pmc)).get("ehyb_ell_kernel_hbm_bytes_per_launch")
+            except Exception:
+                traffic = None
+        roofline = {"bound": "hbm", "kernel": "ehyb_ell_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
+                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                    "alg_bytes_per_launch": bytes_ell, "avg_launch_ms": round(ell_ms, 5),
+                    "er_kernel_avg_launch_ms": round(er_ms, 5), "format_bytes_per_spmv": st["bytes_format"],
+                    "whole_spmv_alg_GBps": round(st["bytes_alg"] / ((ell_ms + er_ms) * 1e-3) / 1e9, 1)}
+
+    if rank == 0:
+        ms_per_step = elapsed / args.steps * 1e3
+        value = 2.0 * nnz * args.steps / elapsed / 1e9
+        out = {
+            "metric": "fp64 SpMV GFLOP/s (2*nnz/t_iter), EHYB on MI355X",
+            "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic: " + desc,
+            "config": {"workload": args.workload, "rows": n, "nnz": nnz, "parts": int(m.c.nParts),
+                       "lds_doubles": int(cfg.lds_doubles), "part_rows": int(cfg.part_rows), "threads": int(cfg.threads),
+                       "window_mode": "halo" if cfg.window_mode != 1 else "reference",
+                       "nnz_ell": st["nnz_ell"], "nnz_er": st["nnz_er"], "ell_padding": st["ell_padding"],
+                       "alg_bytes_per_spmv": st["bytes_alg"] if world == 1 else None,
+                       "exchange": "none" if world == 1 else "RCCL all-gatherv of x segments"},
+            "alg_GBps": round((12 * nnz + 4 * (n + 1) + 16 * n) / (elapsed / args.steps) / 1e9, 1),
+            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+        }
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,109 @@
+"""GPU parity: the HIP path, called through the C-ABI, against the CPU oracle.
+
+Tolerance (fp64, stated in SURVEY.md 8c / BASELINE.md 4): per row
+    |y_gpu - y_cpu| <= 1e-12 * sum_j |a_ij * x_j|
+EHYB changes the summation order (ELL pairs, then += residual), so bit equality with the
+row-ordered CPU sum is not expected; the reference's own check is 1 % relative
+(solver_test.c:389) and is also evaluated.
+"""
+import numpy as np
+import pytest
+
+from util import SMALL_CASES, Case
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("name,kind,args", SMALL_CASES, ids=[c[0] for c in SMALL_CASES])
+@pytest.mark.parametrize("mode", [1, 2], ids=["refwindow", "halo"])
+def test_spmvGPuEHYB_matches_oracle(E, O, gpu, name, kind, args, mode):
+    """The drop-in symbol end to end: reorder -> spmvGPuEHYB -> recover -> compare."""
+    cfg = E.make_config(window_mode=mode, lds_doubles=4096)
+    c = Case(E, O, kind, args, cfg)
+    yp, iters = E.spmv_gpu_ehyb(c.m, c.xp, 3)
+    assert iters == 3
+    bad, worst = c.check(yp)
+    assert bad == 0, f"{name}: {bad} rows over tolerance, worst {worst:.3e}"
+    # The reference's own check (solver_test.c:389): 1 % of min(|a|,|b|).  It has no pass/fail
+    # and trips on rows whose terms cancel to ~0, so only rows that are NOT cancellation rows
+    # may be flagged.
+    y = c.recover(yp)
+    loose_bad, diff, ampl = O.compare(y, c.y_ref, 0.01)
+    cancel = int(np.count_nonzero(np.abs(c.y_ref) < 1e-10 * c.scale))
+    assert loose_bad <= cancel
+    assert diff <= 1e-12 * c.scale.sum()
+
+
+@pytest.mark.parametrize("threads", [256, 512, 1024])
+@pytest.mark.parametrize("lds", [1024, 6144, 20480])
+def test_plan_configs(E, O, gpu, threads, lds):
+    """Workgroup sizes and window sizes up to the full 160 KiB of LDS."""
+    cfg = E.make_config(window_mode=2, lds_doubles=lds, threads=threads, items_per_cu=2)
+    c = Case(E, O, "fem3d", (30000, 3, 22, 22, 13500, 1, 1), cfg)
+    plan = E.Plan(c.m, cfg)
+    yp = plan.spmv_host(c.xp, iters=2)
+    bad, worst = c.check(yp)
+    assert bad == 0, f"threads={threads} lds={lds}: worst {worst:.3e}"
+    st = plan.stats
+    assert st["nnz_ell"] + st["nnz_er"] == c.nnz
+
+
+def test_residual_recomputed_every_iteration(E, O, gpu):
+    """The reference computes the residual only on its first launch (spmv.cu:41 vs
+    kernel.cu:171-176); here x may change between multiplies."""
+    cfg = E.make_config(window_mode=1, lds_doubles=1024)
+    c = Case(E, O, "rmat", (13, 1 << 16, 9), cfg)
+    plan = E.Plan(c.m, cfg)
+    assert plan.stats["nnz_er"] > 0
+    x2 = c.x[::-1].copy()
+    y_ref2 = O.spmv_coo(c.n, c.m.I, c.m.J, c.m.V, E.vector_reorder(x2, c.perm))  # permuted matrix & x
+    dx, dy = E.DeviceBuffer(c.n), E.DeviceBuffer(c.n)
+    dx.upload(c.xp)
+    plan.spmv(dx.ptr, dy.ptr)
+    dx.upload(E.vector_reorder(x2, c.perm))
+    plan.spmv(dx.ptr, dy.ptr)
+    y2 = dy.download()
+    scale = O.abs_rowsum(c.n, c.m.I, c.m.J, c.m.V, E.vector_reorder(x2, c.perm))
+    bad, worst = O.check_tolerance(y2, y_ref2, scale)
+    assert bad == 0, f"second multiply with a new x is wrong: worst {worst:.3e}"
+
+
+def test_long_rows_split_with_atomics(E, O, gpu):
+    """Rows far longer than er_seg_len (R-MAT hubs): the working form of longRowKernel."""
+    cfg = E.make_config(window_mode=1, lds_doubles=256, er_seg_len=64)
+    c = Case(E, O, "rmat", (11, 1 << 17, 3), cfg)
+    plan = E.Plan(c.m, cfg)
+    seg_row = plan.array("er_seg_row")
+    assert (seg_row < 0).any(), "expected split rows"
+    yp = plan.spmv_host(c.xp)
+    bad, worst = c.check(yp)
+    assert bad == 0, f"worst {worst:.3e}"
+
+
+def test_empty_residual(E, O, gpu):
+    """Pure ELL (config 3's shape): the reference exit(0)s here (convert.c:136-139)."""
+    cfg = E.make_config(window_mode=1, lds_doubles=4096, partitioner=E.EHYB_PART_CONTIGUOUS)
+    c = Case(E, O, "banded", (1 << 15, 32, 1024), cfg)
+    plan = E.Plan(c.m, cfg)
+    st = plan.stats
+    assert st["nnz_er"] == 0 and st["ell_padding"] == 0
+    bad, worst = c.check(plan.spmv_host(c.xp))
+    assert bad == 0
+
+
+def test_linearity_and_phases(E, O, gpu):
+    """A(ax+bz) = aAx + bAz, and phase 1 + phase 2 == phase 0."""
+    cfg = E.make_config(window_mode=2, lds_doubles=2048)
+    c = Case(E, O, "stencil2d", (150, 150, 9, 8000, 4), cfg)
+    plan = E.Plan(c.m, cfg)
+    rng = np.random.default_rng(0)
+    z = rng.standard_normal(c.n)
+    ya, yz = plan.spmv_host(c.xp), plan.spmv_host(z)
+    ycomb = plan.spmv_host(2.5 * c.xp - 0.75 * z)
+    scale = np.abs(2.5 * ya) + np.abs(0.75 * yz) + 1e-300
+    assert np.max(np.abs(ycomb - (2.5 * ya - 0.75 * yz)) / scale) < 1e-10
+    dx, dy = E.DeviceBuffer(c.n), E.DeviceBuffer(c.n)
+    dx.upload(c.xp)
+    plan.spmv(dx.ptr, dy.ptr, phase=1)
+    plan.spmv(dx.ptr, dy.ptr, phase=2)
+    assert np.array_equal(dy.download(), ya)

@@ -1,0 +1,43 @@
+"""Shared helpers for the parity tests: the harness flow of solver_test.c:350-389."""
+import numpy as np
+
+
+class Case:
+    """read/generate -> x -> CPU reference y -> reorder -> P*x (solver_test.c:350-376)."""
+
+    def __init__(self, E, O, kind, args, cfg, reorder=True):
+        self.E, self.O, self.cfg = E, O, cfg
+        m = E.Matrix.generate(kind, *args, cfg=cfg)
+        self.m = m
+        self.n = m.n
+        self.x = O.x_glibc(m.n)                                   # solver_test.c:89-92
+        self.y_ref = O.spmv_coo(m.n, m.I, m.J, m.V, self.x)       # solver_test.c:102 / 247,254
+        self.scale = O.abs_rowsum(m.n, m.I, m.J, m.V, self.x)
+        self.nnz = m.nnz
+        if reorder:
+            m.reorder(cfg)                                        # solver_test.c:370/373
+        else:
+            m.reorder_list[:] = np.arange(m.n, dtype=np.int32)
+        self.perm = m.reorder_list.copy()
+        self.xp = E.vector_reorder(self.x, self.perm)             # solver_test.c:376
+
+    def recover(self, yp):
+        return self.E.vector_recover(yp, self.perm)               # solver_test.c:383
+
+    def check(self, yp, tol=None):
+        y = self.recover(yp)
+        bad, worst = self.O.check_tolerance(y, self.y_ref, self.scale, tol or self.O.TOLERANCE)
+        return bad, worst
+
+
+SMALL_CASES = [
+    # (name, generator, args) -- sized so the CPU oracle takes well under a second each
+    ("fem3d_scrambled", "fem3d", (30000, 3, 22, 22, 13500, 1, 1)),
+    ("fem3d_natural", "fem3d", (24000, 3, 20, 20, 0, 0, 2)),
+    ("stencil5_noise", "stencil2d", (150, 150, 5, 3000, 1)),
+    ("stencil9_noise", "stencil2d", (120, 100, 9, 6000, 3)),
+    ("rmat_s14", "rmat", (14, 1 << 17, 1)),
+    ("rmat_s12_dense", "rmat", (12, 1 << 18, 5)),
+    ("banded_16k", "banded", (1 << 14, 32, 1024)),
+    ("kkt3d_12", "kkt3d", (12,)),
+]
