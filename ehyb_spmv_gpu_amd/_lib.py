@@ -48,7 +48,8 @@ class Config(C.Structure):
         ("seed", C.c_int32),
         ("n_top", C.c_int32),
         ("er_threads", C.c_int32),
-        ("reserved", C.c_int32 * 4),
+        ("ell_variant", C.c_int32),
+        ("reserved", C.c_int32 * 3),
     ]
 
 

@@ -40,9 +40,9 @@ Config resolve_config(const ehyb_config* in)
     int dflt_rows = c.window_mode == EHYB_WINDOW_REFERENCE ? c.lds_doubles : c.lds_doubles * 5 / 8;
     c.part_rows = z.part_rows > 0 ? std::min(z.part_rows, c.lds_doubles) : dflt_rows;
     c.part_rows = std::max(kSlabRows, round_down(c.part_rows, kSlabRows));
-    c.threads = z.threads > 0 ? z.threads : 512;
+    c.threads = z.threads > 0 ? z.threads : 1024;  // 2 workgroups x 16 waves per CU at the default window
     c.threads = std::min(1024, std::max(64, round_down(c.threads, 64)));
-    c.items_per_cu = z.items_per_cu > 0 ? z.items_per_cu : 4;
+    c.items_per_cu = z.items_per_cu > 0 ? z.items_per_cu : 3;  // measured best (profiles/r01_sweep_*.txt)
     c.partitioner = z.partitioner;
     c.er_seg_len = z.er_seg_len > 0 ? std::max(64, z.er_seg_len) : 4096;
     c.host_threads = z.host_threads;
@@ -50,6 +50,7 @@ Config resolve_config(const ehyb_config* in)
     c.seed = z.seed;
     c.n_top = z.n_top > 1 ? z.n_top : 1;
     c.er_threads = z.er_threads > 0 ? std::min(1024, std::max(64, round_down(z.er_threads, 64))) : 256;
+    c.ell_variant = z.ell_variant > 0 ? z.ell_variant : 3;
     return c;
 }
 
@@ -90,7 +91,8 @@ int ehyb_sizing(int dimension, const ehyb_config* cfg, int* nParts, int* vectorC
     if (dimension <= 0) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_sizing: dimension %d", dimension);
     Config c = resolve_config(cfg);
     int cache = c.part_rows;
-    int64_t usable = std::max<int64_t>(kSlabRows, (int64_t)(cache * 0.97));
+    // the graph partitioner needs slack to balance; contiguous blocks are cut exactly
+    int64_t usable = c.partitioner == EHYB_PART_CONTIGUOUS ? cache : std::max<int64_t>(kSlabRows, (int64_t)(cache * 0.97));
     int64_t parts = (dimension + usable - 1) / usable;
     if (c.n_top > 1) parts = (parts + c.n_top - 1) / c.n_top * c.n_top;
     if (parts < 1) parts = 1;

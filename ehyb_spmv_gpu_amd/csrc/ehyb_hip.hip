@@ -37,16 +37,60 @@ using namespace ehyb;
         }                                                                                     \
     } while (0)
 
-// ------------------------------------------------------------------ ELL kernel
+// ------------------------------------------------------------------ window staging
+// The LDS image of a partition's window starts at the even row at or below the partition start
+// (the layout builder numbers window-local columns from there), so the contiguous part moves
+// as 16-byte aligned double2 loads and ds_write_b128; up to four loads per thread are issued
+// before the first LDS write.  Halo columns follow: index load, x gather, LDS write, again four
+// deep.  win[0] may hold x[ps-1] when ps is odd; no entry refers to it.
 template <int THREADS>
+__device__ __forceinline__ void stage_window(double* __restrict__ win, const double* __restrict__ x, int ps,
+                                             int wl, const int* __restrict__ hc, int hn)
+{
+    const int base = ps & ~1;
+    const int cnt = wl + (ps & 1);
+    const int n2 = cnt >> 1;
+    const double2* __restrict__ x2 = reinterpret_cast<const double2*>(x + base);
+    double2* __restrict__ w2 = reinterpret_cast<double2*>(win);
+    for (int i0 = threadIdx.x; i0 < n2; i0 += 4 * THREADS) {
+        double2 a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j * THREADS < n2) a[j] = x2[i0 + j * THREADS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j * THREADS < n2) w2[i0 + j * THREADS] = a[j];
+    }
+    if ((cnt & 1) && threadIdx.x == 0) win[cnt - 1] = x[base + cnt - 1];
+    double* __restrict__ wh = win + cnt;
+    for (int i0 = threadIdx.x; i0 < hn; i0 += 4 * THREADS) {
+        int c[4];
+        double a[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j * THREADS < hn) c[j] = hc[i0 + j * THREADS];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j * THREADS < hn) a[j] = x[c[j]];
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+            if (i0 + j * THREADS < hn) wh[i0 + j * THREADS] = a[j];
+    }
+}
+
+// ------------------------------------------------------------------ ELL kernel
+// STAMP = true is a diagnostic instantiation (tools/ only): thread 0 of every workgroup records
+// the 100 MHz wall clock at entry, after staging and at exit into a buffer of its own.
+template <int THREADS, bool STAMP = false, bool SCALAR_STAGE = false>
 __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
     const int4* __restrict__ items, const int* __restrict__ part_boundary, const int* __restrict__ win_len,
     const int* __restrict__ halo_ptr, const int* __restrict__ halo_cols,
     const uint32_t* __restrict__ slab_pair_ptr, const int* __restrict__ slab_row,
     const double2* __restrict__ ell_val, const uint32_t* __restrict__ ell_col, const double* __restrict__ x,
-    double* __restrict__ y)
+    double* __restrict__ y, unsigned long long* __restrict__ stamps = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) double win[];
+    if (STAMP && threadIdx.x == 0) stamps[4 * blockIdx.x + 0] = wall_clock64();
     const int4 it = items[blockIdx.x];
     const int p = it.x;
     const int ps = part_boundary[p];
@@ -55,9 +99,15 @@ __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
     const int hb = halo_ptr[p];
     const int hn = halo_ptr[p + 1] - hb;
 
-    for (int i = threadIdx.x; i < wl; i += THREADS) win[i] = x[ps + i];
-    for (int i = threadIdx.x; i < hn; i += THREADS) win[wl + i] = x[halo_cols[hb + i]];
+    if (SCALAR_STAGE) {  // A/B arm: one dependent load per thread per pass
+        const int base = ps & ~1, cnt = wl + (ps & 1);
+        for (int i = threadIdx.x; i < cnt; i += THREADS) win[i] = x[base + i];
+        for (int i = threadIdx.x; i < hn; i += THREADS) win[cnt + i] = x[halo_cols[hb + i]];
+    } else {
+        stage_window<THREADS>(win, x, ps, wl, halo_cols + hb, hn);
+    }
     __syncthreads();
+    if (STAMP && threadIdx.x == 0) stamps[4 * blockIdx.x + 1] = wall_clock64();
 
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -91,6 +141,113 @@ __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
         const int row = slab_row[s] + lane;
         if (row < pe) y[row] = acc0 + acc1;
     }
+    if (STAMP) {
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            stamps[4 * blockIdx.x + 2] = wall_clock64();
+            unsigned xcc;
+            asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+            stamps[4 * blockIdx.x + 3] = xcc;
+        }
+    }
+}
+
+// ------------------------------------------------------------------ ELL kernel, pipelined
+// Same arithmetic as ehyb_ell_kernel.  Differences, all about keeping HBM requests in flight:
+//   * window staging issues 4 independent loads per thread before the first LDS write;
+//   * the slab walk is one software-pipelined stream of 4-pair groups: the loads of group g+1
+//     (possibly the first group of the wave's next slab) are issued before group g is
+//     consumed, so a wave always has 4 x (1 KiB + 256 B) outstanding, also across slabs;
+//   * a slab's last group is predicated (wave-uniform) instead of falling into a scalar tail.
+struct EllGroup {
+    double2 v[4];
+    uint32_t c[4];
+};
+
+// Unconditional loads: pair indices past the slab's last pair are clamped onto it (same cache
+// lines, no extra HBM traffic) and masked out when consumed, so the loop body stays one basic
+// block and the compiler can count outstanding loads exactly.
+__device__ __forceinline__ void ell_load(EllGroup& g, const double2* __restrict__ v,
+                                         const uint32_t* __restrict__ c, int k, int last)
+{
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int idx = min(k + j, last);  // scalar
+        g.v[j] = v[(size_t)idx * 64];
+        g.c[j] = c[(size_t)idx * 64];
+    }
+}
+
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void ehyb_ell_kernel_pipe(
+    const int4* __restrict__ items, const int* __restrict__ part_boundary, const int* __restrict__ win_len,
+    const int* __restrict__ halo_ptr, const int* __restrict__ halo_cols,
+    const uint32_t* __restrict__ slab_pair_ptr, const int* __restrict__ slab_row,
+    const double2* __restrict__ ell_val, const uint32_t* __restrict__ ell_col, const double* __restrict__ x,
+    double* __restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    const int4 it = items[blockIdx.x];
+    const int p = it.x;
+    const int ps = part_boundary[p];
+    const int pe = part_boundary[p + 1];
+    const int wl = win_len[p];
+    const int hb = halo_ptr[p];
+    const int hn = halo_ptr[p + 1] - hb;
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int WAVES = THREADS / 64;
+
+    stage_window<THREADS>(win, x, ps, wl, halo_cols + hb, hn);
+    __syncthreads();
+
+    int s = it.y + wave;
+    if (s >= it.z) return;
+    uint32_t p0 = slab_pair_ptr[s];
+    int np = (int)(slab_pair_ptr[s + 1] - p0);
+    const double2* __restrict__ v = ell_val + (size_t)p0 * 64 + lane;
+    const uint32_t* __restrict__ c = ell_col + (size_t)p0 * 64 + lane;
+    EllGroup ga, gb;  // ping-pong register sets: no copies, so no wait before the next issue
+    ell_load(ga, v, c, 0, max(np - 1, 0));
+
+    double acc0 = 0.0, acc1 = 0.0;
+    int k = 0;
+    // One pipeline step: issue the loads of the group after CUR into NXT, then consume CUR.
+#define ELL_STEP(CUR, NXT)                                                                        \
+    {                                                                                             \
+        const bool slab_end = k + 4 >= np;                                                        \
+        const int ns = slab_end ? s + WAVES : s;                                                  \
+        const bool has_next = ns < it.z;                                                          \
+        const int ms = has_next ? ns : s; /* keep the prefetch addresses valid at the very end */ \
+        const uint32_t q0 = slab_pair_ptr[ms];                                                    \
+        const int nnp = (int)(slab_pair_ptr[ms + 1] - q0);                                        \
+        const int nk = slab_end ? 0 : k + 4;                                                      \
+        ell_load(NXT, ell_val + (size_t)q0 * 64 + lane, ell_col + (size_t)q0 * 64 + lane, nk,     \
+                 max(nnp - 1, 0));                                                                \
+        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
+        {                                                                                         \
+            const bool live = k + j < np; /* wave-uniform mask of the clamped pairs */            \
+            const double vx = live ? CUR.v[j].x : 0.0;                                            \
+            const double vy = live ? CUR.v[j].y : 0.0;                                            \
+            acc0 = fma(vx, win[CUR.c[j] & 0xffffu], acc0);                                        \
+            acc1 = fma(vy, win[CUR.c[j] >> 16], acc1);                                            \
+        }                                                                                         \
+        if (slab_end) {                                                                           \
+            const int row = slab_row[s] + lane;                                                   \
+            if (row < pe) y[row] = acc0 + acc1;                                                   \
+            acc0 = 0.0;                                                                           \
+            acc1 = 0.0;                                                                           \
+            if (!has_next) break;                                                                 \
+        }                                                                                         \
+        s = ns;                                                                                   \
+        k = nk;                                                                                   \
+        np = nnp;                                                                                 \
+    }
+    for (;;) {
+        ELL_STEP(ga, gb)
+        ELL_STEP(gb, ga)
+    }
+#undef ELL_STEP
 }
 
 // ------------------------------------------------------------------ residual kernel
@@ -166,12 +323,21 @@ static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st)
 #define ELL_ARGS                                                                                            \
     (const int4*)P->d_items, P->d_part_boundary, P->d_win_len, P->d_halo_ptr, P->d_halo_cols,               \
         P->d_slab_pair_ptr, P->d_slab_row, (const double2*)P->d_ell_val, (const uint32_t*)P->d_ell_col, x, y
+    const int var = P->cfg.ell_variant;  // 1 simple, 2 pipelined, 3 simple + scalar staging (A/B arm)
+#define ELL_LAUNCH(T)                                                                                        \
+    if (var == 2)                                                                                            \
+        hipLaunchKernelGGL(ehyb_ell_kernel_pipe<T>, dim3(n_items), dim3(T), lds, st, ELL_ARGS);              \
+    else if (var == 3)                                                                                       \
+        hipLaunchKernelGGL((ehyb_ell_kernel<T, false, true>), dim3(n_items), dim3(T), lds, st, ELL_ARGS, nullptr); \
+    else                                                                                                     \
+        hipLaunchKernelGGL((ehyb_ell_kernel<T, false, false>), dim3(n_items), dim3(T), lds, st, ELL_ARGS, nullptr);
     switch (P->cfg.threads) {
-        case 256: hipLaunchKernelGGL(ehyb_ell_kernel<256>, dim3(n_items), dim3(256), lds, st, ELL_ARGS); break;
-        case 512: hipLaunchKernelGGL(ehyb_ell_kernel<512>, dim3(n_items), dim3(512), lds, st, ELL_ARGS); break;
-        case 1024: hipLaunchKernelGGL(ehyb_ell_kernel<1024>, dim3(n_items), dim3(1024), lds, st, ELL_ARGS); break;
+        case 256: ELL_LAUNCH(256) break;
+        case 512: ELL_LAUNCH(512) break;
+        case 1024: ELL_LAUNCH(1024) break;
         default: EHYB_FAIL(EHYB_ERR_ARG, "ELL workgroup size %d not built (256/512/1024)", P->cfg.threads);
     }
+#undef ELL_LAUNCH
 #undef ELL_ARGS
     HIP_TRY(hipGetLastError());
     return EHYB_OK;
@@ -196,7 +362,7 @@ template <class T>
 static int upload(T** dst, const std::vector<T>& src)
 {
     *dst = nullptr;
-    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T);
+    size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T) + 4096;  // slack: clamped prefetches
     HIP_TRY(hipMalloc((void**)dst, bytes));
     if (!src.empty()) HIP_TRY(hipMemcpy(*dst, src.data(), src.size() * sizeof(T), hipMemcpyHostToDevice));
     return EHYB_OK;
@@ -305,6 +471,37 @@ int ehyb_measure_read_bw(size_t bytes, int iters, double* gbps)
     return EHYB_OK;
 }
 
+// Diagnostic (tools/stamps.py): one launch of the stamped instantiation of the simple ELL kernel.
+// out[4*i + {0,1,2,3}] = entry / staged / exit wall-clock ticks (100 MHz) and XCC id of item i.
+int ehyb_debug_ell_stamps(ehyb_plan* P, const double* x, double* y, unsigned long long* out_host)
+{
+    if (!P || !P->uploaded || !out_host) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_debug_ell_stamps: bad arguments");
+    const HostLayout& H = P->host;
+    const int n_items = (int)(H.items.size() / 4);
+    const size_t lds = (((size_t)H.lds_doubles * 8) + 15) / 16 * 16;
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, (size_t)n_items * 32));
+    HIP_TRY(hipMemset(d, 0, (size_t)n_items * 32));
+#define STAMP_LAUNCH(T)                                                                                          \
+    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)lds));                                                                        \
+    hipLaunchKernelGGL((ehyb_ell_kernel<T, true>), dim3(n_items), dim3(T), lds, 0, (const int4*)P->d_items,        \
+                       P->d_part_boundary, P->d_win_len, P->d_halo_ptr, P->d_halo_cols, P->d_slab_pair_ptr,       \
+                       P->d_slab_row, (const double2*)P->d_ell_val, (const uint32_t*)P->d_ell_col, x, y, d);
+    switch (P->cfg.threads) {
+        case 256: STAMP_LAUNCH(256) break;
+        case 512: STAMP_LAUNCH(512) break;
+        case 1024: STAMP_LAUNCH(1024) break;
+        default: EHYB_FAIL(EHYB_ERR_ARG, "workgroup size %d not built", P->cfg.threads);
+    }
+#undef STAMP_LAUNCH
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
+    HIP_TRY(hipMemcpy(out_host, d, (size_t)n_items * 32, hipMemcpyDeviceToHost));
+    (void)hipFree(d);
+    return EHYB_OK;
+}
+
 int ehyb_plan_upload(ehyb_plan* P)
 {
     clear_error();
@@ -337,9 +534,15 @@ int ehyb_plan_upload(ehyb_plan* P)
 #undef UP
     // opt in to the full 160 KiB of LDS (the role of cudaFuncSetAttribute at kernel.cu:351,411)
     const int lds = (int)((((size_t)H.lds_doubles * 8) + 15) / 16 * 16);
-    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<256, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<512, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<512, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<1024, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel_pipe<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel_pipe<512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel_pipe<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
     P->uploaded = true;
     return EHYB_OK;
 }

@@ -37,6 +37,7 @@ struct Config {
     int seed;
     int n_top;
     int er_threads;
+    int ell_variant;
 };
 Config resolve_config(const ehyb_config* cfg);
 

@@ -81,7 +81,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         } else {
             src = {row_begin, row_end};
         }
-        const int cap = (m->partBoundary && m->nParts > 0) ? lds : std::min(lds, cfg.part_rows);
+        // one slot is kept free: the LDS image may start one row below an odd partition start
+        const int cap = (m->partBoundary && m->nParts > 0) ? lds - 1 : std::min(lds - 1, cfg.part_rows);
         for (size_t k = 0; k + 1 < src.size(); ++k) {
             int b = src[k], e = src[k + 1];
             if (e == b) continue;  // empty partition
@@ -113,10 +114,10 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             int wlen;
             PartScratch& S = ps[p];
             if (!halo_mode) {
-                wlen = std::min(lds, std::min(n, cfg.n_top > 1 ? row_end : n) - s);
+                wlen = std::min(lds - (s & 1), std::min(n, cfg.n_top > 1 ? row_end : n) - s);
             } else {
                 wlen = own;
-                int hcap = lds - own;
+                int hcap = lds - own - (s & 1);  // the LDS image starts at the even row below s
                 cand.clear();
                 for (int r = s; r < e; ++r)
                     for (int k = rp[r]; k < rp[r + 1]; ++k) {
@@ -185,7 +186,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     for (int p = 0; p < np; ++p) {
         L->halo_ptr[p + 1] = L->halo_ptr[p] + (int32_t)ps[p].halo.size();
         slab_base[p + 1] = slab_base[p] + (int64_t)ps[p].slab_w2.size();
-        max_win = std::max(max_win, L->win_len[p] + (int)ps[p].halo.size());
+        max_win = std::max(max_win, (pb[p] & 1) + L->win_len[p] + (int)ps[p].halo.size());
     }
     if (max_win > lds) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: window of %d doubles exceeds %d", max_win, lds);
     L->lds_doubles = max_win;
@@ -242,11 +243,13 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             for (int k = rp[r]; k < rp[r + 1]; ++k) {
                 int j = m->J[k];
                 int local = -1;
+                // window-local index: the LDS image starts at the even row at or below s, so the
+                // staging loads of the kernel are 16-byte aligned (x is hipMalloc-aligned)
                 if (j >= s && j < s + wlen)
-                    local = j - s;
+                    local = j - (s & ~1);
                 else if (halo_mode && !S.halo.empty()) {
                     int h = halo_lookup(S.halo, j);
-                    if (h >= 0) local = wlen + h;
+                    if (h >= 0) local = (s & 1) + wlen + h;
                 }
                 if (local >= 0) {
                     if (k_ell >= 2 * w2) {  // convert.c:251-254

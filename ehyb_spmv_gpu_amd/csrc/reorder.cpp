@@ -174,7 +174,7 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
 #pragma omp for schedule(dynamic, 4)
             for (int p = 0; p < nparts; ++p) {
                 const int own = pb[p + 1] - pb[p];
-                const int hcap = c.lds_doubles - own;
+                const int hcap = c.lds_doubles - own - (pb[p] & 1);
                 if (hcap <= 0) continue;
                 cand.clear();
                 for (int q = pb[p]; q < pb[p + 1]; ++q) {

@@ -83,7 +83,9 @@ typedef struct ehyb_config {
     int32_t seed;          /* partitioner tie-breaking seed (deterministic per seed)      */
     int32_t n_top;         /* top-level row blocks (one per GPU); 0/1 = single GPU        */
     int32_t er_threads;    /* residual workgroup size                                     */
-    int32_t reserved[4];
+    int32_t ell_variant;   /* ELL kernel A/B arms: 0 = default (3), 1 = simple loop + 4-deep staging,
+                              2 = software-pipelined loop, 3 = simple loop + scalar staging */
+    int32_t reserved[3];
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);

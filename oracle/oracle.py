@@ -162,7 +162,8 @@ def walk_plan(plan, x):
     for p, s0, s1, _ in items:
         ps, pe = int(pb[p]), int(pb[p + 1])
         wl = int(win_len[p])
-        win = np.concatenate([x[ps:ps + wl], x[halo_cols[halo_ptr[p]:halo_ptr[p + 1]]]])
+        base = ps & ~1  # the LDS image starts at the even row at or below the partition start
+        win = np.concatenate([x[base:ps + wl], x[halo_cols[halo_ptr[p]:halo_ptr[p + 1]]]])
         for s in range(s0, s1):
             p0, p1 = spp[s], spp[s + 1]
             acc = np.zeros(64, dtype=np.float64)
