@@ -67,7 +67,10 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     pb.clear();
     {
         std::vector<int> src;
-        if (m->partBoundary && m->nParts > 0) {
+        // A matrix that never went through the reorder step has nParts from the sizing rule but
+        // an all-zero partBoundary: treated as "no partition information".
+        const bool have_parts = m->partBoundary && m->nParts > 0 && m->partBoundary[m->nParts] == n;
+        if (have_parts) {
             bool okb = false, oke = false;
             for (int p = 0; p <= m->nParts; ++p) {
                 int b = m->partBoundary[p];
@@ -81,13 +84,24 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         } else {
             src = {row_begin, row_end};
         }
-        // one slot is kept free: the LDS image may start one row below an odd partition start
-        const int cap = (m->partBoundary && m->nParts > 0) ? lds - 1 : std::min(lds - 1, cfg.part_rows);
+        const int cap0 = have_parts ? lds : std::min(lds, cfg.part_rows);
         for (size_t k = 0; k + 1 < src.size(); ++k) {
             int b = src[k], e = src[k + 1];
             if (e == b) continue;  // empty partition
-            int pieces = (e - b + cap - 1) / cap;
-            for (int q = 0; q < pieces; ++q) pb.push_back(b + (int)((int64_t)(e - b) * q / pieces));
+            // The LDS image starts one row below an odd piece start, so such a piece may hold
+            // one row less: retry with a smaller cap if a piece would not fit.
+            for (int cap = cap0;; --cap) {
+                int pieces = (e - b + cap - 1) / cap;
+                bool fits = true;
+                for (int q = 0; q < pieces && fits; ++q) {
+                    int s0 = b + (int)((int64_t)(e - b) * q / pieces), s1 = b + (int)((int64_t)(e - b) * (q + 1) / pieces);
+                    fits = (s0 & 1) + (s1 - s0) <= lds;
+                }
+                if (fits || cap <= 2) {
+                    for (int q = 0; q < pieces; ++q) pb.push_back(b + (int)((int64_t)(e - b) * q / pieces));
+                    break;
+                }
+            }
         }
         pb.push_back(row_end);
     }

@@ -1,0 +1,219 @@
+"""Host layout builder (the COO2EHYB role): invariants, reference-rule agreement, edge cases.
+CPU only: the layout is walked with oracle.walk_plan, which indexes the arrays exactly as the
+HIP kernels do."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import ehyb_ref_layout as R
+from util import SMALL_CASES, Case
+
+
+def _walk_ok(E, O, c, plan):
+    yp, written = O.walk_plan(plan, c.xp)
+    assert (written[plan.rows[0]:plan.rows[1]] == 1).all(), "every row is written exactly once by the ELL phase"
+    bad, worst = c.check(yp)
+    assert bad == 0, f"worst {worst:.3e}"
+
+
+@pytest.mark.parametrize("name,kind,args", SMALL_CASES, ids=[c[0] for c in SMALL_CASES])
+@pytest.mark.parametrize("mode", [1, 2], ids=["refwindow", "halo"])
+def test_walk_equals_oracle(E, O, name, kind, args, mode):
+    cfg = E.make_config(window_mode=mode, lds_doubles=2048)
+    c = Case(E, O, kind, args, cfg)
+    plan = E.Plan(c.m, cfg, upload=False)
+    _walk_ok(E, O, c, plan)
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_structural_invariants(E, O, mode):
+    """The reference's exit()-style self-checks (convert.c:122-125,226-263,287-303) as assertions:
+    (i) every entry lands in exactly one of ELL / residual, (ii) window-local columns stay inside
+    the window, (iii) no row exceeds its slab width, (iv) residual rows map back uniquely."""
+    cfg = E.make_config(window_mode=mode, lds_doubles=1024, er_seg_len=64)
+    c = Case(E, O, "rmat", (13, 1 << 16, 2), cfg)
+    plan = E.Plan(c.m, cfg, upload=False)
+    st = plan.stats
+    A = c.m.to_scipy()
+    assert st["nnz_ell"] + st["nnz_er"] == c.nnz == st["nnz"]
+    assert st["size_block_ell"] == st["nnz_ell"] + st["ell_padding"]
+    pb, wl = plan.array("part_boundary"), plan.array("win_len")
+    hp, hc = plan.array("halo_ptr"), plan.array("halo_cols")
+    spp, srow, spart = plan.array("slab_pair_ptr").astype(np.int64), plan.array("slab_row"), plan.array("slab_part")
+    ev, ec = plan.array("ell_val"), plan.array("ell_col").astype(np.int64)
+    assert pb[0] == 0 and pb[-1] == c.n and np.all(np.diff(pb) > 0)
+    assert spp[-1] * 128 == st["size_block_ell"] == len(ev) == len(ec)
+    rp, J, V = c.m.row_idx, c.m.J, c.m.V
+    seen = 0
+    for s in range(len(srow)):
+        p = spart[s]
+        ps, pe = pb[p], pb[p + 1]
+        base = ps & ~1
+        wsize = (ps & 1) + wl[p] + (hp[p + 1] - hp[p])
+        assert wsize <= cfg.lds_doubles
+        cols = ec[spp[s] * 128:spp[s + 1] * 128].reshape(-1, 64, 2)
+        vals = ev[spp[s] * 128:spp[s + 1] * 128].reshape(-1, 64, 2)
+        assert cols.size == 0 or cols.max() < wsize                              # (ii)
+        halo = hc[hp[p]:hp[p + 1]]
+        assert np.all(np.diff(halo) > 0) and not np.any((halo >= ps) & (halo < pe))
+        for lane in range(64):
+            r = srow[s] + lane
+            if r >= pe:
+                assert not vals[:, lane, :].any()                                # padding lanes are zero
+                continue
+            rc, rv = J[rp[r]:rp[r + 1]], V[rp[r]:rp[r + 1]]
+            in_own = (rc >= ps) & (rc < ps + wl[p])
+            in_halo = np.isin(rc, halo)
+            k = int(np.count_nonzero(in_own | in_halo))
+            assert k <= 2 * cols.shape[0]                                         # (iii)
+            flat_c, flat_v = cols[:, lane, :].reshape(-1), vals[:, lane, :].reshape(-1)
+            # entries keep the row's storage order; window-local ids decode to the global column
+            dec = np.where(flat_c[:k] < (ps & 1) + wl[p], flat_c[:k] + base, 0)
+            hal = flat_c[:k] >= (ps & 1) + wl[p]
+            dec[hal] = halo[flat_c[:k][hal] - (ps & 1) - wl[p]]
+            assert np.array_equal(dec, rc[in_own | in_halo]) and np.array_equal(flat_v[:k], rv[in_own | in_halo])
+            assert not flat_v[k:].any() and not flat_c[k:].any()                 # zero padding (col 0, val 0)
+            seen += k
+    assert seen == st["nnz_ell"]                                                  # (i)
+    seg_ptr, seg_row = plan.array("er_seg_ptr"), plan.array("er_seg_row")
+    assert np.all(np.diff(np.diff(seg_ptr)) <= 0), "segments sorted by length, longest first"
+    assert np.diff(seg_ptr).max() <= cfg.er_seg_len
+    rows = seg_row & 0x7FFFFFFF
+    uniq, counts = np.unique(rows, return_counts=True)
+    split = set(uniq[counts > 1].tolist())
+    assert split == set(rows[seg_row < 0].tolist())                               # (iv) + split flag
+    assert len(uniq) == st["rows_er"]
+    bins = plan.array("er_bins")
+    assert bins[0] == 0 and bins[3] == len(seg_row) and bins[1] <= bins[2] <= bins[3]
+    items = plan.array("items").reshape(-1, 4)
+    covered = np.zeros(len(srow), dtype=int)
+    for p, s0, s1, _ in items:
+        assert s0 < s1 and np.all(spart[s0:s1] == p)
+        covered[s0:s1] += 1
+    assert np.all(covered == 1), "work items tile the slabs exactly once"
+    del A
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_reference_window_rule_matches_restated_convert(E, O, seed):
+    """EHYB_WINDOW_REFERENCE uses the membership test of convert.c:247: the residual count must
+    equal toER of the restated COO2EHYB, and the ELL size must equal its sizeBlockELL at slab
+    height 64 (widths rounded up to even here)."""
+    rng = np.random.default_rng(seed)
+    n, size, cache = 1024, 256, 256
+    rows, cols = [], []
+    for i in range(n):
+        p = i // size
+        for j in set(rng.integers(p * size, (p + 1) * size, rng.integers(1, 9)).tolist()
+                     + rng.integers(0, n, rng.integers(0, 3)).tolist() + [i]):
+            rows.append(i)
+            cols.append(j)
+    A = sp.coo_matrix((rng.uniform(-1, 1, len(rows)), (rows, cols)), shape=(n, n)).tocsr()
+    A.sort_indices()
+    cfg = E.make_config(window_mode=1, lds_doubles=cache)
+    m = E.Matrix.from_csr(A.indptr, A.indices, A.data, cfg)
+    pb = np.arange(0, n + 1, size, dtype=np.int32)
+    m.c.nParts = len(pb) - 1
+    m.part_boundary[:] = pb
+    plan = E.Plan(m, cfg, upload=False)
+    st = plan.stats
+    L = R.build_reference_ehyb(A.indptr, A.indices, A.data, pb, cache, warp=64)
+    assert st["nnz_er"] == L["to_er"]
+    assert st["rows_er"] == L["rows_er"]
+    # same widths up to the even rounding
+    w_ref = L["width"]
+    w_here = 2 * np.diff(plan.array("slab_pair_ptr").astype(np.int64))
+    assert np.array_equal(w_here, (w_ref + 1) // 2 * 2)
+    x = O.x_glibc(n)
+    assert np.allclose(O.walk_plan(plan, x)[0], R.walk_reference_ehyb(L, x), rtol=0, atol=1e-13)
+
+
+def _case_from_csr(E, O, A, cfg):
+    A = sp.csr_matrix(A)
+    A.sort_indices()
+    m = E.Matrix.from_csr(A.indptr, A.indices, A.data, cfg)
+    x = O.x_glibc(m.n)
+    y_ref = O.spmv_coo(m.n, m.I, m.J, m.V, x) if m.nnz else np.zeros(m.n)
+    scale = O.abs_rowsum(m.n, m.I, m.J, m.V, x) if m.nnz else np.zeros(m.n)
+    return m, x, y_ref, scale
+
+
+@pytest.mark.parametrize("mode", [1, 2])
+def test_edge_cases(E, O, mode):
+    """Empty rows, a dense row, a matrix smaller than one slab, a zero matrix, diagonal only."""
+    cfg = E.make_config(window_mode=mode, lds_doubles=128, er_seg_len=64)
+    rng = np.random.default_rng(0)
+    mats = {
+        "tiny_3x3": sp.csr_matrix(np.array([[1.0, 0, 2], [0, 0, 0], [3, 0, 4]])),
+        "one_by_one": sp.csr_matrix(np.array([[2.5]])),
+        "zero_5x5": sp.csr_matrix((5, 5)),
+        "diag_200": sp.identity(200, format="csr") * 3.0,
+        "empty_rows": sp.random(300, 300, density=0.01, random_state=1, format="csr"),
+        "dense_row": sp.vstack([sp.csr_matrix(np.ones((1, 700))), sp.random(699, 700, density=0.005, random_state=2)]).tocsr(),
+        "dense_col": sp.hstack([sp.csr_matrix(np.ones((500, 1))), sp.random(500, 499, density=0.005, random_state=3)]).tocsr(),
+    }
+    for name, A in mats.items():
+        m, x, y_ref, scale = _case_from_csr(E, O, A, cfg)
+        if m.nnz:
+            m.reorder(cfg, symmetric=False)
+        else:
+            m.reorder_list[:] = np.arange(m.n, dtype=np.int32)
+            m.c.nParts = 1
+            m.part_boundary[:] = [0, m.n]
+        plan = E.Plan(m, cfg, upload=False)
+        yp, written = O.walk_plan(plan, E.vector_reorder(x, m.reorder_list))
+        assert (written == 1).all(), name
+        y = E.vector_recover(yp, m.reorder_list)
+        assert O.check_tolerance(y, y_ref, scale + 1e-300)[0] == 0, name
+    del rng
+
+
+def test_oversized_partition_is_split(E, O):
+    """A caller whose partitions exceed the window (e.g. a single partition) still gets a valid plan."""
+    cfg = E.make_config(window_mode=2, lds_doubles=256)
+    c = Case(E, O, "stencil2d", (60, 50, 5, 500, 1), cfg, reorder=False)
+    c.m.c.nParts = 1
+    c.m.part_boundary[:] = [0, c.n]
+    plan = E.Plan(c.m, cfg, upload=False)
+    assert plan.stats["n_parts"] >= c.n // 256
+    _walk_ok(E, O, c, plan)
+    # no partition information at all
+    c.m.c.nParts = 0
+    plan2 = E.Plan(c.m, cfg, upload=False)
+    _walk_ok(E, O, c, plan2)
+
+
+def test_row_range_plans_compose(E, O):
+    """Plans over row blocks (the multi-GPU sharding) together reproduce the whole product."""
+    cfg = E.make_config(window_mode=2, lds_doubles=512, n_top=2)
+    c = Case(E, O, "fem3d", (12000, 3, 16, 16, 13500, 1, 3), cfg)
+    pb = c.m.part_boundary
+    cut = int(pb[len(pb) // 2])
+    y = np.zeros(c.n)
+    for r0, r1 in ((0, cut), (cut, c.n)):
+        plan = E.Plan(c.m, cfg, rows=(r0, r1), upload=False)
+        yp, written = O.walk_plan(plan, c.xp)
+        assert written[r0:r1].min() == 1 and written[:r0].sum() == 0 and written[r1:].sum() == 0
+        y[r0:r1] = yp[r0:r1]
+        # with n_top > 1 the ELL windows only touch the block's own x segment
+        hc = plan.array("halo_cols")
+        assert len(hc) == 0 or (hc.min() >= r0 and hc.max() < r1)
+    assert c.check(y)[0] == 0
+    with pytest.raises(E.EhybError):
+        E.Plan(c.m, cfg, rows=(1, c.n), upload=False)  # not on a partition boundary
+
+
+def test_bad_inputs_are_rejected(E, O):
+    cfg = E.make_config()
+    A = sp.random(50, 50, density=0.1, random_state=0, format="csr")
+    m = E.Matrix.from_csr(A.indptr, A.indices, A.data, cfg)
+    m.c.nParts = 0
+    keep = m.J[0]
+    m.J[0] = 50  # out of range column
+    with pytest.raises(E.EhybError):
+        E.Plan(m, cfg, upload=False)
+    m.J[0] = keep
+    m.row_idx[3] = m.row_idx[2] - 1 if m.row_idx[2] > 0 else 0
+    m.row_idx[2] = m.row_idx[3] + 5
+    with pytest.raises(E.EhybError):
+        E.Plan(m, cfg, upload=False)

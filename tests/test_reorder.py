@@ -1,0 +1,146 @@
+"""Host pre-step: partitioner and matrixReorder equivalents (reference reordering.c), CPU only."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+
+from oracle import ehyb_ref_layout as R
+
+
+def grid_graph(nx, ny):
+    idx = np.arange(nx * ny).reshape(ny, nx)
+    e = [(idx[:, :-1].ravel(), idx[:, 1:].ravel()), (idx[:-1, :].ravel(), idx[1:, :].ravel())]
+    r = np.concatenate([a for a, _ in e] + [b for _, b in e])
+    c = np.concatenate([b for _, b in e] + [a for a, _ in e])
+    A = sp.coo_matrix((np.ones(len(r)), (r, c)), shape=(nx * ny, nx * ny)).tocsr()
+    return A
+
+
+def cut_of(A, part):
+    C = A.tocoo()
+    return int(np.count_nonzero(part[C.row] != part[C.col]) // 2)
+
+
+@pytest.mark.parametrize("nparts", [2, 7, 16, 64])
+def test_partition_is_valid_and_compact(E, nparts):
+    A = grid_graph(96, 80)
+    n = A.shape[0]
+    cap = int(np.ceil(n / nparts * 1.03))
+    part, cut = E.partition_graph(A.indptr, A.indices, nparts, cap)
+    assert part.min() >= 0 and part.max() < nparts
+    sizes = np.bincount(part, minlength=nparts)
+    assert sizes.max() <= cap and sizes.sum() == n
+    assert cut == cut_of(A, part)
+    # compact parts: within 1.5x of a square tiling (perimeter 4*sqrt(area) per part, every
+    # cut edge shared by two parts)
+    ideal = 4 * np.sqrt(n / nparts) * nparts / 2
+    assert cut < 1.5 * ideal + 40, (cut, ideal)
+    # deterministic for a given seed
+    part2, cut2 = E.partition_graph(A.indptr, A.indices, nparts, cap)
+    assert np.array_equal(part, part2) and cut == cut2
+
+
+def test_partition_hard_cap_and_errors(E):
+    A = grid_graph(40, 40)
+    n = A.shape[0]
+    part, _ = E.partition_graph(A.indptr, A.indices, 10, 160)  # exactly n/10: zero slack
+    assert np.bincount(part).max() <= 160
+    with pytest.raises(E.EhybError):
+        E.partition_graph(A.indptr, A.indices, 10, 150)  # 10 x 150 < 1600
+    one, cut = E.partition_graph(A.indptr, A.indices, 1)
+    assert not one.any() and cut == 0
+    # vertex weights (used for the per-GPU blocks): balance on weight, not count
+    w = np.ones(n, dtype=np.int32)
+    w[: n // 4] = 5
+    part, _ = E.partition_graph(A.indptr, A.indices, 4, 0, vwgt=w)
+    pw = np.bincount(part, weights=w, minlength=4)
+    assert pw.max() <= w.sum() / 4 * 1.001 + 1 + 5
+
+
+def test_partition_contiguous_and_disconnected(E):
+    A = sp.block_diag([grid_graph(10, 10), grid_graph(7, 9), sp.csr_matrix((5, 5))]).tocsr()  # 5 isolated vertices
+    n = A.shape[0]
+    part, _ = E.partition_graph(A.indptr, A.indices, 6, 32)
+    assert np.bincount(part, minlength=6).max() <= 32
+    cfg = E.make_config(partitioner=E.EHYB_PART_CONTIGUOUS)
+    part, _ = E.partition_graph(A.indptr, A.indices, 4, 0, cfg=cfg)
+    assert np.all(np.diff(part) >= 0) and part[0] == 0 and part[-1] == 3
+
+
+@pytest.mark.parametrize("kind,args,sym", [
+    ("stencil2d", (40, 30, 9, 300, 2), True),
+    ("rmat", (10, 1 << 13, 4), False),
+    ("fem3d", (3000, 3, 10, 10, 13500, 1, 5), True),
+])
+@pytest.mark.parametrize("mode", [1, 2])
+def test_matrix_reorder_contract(E, O, kind, args, sym, mode):
+    """What matrixReorder[_unsym] promises (reordering.c:231-378 / 41-228)."""
+    cfg = E.make_config(window_mode=mode, lds_doubles=256)
+    m = E.Matrix.generate(kind, *args, cfg=cfg)
+    A = m.to_scipy()
+    n, nnz = m.n, m.nnz
+    nparts, cache = m.c.nParts, int(m.c.vectorCacheSize)
+    m.reorder(cfg, symmetric=sym)
+    lst = m.reorder_list.copy()
+    assert sorted(lst.tolist()) == list(range(n)), "reorderList is a permutation"
+    pb = m.part_boundary
+    assert pb[0] == 0 and pb[-1] == n and len(pb) == nparts + 1
+    assert np.diff(pb).max() <= cache
+    assert m.nnz == nnz
+    rp, I, J, V = m.row_idx, m.I, m.J, m.V
+    assert np.array_equal(np.repeat(np.arange(n), np.diff(rp)), I), "row-grouped (rowIdx consistent with I)"
+    assert np.array_equal(m.num_in_row, np.diff(rp))
+    # P A P^T: entry (i,j) of A sits at (list[i], list[j])
+    B = sp.csr_matrix((V, J, rp.astype(np.int64)), shape=(n, n))
+    inv = np.empty(n, dtype=np.int64)
+    inv[lst] = np.arange(n)
+    assert abs(B[lst][:, lst] - A).max() == 0 if False else abs(B - A[inv][:, inv]).max() == 0
+    # entries of a row keep their original relative order (reordering.c:348-357)
+    i_old = int(np.argmax(np.diff(A.indptr)))
+    new_row = lst[i_old]
+    assert np.array_equal(J[rp[new_row]:rp[new_row + 1]], lst[A.indices[A.indptr[i_old]:A.indptr[i_old + 1]]])
+    # numInRow2 = entries inside [partStart, partStart + cache) (reordering.c:358-361)
+    assert np.array_equal(m.num_in_row2, R.num_in_row2(rp, J, pb, cache))
+    # rows of a partition are sorted by the ELL-entry key, descending (reordering.c:334):
+    # in reference-window mode the key is the in-partition count
+    if mode == 1:
+        part_of = np.searchsorted(pb, np.arange(n), side="right") - 1
+        key = np.zeros(n, dtype=np.int64)
+        np.add.at(key, I[part_of[I] == part_of[J]], 1)
+        for p in range(nparts):
+            k = key[pb[p]:pb[p + 1]]
+            assert np.all(np.diff(k) <= 0), f"partition {p} not sorted by in-partition entries"
+    # vectorReorder / vectorRecover round trip (reordering.c:380-391)
+    x = O.x_glibc(n)
+    xp = E.vector_reorder(x, lst)
+    assert np.array_equal(xp[lst], x) and np.array_equal(E.vector_recover(xp, lst), x)
+    # the permuted product, un-permuted, is the original product
+    y = E.vector_recover(B @ xp, lst)
+    assert np.allclose(y, A @ x, rtol=0, atol=1e-13)
+
+
+def test_reorder_rejects_bad_input(E):
+    cfg = E.make_config()
+    m = E.Matrix.generate("stencil2d", 10, 10, 5, 0, 1, cfg=cfg)
+    m.c.nParts = 0
+    with pytest.raises(E.EhybError):
+        m.reorder(cfg)
+    m.c.nParts = 2
+    m.J[3] = 1000
+    with pytest.raises(E.EhybError):
+        m.reorder(cfg)
+
+
+def test_sizing(E):
+    """The MI355X re-derivation of solver_test.c:158-182: window from the LDS budget, parts from it."""
+    cfg = E.make_config(window_mode=2, lds_doubles=10240)
+    nparts, cache, kpp = E.sizing(943695, cfg)
+    assert cache == 6400 and cache <= 10240
+    assert nparts * cache >= 943695 and (nparts - 1) * cache < 943695 * 1.04
+    assert kpp >= 1
+    ref = E.make_config(window_mode=1, lds_doubles=20480)
+    nparts, cache, _ = E.sizing(4194304, ref)           # config 3: past the reference's int16 limit
+    assert cache == 20480 and nparts * cache >= 4194304
+    small = E.sizing(10974, E.make_config())            # bcsstk17-sized
+    assert small[0] >= 1 and small[1] <= 20480
+    with pytest.raises(E.EhybError):
+        E.sizing(0)
