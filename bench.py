@@ -51,6 +51,7 @@ def main():
     ap.add_argument("--items-per-cu", type=int, default=0)
     ap.add_argument("--window-mode", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange first, then multiply (no stream overlap)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -119,35 +120,19 @@ def main():
     log(f"[bench] reorder (partition into {m.c.nParts} parts) {time.time() - t0:.1f}s")
     perm = m.reorder_list.copy()
     xp = E.vector_reorder(x, perm)
-    pb = m.part_boundary.copy()
-    if world > 1:
-        import ctypes as C
+    from ehyb_spmv_gpu_amd import dist as D
 
-        blocks = (C.c_int * (world + 1))()
-        E.host._check(E.host._lib.load().ehyb_top_boundary(C.byref(m.c), C.byref(cfg), world, blocks), "ehyb_top_boundary")
-        row_cuts = [int(pb[blocks[b]]) for b in range(world + 1)]
-    else:
-        row_cuts = [0, n]
-    r0, r1 = row_cuts[rank], row_cuts[rank + 1]
+    dev = torch.device("cuda", local_rank)
     t0 = time.time()
-    plan = E.Plan(m, cfg, rows=(r0, r1))
+    sh = D.ShardedSpmv(m, cfg, rank, world, dev, overlap=not args.no_overlap)   # plan for this rank's row block
+    sh.set_x(xp)
+    plan, r0, r1, row_cuts = sh.plan, sh.r0, sh.r1, sh.cuts
+    x_d, y_d = sh.x, sh.y
     st = plan.stats
     log(f"[bench] rank {rank}: rows [{r0},{r1}) plan built+uploaded in {time.time() - t0:.1f}s: "
         f"ell {st['nnz_ell']} er {st['nnz_er']} pad {st['ell_padding']} items {st['n_items']} lds {st['lds_bytes']}B")
-
-    dev = torch.device("cuda", local_rank)
-    x_d = torch.from_numpy(xp).to(dev)
-    y_d = torch.zeros(n, dtype=torch.float64, device=dev)
     stream = torch.cuda.current_stream().cuda_stream
-
-    xs = [x_d[row_cuts[b]:row_cuts[b + 1]] for b in range(world)] if world > 1 else None
-
-    def step():
-        if world > 1:
-            # every rank publishes its own x segment, all ranks end with the full x:
-            # all-gatherv over xGMI (ragged segments -> list form).
-            dist.all_gather(xs, xs[rank])
-        plan.spmv(x_d.data_ptr(), y_d.data_ptr(), stream)
+    step = sh.step  # N = 1: one SpMV; N > 1: all-gatherv of the x segments over xGMI + local multiply
 
     for _ in range(args.warmup):
         step()

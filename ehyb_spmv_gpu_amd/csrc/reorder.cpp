@@ -103,6 +103,10 @@ static void build_adjacency(const matrixCOO* m, bool symmetric_pattern, std::vec
 
 using namespace ehyb;
 
+// First partition of every top-level block of the most recent two-level reorder on this thread
+// (read back through ehyb_top_boundary).
+static thread_local std::vector<int> g_block_first;
+
 extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const ehyb_config* cfg)
 {
     clear_error();
@@ -134,6 +138,56 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
         int rc;
         if (c.partitioner == EHYB_PART_MTMETIS) {
             rc = mtmetis_partition(n, xadj.data(), adj.data(), nparts, symmetric_pattern ? 1 : 6, part.data(), &cut);
+        } else if (c.n_top > 1) {
+            // Two levels: n_top row blocks of equal entry counts -- one per GPU, so
+            // that every GPU streams the same bytes -- then window-sized partitions inside each
+            // block.  The partitions of a block are numbered consecutively.
+            std::vector<int> vw(n, 1);
+            for (int64_t k = 0; k < nnz; ++k) vw[m->I[k]]++;
+            int64_t total = 0;
+            int maxw = 1;
+            for (int i = 0; i < n; ++i) total += vw[i], maxw = std::max(maxw, vw[i]);
+            std::vector<int> top(n, 0);
+            int64_t tcap = (int64_t)((double)total / c.n_top * 1.03) + maxw;
+            rc = partition_graph(n, xadj.data(), adj.data(), vw.data(), c.n_top, (int)std::min<int64_t>(tcap, 0x7FFFFFFF), c,
+                                 top.data(), &cut);
+            if (rc != EHYB_OK) return rc;
+            const int usable = std::max(kSlabRows, (int)(cache * 0.97));
+            std::vector<int> local(n, -1), verts;
+            std::vector<int64_t> sx;
+            std::vector<int> sa, spart;
+            int offset = 0;
+            g_block_first.assign(c.n_top + 1, 0);
+            for (int b = 0; b < c.n_top; ++b) {
+                verts.clear();
+                for (int i = 0; i < n; ++i)
+                    if (top[i] == b) {
+                        local[i] = (int)verts.size();
+                        verts.push_back(i);
+                    }
+                const int nb = (int)verts.size();
+                const int kb = std::max(1, (nb + usable - 1) / usable);
+                sx.assign((size_t)nb + 1, 0);
+                sa.clear();
+                for (int q = 0; q < nb; ++q) {
+                    int v = verts[q];
+                    for (int64_t e = xadj[v]; e < xadj[v + 1]; ++e)
+                        if (top[adj[e]] == b) sa.push_back(local[adj[e]]);
+                    sx[q + 1] = (int64_t)sa.size();
+                }
+                spart.assign(nb, 0);
+                int64_t bcut = 0;
+                if (nb > 0) {
+                    rc = partition_graph(nb, sx.data(), sa.data(), nullptr, kb, cap, c, spart.data(), &bcut);
+                    if (rc != EHYB_OK) return rc;
+                }
+                for (int q = 0; q < nb; ++q) part[verts[q]] = offset + spart[q];
+                g_block_first[b] = offset;
+                offset += kb;
+            }
+            g_block_first[c.n_top] = offset;
+            nparts = offset;
+            m->nParts = nparts;
         } else {
             rc = partition_graph(n, xadj.data(), adj.data(), nullptr, nparts, cap, c, part.data(), &cut);
         }
@@ -264,8 +318,13 @@ extern "C" int ehyb_top_boundary(const matrixCOO* m, const ehyb_config* cfg, int
 {
     if (!m || !part_of_block || n_top < 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_top_boundary: bad arguments");
     (void)cfg;
-    // Blocks are runs of whole partitions with (nearly) equal entry counts.
     const int np = m->nParts;
+    // the blocks of a two-level reorder done by this thread on this matrix
+    if ((int)g_block_first.size() == n_top + 1 && g_block_first[n_top] == np) {
+        for (int b = 0; b <= n_top; ++b) part_of_block[b] = g_block_first[b];
+        return EHYB_OK;
+    }
+    // otherwise: runs of whole partitions with (nearly) equal entry counts
     std::vector<int64_t> w(np + 1, 0);
     for (int p = 0; p < np; ++p)
         w[p + 1] = w[p] + (m->rowIdx[m->partBoundary[p + 1]] - m->rowIdx[m->partBoundary[p]]);
@@ -274,7 +333,6 @@ extern "C" int ehyb_top_boundary(const matrixCOO* m, const ehyb_config* cfg, int
     for (int b = 1; b < n_top; ++b) {
         int64_t target = w[np] * b / n_top;
         while (p < np && w[p] < target) ++p;
-        // keep at least one partition per block when possible
         p = std::max(p, part_of_block[b - 1] + (np >= n_top ? 1 : 0));
         p = std::min(p, np - (np >= n_top ? (n_top - b) : 0));
         part_of_block[b] = p;

@@ -1,0 +1,26 @@
+"""N > 1 on CPU: world_size-2 (and 3) gloo runs of the sharding + exchange logic."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+@pytest.mark.parametrize("world", [2, 3])
+def test_sharded_path_gloo(world):
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "dist_worker.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "DIST_OK" in p.stdout, p.stdout[-3000:]
+    assert p.stdout.count("DIST_CASE") == 3

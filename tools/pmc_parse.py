@@ -1,0 +1,63 @@
+#!/usr/bin/env python3
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into profiles/pmc_latest.json.
+
+usage: python tools/pmc_parse.py <fetch_dir> <write_dir> <out.json>
+
+Units and corrections as MI355X_MICROARCH.md (HBM / rocprofv3) prescribes: the counters are in
+KiB; on gfx950 FETCH_SIZE reports exactly half of a wide coalesced streaming read, so it is
+doubled -- the factor is re-measured here on ehyb_read_kernel (1 GiB of 16-byte-per-lane loads
+per launch) and that measured factor is what is applied to the SpMV kernels.
+"""
+import csv
+import glob
+import json
+import os
+import sys
+
+
+def per_kernel(dirpath, counter):
+    out = {}
+    files = glob.glob(os.path.join(dirpath, "**", "*counter_collection.csv"), recursive=True)
+    for f in files:
+        for row in csv.DictReader(open(f)):
+            if row.get("Counter_Name") != counter:
+                continue
+            name = row["Kernel_Name"].split("(")[0].replace("void ", "")
+            out.setdefault(name, []).append(float(row["Counter_Value"]))
+    return out
+
+
+def main():
+    fetch_dir, write_dir, out_path = sys.argv[1:4]
+    fetch = per_kernel(fetch_dir, "FETCH_SIZE")
+    write = per_kernel(write_dir, "WRITE_SIZE")
+    res = {"units": "bytes per launch; counters are KiB", "kernels": {}}
+    probe = [k for k in fetch if "ehyb_read_kernel" in k]
+    factor = 2.0
+    if probe:
+        vals = fetch[probe[0]]
+        mean_kib = sum(vals) / len(vals)
+        factor = (1 << 30) / (mean_kib * 1024.0)
+        res["fetch_calibration"] = {"kernel": probe[0], "known_bytes": 1 << 30, "FETCH_SIZE_KiB_mean": mean_kib,
+                                    "factor": factor, "guide_factor": 2.0}
+    for name in sorted(set(fetch) | set(write)):
+        fv, wv = fetch.get(name, []), write.get(name, [])
+        f_raw = sum(fv) / len(fv) * 1024 if fv else None
+        w_raw = sum(wv) / len(wv) * 1024 if wv else None
+        res["kernels"][name] = {
+            "launches": max(len(fv), len(wv)),
+            "FETCH_SIZE_bytes_raw": f_raw, "WRITE_SIZE_bytes": w_raw,
+            "fetch_bytes_corrected": None if f_raw is None else f_raw * factor,
+            "hbm_bytes_per_launch": None if f_raw is None else f_raw * factor + (w_raw or 0.0),
+        }
+    for name, k in res["kernels"].items():
+        if "ehyb_ell_kernel" in name and k["hbm_bytes_per_launch"]:
+            res["ehyb_ell_kernel_hbm_bytes_per_launch"] = k["hbm_bytes_per_launch"]
+        if "ehyb_er_kernel" in name and k["hbm_bytes_per_launch"]:
+            res["ehyb_er_kernel_hbm_bytes_per_launch"] = k["hbm_bytes_per_launch"]
+    json.dump(res, open(out_path, "w"), indent=1)
+    print(json.dumps(res, indent=1))
+
+
+if __name__ == "__main__":
+    main()

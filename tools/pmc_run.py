@@ -1,0 +1,45 @@
+#!/usr/bin/env python3
+"""Workload for the PMC passes (run under `rocprofv3 --pmc <counter> --kernel-trace`):
+a few launches of the streaming-read probe over a known byte count (calibration of FETCH_SIZE
+for this access width, MI355X_MICROARCH.md section HBM) followed by SpMVs of the bench workload.
+
+usage: rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d OUT -- python3 tools/pmc_run.py
+"""
+import argparse
+import ctypes as C
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", default="audikw_1-like")
+    ap.add_argument("--iters", type=int, default=10)
+    args = ap.parse_args()
+    import bench as B
+    import ehyb_spmv_gpu_amd as E
+    from ehyb_spmv_gpu_amd import _lib
+
+    lib = _lib.load()
+    bw = C.c_double()
+    lib.ehyb_measure_read_bw(1 << 30, 5, C.byref(bw))  # 8 launches of ehyb_read_kernel over 1 GiB
+    gen, gargs, _ = B.WORKLOADS[args.workload]
+    cfg = E.make_config()
+    m = E.Matrix.generate(gen, *gargs, cfg=cfg)
+    x = E.x_glibc(m.n)
+    m.reorder(cfg)
+    xp = E.vector_reorder(x, m.reorder_list)
+    plan = E.Plan(m, cfg)
+    dx, dy = E.DeviceBuffer(m.n).upload(xp), E.DeviceBuffer(m.n)
+    for _ in range(args.iters):
+        plan.spmv(dx.ptr, dy.ptr)
+    lib.ehyb_dev_sync()
+    st = plan.stats
+    print("PMC_RUN", {k: st[k] for k in ("nnz", "nnz_ell", "nnz_er", "size_block_ell", "bytes_format", "bytes_alg", "n_items", "window_loads")})
+
+
+if __name__ == "__main__":
+    main()
