@@ -49,19 +49,20 @@ class Config(C.Structure):
         ("n_top", C.c_int32),
         ("er_threads", C.c_int32),
         ("ell_variant", C.c_int32),
-        ("reserved", C.c_int32 * 3),
+        ("col_sharing", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
 _STAT_NAMES = [
     "nnz", "nnz_ell", "nnz_er", "ell_padding", "size_block_ell", "size_er", "rows_er",
     "er_segments", "n_rows", "n_cols", "n_parts", "n_slabs", "n_items", "halo_cols",
-    "window_loads", "bytes_format", "bytes_alg", "max_row", "lds_bytes",
+    "window_loads", "bytes_format", "bytes_alg", "max_row", "lds_bytes", "col_words",
 ]
 
 
 class Stats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in _STAT_NAMES] + [("reserved", C.c_int64 * 5)]
+    _fields_ = [(n, C.c_int64) for n in _STAT_NAMES] + [("reserved", C.c_int64 * 4)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n in _STAT_NAMES}

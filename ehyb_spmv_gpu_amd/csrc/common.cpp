@@ -51,6 +51,7 @@ Config resolve_config(const ehyb_config* in)
     c.n_top = z.n_top > 1 ? z.n_top : 1;
     c.er_threads = z.er_threads > 0 ? std::min(1024, std::max(64, round_down(z.er_threads, 64))) : 256;
     c.ell_variant = z.ell_variant > 0 ? z.ell_variant : 3;
+    c.col_sharing = z.col_sharing == 2 ? 2 : 1;
     return c;
 }
 

@@ -85,7 +85,7 @@ template <int THREADS, bool STAMP = false, bool SCALAR_STAGE = false>
 __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
     const int4* __restrict__ items, const int* __restrict__ part_boundary, const int* __restrict__ win_len,
     const int* __restrict__ halo_ptr, const int* __restrict__ halo_cols,
-    const uint32_t* __restrict__ slab_pair_ptr, const int* __restrict__ slab_row,
+    const uint4* __restrict__ slab_meta, const uint8_t* __restrict__ lane_group,
     const double2* __restrict__ ell_val, const uint32_t* __restrict__ ell_col, const double* __restrict__ x,
     double* __restrict__ y, unsigned long long* __restrict__ stamps = nullptr)
 {
@@ -114,15 +114,17 @@ __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
     constexpr int WAVES = THREADS / 64;
 
     for (int s = it.y + wave; s < it.z; s += WAVES) {
-        const uint32_t p0 = slab_pair_ptr[s];
-        const int np = (int)(slab_pair_ptr[s + 1] - p0);
-        const double2* __restrict__ v = ell_val + (size_t)p0 * 64 + lane;
-        const uint32_t* __restrict__ c = ell_col + (size_t)p0 * 64 + lane;
+        // slab record {first value pair, first column word, first row, pairs << 8 | groups - 1}
+        const uint4 sm = slab_meta[s];
+        const int np = (int)(sm.w >> 8);
+        const int G = (int)(sm.w & 0xffu) + 1;  // lanes with equal column lists share one word per pair
+        const double2* __restrict__ v = ell_val + (size_t)sm.x * 64 + lane;
+        const uint32_t* __restrict__ c = ell_col + sm.y + lane_group[(size_t)s * 64 + lane];
         double acc0 = 0.0, acc1 = 0.0;
         int k = 0;
         for (; k + 4 <= np; k += 4) {
             const double2 v0 = v[(k + 0) * 64], v1 = v[(k + 1) * 64], v2 = v[(k + 2) * 64], v3 = v[(k + 3) * 64];
-            const uint32_t c0 = c[(k + 0) * 64], c1 = c[(k + 1) * 64], c2 = c[(k + 2) * 64], c3 = c[(k + 3) * 64];
+            const uint32_t c0 = c[(k + 0) * G], c1 = c[(k + 1) * G], c2 = c[(k + 2) * G], c3 = c[(k + 3) * G];
             acc0 = fma(v0.x, win[c0 & 0xffffu], acc0);
             acc1 = fma(v0.y, win[c0 >> 16], acc1);
             acc0 = fma(v1.x, win[c1 & 0xffffu], acc0);
@@ -134,11 +136,11 @@ __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
         }
         for (; k < np; ++k) {
             const double2 v0 = v[k * 64];
-            const uint32_t c0 = c[k * 64];
+            const uint32_t c0 = c[k * G];
             acc0 = fma(v0.x, win[c0 & 0xffffu], acc0);
             acc1 = fma(v0.y, win[c0 >> 16], acc1);
         }
-        const int row = slab_row[s] + lane;
+        const int row = (int)sm.z + lane;
         if (row < pe) y[row] = acc0 + acc1;
     }
     if (STAMP) {
@@ -168,13 +170,13 @@ struct EllGroup {
 // lines, no extra HBM traffic) and masked out when consumed, so the loop body stays one basic
 // block and the compiler can count outstanding loads exactly.
 __device__ __forceinline__ void ell_load(EllGroup& g, const double2* __restrict__ v,
-                                         const uint32_t* __restrict__ c, int k, int last)
+                                         const uint32_t* __restrict__ c, int k, int last, int G)
 {
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
         const int idx = min(k + j, last);  // scalar
         g.v[j] = v[(size_t)idx * 64];
-        g.c[j] = c[(size_t)idx * 64];
+        g.c[j] = c[(size_t)idx * G];
     }
 }
 
@@ -182,7 +184,7 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel_pipe(
     const int4* __restrict__ items, const int* __restrict__ part_boundary, const int* __restrict__ win_len,
     const int* __restrict__ halo_ptr, const int* __restrict__ halo_cols,
-    const uint32_t* __restrict__ slab_pair_ptr, const int* __restrict__ slab_row,
+    const uint4* __restrict__ slab_meta, const uint8_t* __restrict__ lane_group,
     const double2* __restrict__ ell_val, const uint32_t* __restrict__ ell_col, const double* __restrict__ x,
     double* __restrict__ y)
 {
@@ -203,12 +205,12 @@ __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel_pipe(
 
     int s = it.y + wave;
     if (s >= it.z) return;
-    uint32_t p0 = slab_pair_ptr[s];
-    int np = (int)(slab_pair_ptr[s + 1] - p0);
-    const double2* __restrict__ v = ell_val + (size_t)p0 * 64 + lane;
-    const uint32_t* __restrict__ c = ell_col + (size_t)p0 * 64 + lane;
+    uint4 sm = slab_meta[s];
+    int np = (int)(sm.w >> 8);
     EllGroup ga, gb;  // ping-pong register sets: no copies, so no wait before the next issue
-    ell_load(ga, v, c, 0, max(np - 1, 0));
+    ell_load(ga, ell_val + (size_t)sm.x * 64 + lane, ell_col + sm.y + lane_group[(size_t)s * 64 + lane], 0,
+             max(np - 1, 0), (int)(sm.w & 0xffu) + 1);
+    int row0 = (int)sm.z;
 
     double acc0 = 0.0, acc1 = 0.0;
     int k = 0;
@@ -219,11 +221,12 @@ __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel_pipe(
         const int ns = slab_end ? s + WAVES : s;                                                  \
         const bool has_next = ns < it.z;                                                          \
         const int ms = has_next ? ns : s; /* keep the prefetch addresses valid at the very end */ \
-        const uint32_t q0 = slab_pair_ptr[ms];                                                    \
-        const int nnp = (int)(slab_pair_ptr[ms + 1] - q0);                                        \
+        const uint4 qm = slab_meta[ms];                                                           \
+        const int nnp = (int)(qm.w >> 8);                                                         \
         const int nk = slab_end ? 0 : k + 4;                                                      \
-        ell_load(NXT, ell_val + (size_t)q0 * 64 + lane, ell_col + (size_t)q0 * 64 + lane, nk,     \
-                 max(nnp - 1, 0));                                                                \
+        ell_load(NXT, ell_val + (size_t)qm.x * 64 + lane,                                         \
+                 ell_col + qm.y + lane_group[(size_t)ms * 64 + lane], nk, max(nnp - 1, 0),        \
+                 (int)(qm.w & 0xffu) + 1);                                                        \
         _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
         {                                                                                         \
             const bool live = k + j < np; /* wave-uniform mask of the clamped pairs */            \
@@ -233,7 +236,7 @@ __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel_pipe(
             acc1 = fma(vy, win[CUR.c[j] >> 16], acc1);                                            \
         }                                                                                         \
         if (slab_end) {                                                                           \
-            const int row = slab_row[s] + lane;                                                   \
+            const int row = row0 + lane;                                                          \
             if (row < pe) y[row] = acc0 + acc1;                                                   \
             acc0 = 0.0;                                                                           \
             acc1 = 0.0;                                                                           \
@@ -242,6 +245,7 @@ __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel_pipe(
         s = ns;                                                                                   \
         k = nk;                                                                                   \
         np = nnp;                                                                                 \
+        row0 = (int)qm.z;                                                                         \
     }
     for (;;) {
         ELL_STEP(ga, gb)
@@ -322,7 +326,7 @@ static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st)
     const size_t lds = (((size_t)H.lds_doubles * 8) + 15) / 16 * 16;
 #define ELL_ARGS                                                                                            \
     (const int4*)P->d_items, P->d_part_boundary, P->d_win_len, P->d_halo_ptr, P->d_halo_cols,               \
-        P->d_slab_pair_ptr, P->d_slab_row, (const double2*)P->d_ell_val, (const uint32_t*)P->d_ell_col, x, y
+        (const uint4*)P->d_slab_meta, P->d_lane_group, (const double2*)P->d_ell_val, P->d_ell_col, x, y
     const int var = P->cfg.ell_variant;  // 1 simple, 2 pipelined, 3 simple + scalar staging (A/B arm)
 #define ELL_LAUNCH(T)                                                                                        \
     if (var == 2)                                                                                            \
@@ -370,7 +374,8 @@ static int upload(T** dst, const std::vector<T>& src)
 
 static void free_device(ehyb_plan* P)
 {
-    void* ptrs[] = {P->d_part_boundary, P->d_win_len,     P->d_halo_ptr,  P->d_halo_cols, P->d_slab_pair_ptr,
+    void* ptrs[] = {P->d_lane_group,    P->d_slab_meta,
+                    P->d_part_boundary, P->d_win_len,     P->d_halo_ptr,  P->d_halo_cols, P->d_slab_pair_ptr,
                     P->d_slab_row,      P->d_ell_val,     P->d_ell_col,   P->d_items,     P->d_er_seg_ptr,
                     P->d_er_seg_row,    P->d_er_col,      P->d_er_val};
     for (void* q : ptrs)
@@ -380,6 +385,8 @@ static void free_device(ehyb_plan* P)
     P->d_slab_row = P->d_items = P->d_er_seg_row = P->d_er_col = nullptr;
     P->d_ell_val = P->d_er_val = nullptr;
     P->d_ell_col = nullptr;
+    P->d_lane_group = nullptr;
+    P->d_slab_meta = nullptr;
     P->d_er_seg_ptr = nullptr;
     P->uploaded = false;
 }
@@ -486,8 +493,9 @@ int ehyb_debug_ell_stamps(ehyb_plan* P, const double* x, double* y, unsigned lon
     HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                 (int)lds));                                                                        \
     hipLaunchKernelGGL((ehyb_ell_kernel<T, true>), dim3(n_items), dim3(T), lds, 0, (const int4*)P->d_items,        \
-                       P->d_part_boundary, P->d_win_len, P->d_halo_ptr, P->d_halo_cols, P->d_slab_pair_ptr,       \
-                       P->d_slab_row, (const double2*)P->d_ell_val, (const uint32_t*)P->d_ell_col, x, y, d);
+                       P->d_part_boundary, P->d_win_len, P->d_halo_ptr, P->d_halo_cols,                           \
+                       (const uint4*)P->d_slab_meta, P->d_lane_group, (const double2*)P->d_ell_val, P->d_ell_col, \
+                       x, y, d);
     switch (P->cfg.threads) {
         case 256: STAMP_LAUNCH(256) break;
         case 512: STAMP_LAUNCH(512) break;
@@ -526,6 +534,8 @@ int ehyb_plan_upload(ehyb_plan* P)
     UP(d_slab_row, slab_row)
     UP(d_ell_val, ell_val)
     UP(d_ell_col, ell_col)
+    UP(d_lane_group, lane_group)
+    UP(d_slab_meta, slab_meta)
     UP(d_items, items)
     UP(d_er_seg_ptr, er_seg_ptr)
     UP(d_er_seg_row, er_seg_row)

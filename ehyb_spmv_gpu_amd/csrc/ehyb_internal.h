@@ -38,6 +38,7 @@ struct Config {
     int n_top;
     int er_threads;
     int ell_variant;
+    int col_sharing;
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -66,8 +67,13 @@ struct HostLayout {
     std::vector<int32_t> slab_part;       // [n_slabs]
 
     // ELL payload: element (pair p, lane l, half h) at ((pair_ptr[s]+p)*64 + l)*2 + h
+    // Column indices are stored once per *group* of lanes with identical column lists:
+    // word (pair p, group g) at slab_col_ptr[s] + p*G_s + g holds two 16-bit window-local columns.
     std::vector<double> ell_val;
-    std::vector<uint16_t> ell_col;
+    std::vector<uint32_t> ell_col;
+    std::vector<uint32_t> slab_col_ptr;  // [n_slabs+1] prefix of pairs*groups
+    std::vector<uint8_t> lane_group;     // [n_slabs*64]
+    std::vector<uint32_t> slab_meta;     // [n_slabs*4] {pair_ptr, col_ptr, first row, pairs<<8 | groups-1}
 
     // ELL work items {part, slab_begin, slab_end, 0}
     std::vector<int32_t> items;
@@ -126,7 +132,9 @@ struct ehyb_plan {
     uint32_t* d_slab_pair_ptr = nullptr;
     int32_t* d_slab_row = nullptr;
     double* d_ell_val = nullptr;
-    uint16_t* d_ell_col = nullptr;
+    uint32_t* d_ell_col = nullptr;
+    uint8_t* d_lane_group = nullptr;
+    uint32_t* d_slab_meta = nullptr;
     int32_t* d_items = nullptr;
     int64_t* d_er_seg_ptr = nullptr;
     int32_t* d_er_seg_row = nullptr;

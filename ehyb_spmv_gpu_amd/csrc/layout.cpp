@@ -33,6 +33,7 @@ namespace {
 struct PartScratch {
     std::vector<int32_t> halo;       // chosen outside columns, ascending
     std::vector<uint32_t> slab_w2;   // pairs per slab
+    std::vector<uint32_t> slab_g;    // column-list groups per slab
 };
 
 inline int halo_lookup(const std::vector<int32_t>& halo, int col)
@@ -115,6 +116,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     // ---- pass 1: window contents, per-row ELL counts, slab widths
     std::vector<PartScratch> ps(np);
     std::vector<int32_t> cnt_ell(nrows, 0);
+    std::vector<uint8_t> lead_row(nrows, 1);
+    const bool share = cfg.col_sharing != 2;
     L->win_len.assign(np, 0);
     int bad_col = 0, bad_row = 0;
 #pragma omp parallel
@@ -188,6 +191,20 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 uint32_t& sw = S.slab_w2[(r - s) / kSlabRows];
                 if (w2 > sw) sw = w2;
             }
+            // Column-list sharing: a row whose column sequence equals that of the row above it
+            // (same slab) joins that row's group and stores no column indices of its own.
+            // Finite-element matrices with d unknowns per node give groups of d rows.
+            S.slab_g.assign(nslab, 0);
+            for (int r = s; r < e; ++r) {
+                bool lead = true;
+                if (share && (r - s) % kSlabRows != 0) {
+                    const int len = rp[r + 1] - rp[r];
+                    lead = len != rp[r] - rp[r - 1] ||
+                           (len > 0 && memcmp(m->J + rp[r], m->J + rp[r - 1], sizeof(int) * (size_t)len) != 0);
+                }
+                lead_row[r - row_begin] = lead ? 1 : 0;
+                S.slab_g[(r - s) / kSlabRows] += lead ? 1 : 0;
+            }
         }
     }
     if (bad_col) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: column index outside [0,%d)", n);
@@ -209,22 +226,36 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     L->slab_pair_ptr.assign(nslabs + 1, 0);
     L->slab_row.resize(nslabs);
     L->slab_part.resize(nslabs);
+    L->slab_col_ptr.assign(nslabs + 1, 0);
+    L->slab_meta.assign((size_t)nslabs * 4, 0);
     {
-        uint64_t acc = 0;
+        uint64_t acc = 0, acc_c = 0;
         for (int p = 0; p < np; ++p) {
             std::copy(ps[p].halo.begin(), ps[p].halo.end(), L->halo_cols.begin() + L->halo_ptr[p]);
             for (size_t q = 0; q < ps[p].slab_w2.size(); ++q) {
                 int64_t sidx = slab_base[p] + (int64_t)q;
+                const uint32_t w2 = ps[p].slab_w2[q], g = std::max<uint32_t>(1, ps[p].slab_g[q]);
                 L->slab_pair_ptr[sidx] = (uint32_t)acc;
+                L->slab_col_ptr[sidx] = (uint32_t)acc_c;
                 L->slab_row[sidx] = pb[p] + (int32_t)q * kSlabRows;
                 L->slab_part[sidx] = p;
-                acc += ps[p].slab_w2[q];
-                if (acc > 0xFFFFFFFFull) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: ELL part too large for 32-bit pair offsets");
+                // what the kernel reads per slab: one 16-byte record
+                if (w2 >= (1u << 24)) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: slab wider than 2^25 entries");
+                L->slab_meta[4 * sidx + 0] = (uint32_t)acc;
+                L->slab_meta[4 * sidx + 1] = (uint32_t)acc_c;
+                L->slab_meta[4 * sidx + 2] = (uint32_t)L->slab_row[sidx];
+                L->slab_meta[4 * sidx + 3] = (w2 << 8) | (g - 1);
+                acc += w2;
+                acc_c += (uint64_t)w2 * g;
+                if (acc > 0xFFFFFFFFull || acc_c > 0xFFFFFFFFull)
+                    EHYB_FAIL(EHYB_ERR_ARG, "build_layout: ELL part too large for 32-bit offsets");
             }
         }
         L->slab_pair_ptr[nslabs] = (uint32_t)acc;
+        L->slab_col_ptr[nslabs] = (uint32_t)acc_c;
     }
     const int64_t size_ell = (int64_t)L->slab_pair_ptr[nslabs] * 2 * kSlabRows;
+    const int64_t col_words = (int64_t)L->slab_col_ptr[nslabs];
 
     // residual row pointer (row order)
     std::vector<int64_t> er_rp(nrows + 1, 0);
@@ -238,7 +269,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
 
     // ---- pass 3: fill
     L->ell_val.assign((size_t)size_ell, 0.0);
-    L->ell_col.assign((size_t)size_ell, 0);
+    L->ell_col.assign((size_t)col_words, 0);
+    L->lane_group.assign((size_t)nslabs * kSlabRows, 0);
     std::vector<int32_t> tcol((size_t)nnz_er);
     std::vector<double> tval((size_t)nnz_er);
     int overflow = 0;
@@ -247,11 +279,19 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         const int s = pb[p], e = pb[p + 1];
         const int wlen = L->win_len[p];
         const PartScratch& S = ps[p];
+        int gid = 0;
         for (int r = s; r < e; ++r) {
             const int64_t sidx = slab_base[p] + (r - s) / kSlabRows;
             const int lane = (r - s) % kSlabRows;
             const uint64_t pp = L->slab_pair_ptr[sidx];
             const uint32_t w2 = L->slab_pair_ptr[sidx + 1] - L->slab_pair_ptr[sidx];
+            const uint64_t cp = L->slab_col_ptr[sidx];
+            const uint32_t G = (L->slab_meta[4 * sidx + 3] & 0xFF) + 1;
+            const bool lead = lead_row[r - row_begin] != 0;
+            gid = lane == 0 ? 0 : gid + (lead ? 1 : 0);
+            L->lane_group[(size_t)sidx * kSlabRows + lane] = (uint8_t)gid;
+            if (r + 1 == e)  // lanes past the last row of the partition read the last group (values 0)
+                for (int l2 = lane + 1; l2 < kSlabRows; ++l2) L->lane_group[(size_t)sidx * kSlabRows + l2] = (uint8_t)gid;
             uint32_t k_ell = 0;
             int64_t k_er = er_rp[r - row_begin];
             for (int k = rp[r]; k < rp[r + 1]; ++k) {
@@ -272,7 +312,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                     }
                     size_t at = (size_t)(((pp + k_ell / 2) * kSlabRows + lane) * 2 + (k_ell & 1));
                     L->ell_val[at] = m->V[k];
-                    L->ell_col[at] = (uint16_t)local;
+                    if (lead)  // two 16-bit window-local columns per word, one word per pair and group
+                        L->ell_col[(size_t)(cp + (uint64_t)(k_ell / 2) * G + gid)] |= (uint32_t)local << (16 * (k_ell & 1));
                     ++k_ell;
                 } else {
                     tcol[(size_t)k_er] = j;
@@ -397,8 +438,10 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     st.bytes_alg = 12 * nnz + 4 * ((int64_t)nrows + 1) + 8 * (int64_t)n + 8 * (int64_t)nrows;
     int64_t halo_item_loads = st.window_loads;
     for (size_t it = 0; it < L->items.size(); it += 4) halo_item_loads -= L->win_len[L->items[it]];
-    st.bytes_format = 10 * size_ell + 8 * nslabs + 16 * st.n_items + 8 * st.window_loads + 4 * halo_item_loads +
-                      8 * (int64_t)nrows + 12 * nnz_er + 12 * nseg + 16 * nseg;
+    st.col_words = col_words;
+    // values 8 B/element, shared column words 4 B, per slab a 16-byte record + 64-byte lane map
+    st.bytes_format = 8 * size_ell + 4 * col_words + 80 * nslabs + 16 * st.n_items + 8 * st.window_loads +
+                      4 * halo_item_loads + 8 * (int64_t)nrows + 12 * nnz_er + 12 * nseg + 16 * nseg;
     if (nnz_ell + nnz_er != nnz) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: %lld + %lld != %lld", (long long)nnz_ell, (long long)nnz_er, (long long)nnz);
     if (cfg.verbose) {
         printf("toER is %lld, kernel calculation is %lld\n", (long long)nnz_er, (long long)nnz_ell);

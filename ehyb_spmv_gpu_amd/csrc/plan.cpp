@@ -62,6 +62,9 @@ int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int
         case EHYB_ARR_ER_SEG_ROW: VIEW(H.er_seg_row);
         case EHYB_ARR_ER_COL: VIEW(H.er_col);
         case EHYB_ARR_ER_VAL: VIEW(H.er_val);
+        case EHYB_ARR_SLAB_COL_PTR: VIEW(H.slab_col_ptr);
+        case EHYB_ARR_LANE_GROUP: VIEW(H.lane_group);
+        case EHYB_ARR_SLAB_META: VIEW(H.slab_meta);
         case EHYB_ARR_ER_BINS:
             *ptr = (const void*)H.er_bins;
             *count = 8;

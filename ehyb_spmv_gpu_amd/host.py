@@ -19,9 +19,10 @@ EHYB_PART_AUTO, EHYB_PART_CONTIGUOUS, EHYB_PART_MULTILEVEL, EHYB_PART_MTMETIS = 
 ARRAYS = {
     "part_boundary": (0, np.int32), "win_len": (1, np.int32), "halo_ptr": (2, np.int32),
     "halo_cols": (3, np.int32), "slab_pair_ptr": (4, np.uint32), "slab_row": (5, np.int32),
-    "slab_part": (6, np.int32), "ell_val": (7, np.float64), "ell_col": (8, np.uint16),
+    "slab_part": (6, np.int32), "ell_val": (7, np.float64), "ell_col": (8, np.uint32),
     "items": (9, np.int32), "er_seg_ptr": (10, np.int64), "er_seg_row": (11, np.int32),
     "er_col": (12, np.int32), "er_val": (13, np.float64), "er_bins": (14, np.int32),
+    "slab_col_ptr": (15, np.uint32), "lane_group": (16, np.uint8), "slab_meta": (17, np.uint32),
 }
 
 

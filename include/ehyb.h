@@ -85,7 +85,8 @@ typedef struct ehyb_config {
     int32_t er_threads;    /* residual workgroup size                                     */
     int32_t ell_variant;   /* ELL kernel A/B arms: 0 = default (3), 1 = simple loop + 4-deep staging,
                               2 = software-pipelined loop, 3 = simple loop + scalar staging */
-    int32_t reserved[3];
+    int32_t col_sharing;   /* 0/1 = rows with the column list of the row above share its indices, 2 = off */
+    int32_t reserved[2];
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);
@@ -174,7 +175,8 @@ typedef struct ehyb_stats {
     int64_t bytes_alg;      /* 12*nnz + 4*(rows+1) + 8*cols + 8*rows      */
     int64_t max_row;        /* longest row                                            */
     int64_t lds_bytes;      /* dynamic LDS per ELL workgroup                          */
-    int64_t reserved[5];
+    int64_t col_words;      /* stored 4-byte column words (2 x 16 bit) after sharing  */
+    int64_t reserved[4];
 } ehyb_stats;
 int ehyb_plan_stats(const ehyb_plan* plan, ehyb_stats* out);
 
@@ -188,13 +190,17 @@ enum {
     EHYB_ARR_SLAB_ROW      = 5, /* int32  [n_slabs]    first row of the slab                  */
     EHYB_ARR_SLAB_PART     = 6, /* int32  [n_slabs]    partition of the slab                  */
     EHYB_ARR_ELL_VAL       = 7, /* double [size_block_ell]  [pair][lane][2]                   */
-    EHYB_ARR_ELL_COL       = 8, /* uint16 [size_block_ell]  window-local column, same order   */
+    EHYB_ARR_ELL_COL       = 8, /* uint32 [col_words] two 16-bit window-local columns per word:
+                                   word (pair k, group g) of slab s at SLAB_COL_PTR[s] + k*G_s + g  */
     EHYB_ARR_ITEMS         = 9, /* int32  [n_items*4]  {partition, slab_begin, slab_end, 0}   */
     EHYB_ARR_ER_SEG_PTR    = 10,/* int64  [er_segments+1]                                     */
     EHYB_ARR_ER_SEG_ROW    = 11,/* int32  [er_segments] bit31 set: row has several segments   */
     EHYB_ARR_ER_COL        = 12,/* int32  [size_er]    global column                          */
     EHYB_ARR_ER_VAL        = 13,/* double [size_er]                                           */
-    EHYB_ARR_ER_BINS       = 14 /* int32  [8]  {seg_begin[4 bins] .. } see DESIGN.md          */
+    EHYB_ARR_ER_BINS       = 14,/* int32  [8]  {seg_begin[4 bins] .. } see DESIGN.md          */
+    EHYB_ARR_SLAB_COL_PTR  = 15,/* uint32 [n_slabs+1]  prefix of pairs * groups               */
+    EHYB_ARR_LANE_GROUP    = 16,/* uint8  [n_slabs*64] column-list group of every lane        */
+    EHYB_ARR_SLAB_META     = 17 /* uint32 [n_slabs*4]  {pair_ptr, col_ptr, row, pairs<<8|G-1}: what the kernel reads */
 };
 int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int64_t* count);
 

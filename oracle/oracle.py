@@ -157,6 +157,9 @@ def walk_plan(plan, x):
     slab_row = plan.array("slab_row")
     ell_val = plan.array("ell_val")
     ell_col = plan.array("ell_col").astype(np.int64)
+    scp = plan.array("slab_col_ptr").astype(np.int64)
+    lane_group = plan.array("lane_group").astype(np.int64).reshape(-1, 64)
+    meta = plan.array("slab_meta").astype(np.int64).reshape(-1, 4)
     items = plan.array("items").reshape(-1, 4)
     written = np.zeros(n, dtype=np.int32)
     for p, s0, s1, _ in items:
@@ -167,9 +170,14 @@ def walk_plan(plan, x):
         for s in range(s0, s1):
             p0, p1 = spp[s], spp[s + 1]
             acc = np.zeros(64, dtype=np.float64)
+            # the 16-byte record the kernel reads must agree with the prefix arrays
+            assert meta[s, 0] == p0 and meta[s, 1] == scp[s] and meta[s, 2] == slab_row[s] and meta[s, 3] >> 8 == p1 - p0
             if p1 > p0:
+                G = int(meta[s, 3] & 0xFF) + 1
+                assert (scp[s + 1] - scp[s]) == (p1 - p0) * G
                 v = ell_val[p0 * 128:p1 * 128].reshape(p1 - p0, 64, 2)
-                c = ell_col[p0 * 128:p1 * 128].reshape(p1 - p0, 64, 2)
+                words = ell_col[scp[s]:scp[s + 1]].reshape(p1 - p0, G)[:, lane_group[s]]  # [pair][lane]
+                c = np.stack([words & 0xFFFF, words >> 16], axis=2)
                 assert c.max() < len(win), "window-local column outside the window"
                 acc = (v * win[c]).sum(axis=(0, 2))
             r0 = int(slab_row[s])

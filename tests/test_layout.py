@@ -40,9 +40,12 @@ def test_structural_invariants(E, O, mode):
     pb, wl = plan.array("part_boundary"), plan.array("win_len")
     hp, hc = plan.array("halo_ptr"), plan.array("halo_cols")
     spp, srow, spart = plan.array("slab_pair_ptr").astype(np.int64), plan.array("slab_row"), plan.array("slab_part")
-    ev, ec = plan.array("ell_val"), plan.array("ell_col").astype(np.int64)
+    ev, ew = plan.array("ell_val"), plan.array("ell_col").astype(np.int64)
+    scp, lg = plan.array("slab_col_ptr").astype(np.int64), plan.array("lane_group").astype(np.int64).reshape(-1, 64)
     assert pb[0] == 0 and pb[-1] == c.n and np.all(np.diff(pb) > 0)
-    assert spp[-1] * 128 == st["size_block_ell"] == len(ev) == len(ec)
+    assert spp[-1] * 128 == st["size_block_ell"] == len(ev)
+    assert scp[-1] == st["col_words"] == len(ew) and st["col_words"] <= st["size_block_ell"] // 2
+    meta = plan.array("slab_meta").astype(np.int64).reshape(-1, 4)
     rp, J, V = c.m.row_idx, c.m.J, c.m.V
     seen = 0
     for s in range(len(srow)):
@@ -51,7 +54,12 @@ def test_structural_invariants(E, O, mode):
         base = ps & ~1
         wsize = (ps & 1) + wl[p] + (hp[p + 1] - hp[p])
         assert wsize <= cfg.lds_doubles
-        cols = ec[spp[s] * 128:spp[s + 1] * 128].reshape(-1, 64, 2)
+        npairs = spp[s + 1] - spp[s]
+        G = int(meta[s, 3] & 0xFF) + 1
+        assert scp[s + 1] - scp[s] == npairs * G and meta[s, 3] >> 8 == npairs
+        assert lg[s].max() < G and lg[s][0] == 0 and np.all(np.diff(lg[s]) >= 0) and np.all(np.diff(lg[s]) <= 1)
+        words = ew[scp[s]:scp[s + 1]].reshape(npairs, G)[:, lg[s]] if npairs else np.zeros((0, 64), dtype=np.int64)
+        cols = np.stack([words & 0xFFFF, words >> 16], axis=2)   # [pair][lane][2] as the kernel decodes it
         vals = ev[spp[s] * 128:spp[s + 1] * 128].reshape(-1, 64, 2)
         assert cols.size == 0 or cols.max() < wsize                              # (ii)
         halo = hc[hp[p]:hp[p + 1]]
@@ -72,7 +80,7 @@ def test_structural_invariants(E, O, mode):
             hal = flat_c[:k] >= (ps & 1) + wl[p]
             dec[hal] = halo[flat_c[:k][hal] - (ps & 1) - wl[p]]
             assert np.array_equal(dec, rc[in_own | in_halo]) and np.array_equal(flat_v[:k], rv[in_own | in_halo])
-            assert not flat_v[k:].any() and not flat_c[k:].any()                 # zero padding (col 0, val 0)
+            assert not flat_v[k:].any()                                          # zero padding (value 0.0)
             seen += k
     assert seen == st["nnz_ell"]                                                  # (i)
     seg_ptr, seg_row = plan.array("er_seg_ptr"), plan.array("er_seg_row")
@@ -92,6 +100,29 @@ def test_structural_invariants(E, O, mode):
         covered[s0:s1] += 1
     assert np.all(covered == 1), "work items tile the slabs exactly once"
     del A
+
+
+def test_shared_column_lists(E, O):
+    """Rows with the column list of the row above store no column words of their own: a 3-dof
+    finite-element matrix needs about a third of the index bytes; switching it off gives one
+    list per lane; both walk to the same y."""
+    kw = dict(window_mode=2, lds_doubles=2048)
+    c = Case(E, O, "fem3d", (24000, 3, 20, 20, 13500, 1, 4), E.make_config(**kw))
+    on = E.Plan(c.m, E.make_config(col_sharing=1, **kw), upload=False)
+    off = E.Plan(c.m, E.make_config(col_sharing=2, **kw), upload=False)
+    s_on, s_off = on.stats, off.stats
+    # sharing off: one word per stored pair and (valid) lane
+    assert 0.98 * s_off["size_block_ell"] <= s_off["col_words"] * 2 <= s_off["size_block_ell"]
+    assert s_on["col_words"] < 0.36 * s_off["col_words"]              # groups of 3 (+ partial groups at slab edges)
+    assert s_on["size_block_ell"] == s_off["size_block_ell"] and s_on["nnz_er"] == s_off["nnz_er"]
+    g = (on.array("slab_meta").reshape(-1, 4)[:, 3] & 0xFF) + 1
+    assert g.max() <= 26 and np.median(g) == 22                        # 64 lanes = 21 nodes x 3 rows + 1
+    assert ((off.array("slab_meta").reshape(-1, 4)[:, 3] & 0xFF) + 1).min() >= 1
+    y_on, _ = O.walk_plan(on, c.xp)
+    y_off, _ = O.walk_plan(off, c.xp)
+    assert np.array_equal(y_on, y_off)
+    assert c.check(y_on)[0] == 0
+    assert s_on["bytes_format"] < 0.90 * s_off["bytes_format"]
 
 
 @pytest.mark.parametrize("seed", [0, 1, 2])

@@ -27,6 +27,7 @@ def main():
     ap.add_argument("--variants", default="1,2")
     ap.add_argument("--items", default="4")
     ap.add_argument("--mode", default="2")
+    ap.add_argument("--sharing", default="1", help="col_sharing values: 1 on, 2 off")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--rounds", type=int, default=2)
     args = ap.parse_args()
@@ -55,9 +56,10 @@ def main():
                 for threads in ints(args.threads):
                     for var in ints(args.variants):
                         for ipc in ints(args.items):
-                            cfg = E.make_config(lds_doubles=lds, part_rows=part_rows, window_mode=mode, threads=threads,
-                                                ell_variant=var, items_per_cu=ipc)
-                            plans.append(((threads, var, ipc), E.Plan(m, cfg)))
+                            for sh in ints(args.sharing):
+                                cfg = E.make_config(lds_doubles=lds, part_rows=part_rows, window_mode=mode, threads=threads,
+                                                    ell_variant=var, items_per_cu=ipc, col_sharing=sh)
+                                plans.append(((threads, var, ipc, sh), E.Plan(m, cfg)))
                 ref = None
                 best = {}
                 for rnd in range(args.rounds):
@@ -74,7 +76,7 @@ def main():
                     st = plan.stats
                     r = best[key]
                     t = r["ms_total"] / args.iters
-                    print(f"mode {mode} lds {lds:6d} rows {part_rows:6d} thr {key[0]:5d} var {key[1]} ipc {key[2]:2d} items {st['n_items']:5d} "
+                    print(f"mode {mode} lds {lds:6d} rows {part_rows:6d} thr {key[0]:5d} var {key[1]} ipc {key[2]:2d} sh {key[3]} items {st['n_items']:5d} "
                           f"ell {st['nnz_ell'] / nnz * 100:6.2f}% pad {st['ell_padding'] / st['size_block_ell'] * 100:5.2f}% "
                           f"| spmv {t * 1e3:8.1f} us  ell {r['ms_ell_avg'] * 1e3:8.1f} us  er {r['ms_er_avg'] * 1e3:7.1f} us "
                           f"| {2 * nnz / t / 1e6:8.1f} GFLOP/s  alg {st['bytes_alg'] / t / 1e6:7.1f} GB/s  maxdiff {r['err']:.1e}",
