@@ -50,7 +50,8 @@ class Config(C.Structure):
         ("er_threads", C.c_int32),
         ("ell_variant", C.c_int32),
         ("col_sharing", C.c_int32),
-        ("reserved", C.c_int32 * 2),
+        ("fuse_er", C.c_int32),
+        ("cap_split", C.c_int32),
     ]
 
 

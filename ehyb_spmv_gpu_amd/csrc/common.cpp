@@ -36,8 +36,8 @@ Config resolve_config(const ehyb_config* in)
     c.lds_doubles = z.lds_doubles > 0 ? std::min(z.lds_doubles, EHYB_LDS_MAX_DOUBLES) : 10240;
     c.lds_doubles = std::max(kSlabRows, round_down(c.lds_doubles, 2));
     // Rows per partition: the whole window in reference mode (convert.c:247 tests against
-    // partStart + vectorCacheSize); 5/8 of it in halo mode, the rest holds gathered columns.
-    int dflt_rows = c.window_mode == EHYB_WINDOW_REFERENCE ? c.lds_doubles : c.lds_doubles * 5 / 8;
+    // partStart + vectorCacheSize); 55 % of it in halo mode (measured best), the rest holds gathered columns.
+    int dflt_rows = c.window_mode == EHYB_WINDOW_REFERENCE ? c.lds_doubles : c.lds_doubles * 11 / 20;
     c.part_rows = z.part_rows > 0 ? std::min(z.part_rows, c.lds_doubles) : dflt_rows;
     c.part_rows = std::max(kSlabRows, round_down(c.part_rows, kSlabRows));
     c.threads = z.threads > 0 ? z.threads : 1024;  // 2 workgroups x 16 waves per CU at the default window
@@ -52,6 +52,10 @@ Config resolve_config(const ehyb_config* in)
     c.er_threads = z.er_threads > 0 ? std::min(1024, std::max(64, round_down(z.er_threads, 64))) : 256;
     c.ell_variant = z.ell_variant > 0 ? z.ell_variant : 3;
     c.col_sharing = z.col_sharing == 2 ? 2 : 1;
+    // measured (tools/sweep.py --fuse 1,2): the fused tail saves ~1 % at best on the bench matrix and
+    // loses badly on residual-heavy inputs, where the flat residual kernel has far more parallelism
+    c.fuse_er = z.fuse_er == 1 ? 1 : 2;
+    c.cap_split = z.cap_split == 2 ? 2 : 1;
     return c;
 }
 

@@ -78,20 +78,75 @@ __device__ __forceinline__ void stage_window(double* __restrict__ win, const dou
     }
 }
 
+// ------------------------------------------------------------------ residual tail
+// The residual segments of a work item's rows, multiplied by the whole workgroup: G lanes per
+// segment (64 / 16 / 4 by segment length, longest first), strided coalesced (col,val) reads, x
+// gathered from global memory, shuffle reduction, then y[row] += sum -- plain for rows with one
+// segment (rows are unique, kernel.cu:69-77), one fp64 atomic per segment for split rows (the
+// working form of kernel.cu:43-67).  Called after the workgroup's own `y[row] = dot` stores
+// and a __syncthreads() (fused), or from ehyb_er_kernel behind the ELL launch.
+template <int G, int THREADS>
+__device__ __forceinline__ void er_bin(int lo, int hi, const int64_t* __restrict__ seg_ptr,
+                                       const int* __restrict__ seg_row, const int* __restrict__ col,
+                                       const double* __restrict__ val, const double* __restrict__ x,
+                                       double* __restrict__ y)
+{
+    constexpr int SEGS = THREADS / G;
+    const int sub = threadIdx.x % G;
+    for (int base = lo; base < hi; base += SEGS) {  // uniform trip count: every lane reaches the shuffles
+        const int seg = base + threadIdx.x / G;
+        double acc0 = 0.0, acc1 = 0.0;
+        if (seg < hi) {
+            const int64_t b = seg_ptr[seg], e = seg_ptr[seg + 1];
+            int64_t k = b + sub;
+            for (; k + G < e; k += 2 * G) {
+                const int ca = col[k], cb = col[k + G];
+                const double va = val[k], vb = val[k + G];
+                acc0 = fma(va, x[ca], acc0);
+                acc1 = fma(vb, x[cb], acc1);
+            }
+            if (k < e) acc0 = fma(val[k], x[col[k]], acc0);
+        }
+        double acc = acc0 + acc1;
+#pragma unroll
+        for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, G);
+        if (sub == 0 && seg < hi) {
+            const int r = seg_row[seg];
+            if (r < 0)
+                unsafeAtomicAdd(&y[r & 0x7fffffff], acc);
+            else
+                y[r] += acc;
+        }
+    }
+}
+
+template <int THREADS>
+__device__ __forceinline__ void er_item(const int4 er, const int64_t* __restrict__ seg_ptr,
+                                        const int* __restrict__ seg_row, const int* __restrict__ col,
+                                        const double* __restrict__ val, const double* __restrict__ x,
+                                        double* __restrict__ y)
+{
+    er_bin<64, THREADS>(er.x, er.y, seg_ptr, seg_row, col, val, x, y);
+    er_bin<16, THREADS>(er.y, er.z, seg_ptr, seg_row, col, val, x, y);
+    er_bin<4, THREADS>(er.z, er.w, seg_ptr, seg_row, col, val, x, y);
+}
+
 // ------------------------------------------------------------------ ELL kernel
 // STAMP = true is a diagnostic instantiation (tools/ only): thread 0 of every workgroup records
 // the 100 MHz wall clock at entry, after staging and at exit into a buffer of its own.
-template <int THREADS, bool STAMP = false, bool SCALAR_STAGE = false>
+template <int THREADS, bool STAMP = false, bool SCALAR_STAGE = false, bool FUSE_ER = false>
 __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
     const int4* __restrict__ items, const int* __restrict__ part_boundary, const int* __restrict__ win_len,
     const int* __restrict__ halo_ptr, const int* __restrict__ halo_cols,
     const uint4* __restrict__ slab_meta, const uint8_t* __restrict__ lane_group,
     const double2* __restrict__ ell_val, const uint32_t* __restrict__ ell_col, const double* __restrict__ x,
-    double* __restrict__ y, unsigned long long* __restrict__ stamps = nullptr)
+    double* __restrict__ y, const int64_t* __restrict__ er_seg_ptr, const int* __restrict__ er_seg_row,
+    const int* __restrict__ er_col, const double* __restrict__ er_val,
+    unsigned long long* __restrict__ stamps = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) double win[];
     if (STAMP && threadIdx.x == 0) stamps[4 * blockIdx.x + 0] = wall_clock64();
-    const int4 it = items[blockIdx.x];
+    const int4 it = items[2 * blockIdx.x];
     const int p = it.x;
     const int ps = part_boundary[p];
     const int pe = part_boundary[p + 1];
@@ -143,6 +198,13 @@ __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
         const int row = (int)sm.z + lane;
         if (row < pe) y[row] = acc0 + acc1;
     }
+    if (FUSE_ER) {  // residual of this item's rows in the same launch (no second kernel boundary)
+        const int4 er = items[2 * blockIdx.x + 1];
+        if (er.w > er.x) {  // workgroup-uniform
+            __syncthreads();  // the y stores above are complete and visible to the workgroup
+            er_item<THREADS>(er, er_seg_ptr, er_seg_row, er_col, er_val, x, y);
+        }
+    }
     if (STAMP) {
         __syncthreads();
         if (threadIdx.x == 0) {
@@ -180,16 +242,17 @@ __device__ __forceinline__ void ell_load(EllGroup& g, const double2* __restrict_
     }
 }
 
-template <int THREADS>
+template <int THREADS, bool FUSE_ER = false>
 __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel_pipe(
     const int4* __restrict__ items, const int* __restrict__ part_boundary, const int* __restrict__ win_len,
     const int* __restrict__ halo_ptr, const int* __restrict__ halo_cols,
     const uint4* __restrict__ slab_meta, const uint8_t* __restrict__ lane_group,
     const double2* __restrict__ ell_val, const uint32_t* __restrict__ ell_col, const double* __restrict__ x,
-    double* __restrict__ y)
+    double* __restrict__ y, const int64_t* __restrict__ er_seg_ptr, const int* __restrict__ er_seg_row,
+    const int* __restrict__ er_col, const double* __restrict__ er_val)
 {
     extern __shared__ __attribute__((aligned(16))) double win[];
-    const int4 it = items[blockIdx.x];
+    const int4 it = items[2 * blockIdx.x];
     const int p = it.x;
     const int ps = part_boundary[p];
     const int pe = part_boundary[p + 1];
@@ -204,7 +267,7 @@ __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel_pipe(
     __syncthreads();
 
     int s = it.y + wave;
-    if (s >= it.z) return;
+    if (s < it.z) {
     uint4 sm = slab_meta[s];
     int np = (int)(sm.w >> 8);
     EllGroup ga, gb;  // ping-pong register sets: no copies, so no wait before the next issue
@@ -252,57 +315,34 @@ __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel_pipe(
         ELL_STEP(gb, ga)
     }
 #undef ELL_STEP
+    }
+    if (FUSE_ER) {
+        const int4 er = items[2 * blockIdx.x + 1];
+        if (er.w > er.x) {
+            __syncthreads();
+            er_item<THREADS>(er, er_seg_ptr, er_seg_row, er_col, er_val, x, y);
+        }
+    }
 }
 
 // ------------------------------------------------------------------ residual kernel
-template <int G, int THREADS>
-__device__ __forceinline__ void er_process(int lo, int hi, int blk, const int64_t* __restrict__ seg_ptr,
-                                           const int* __restrict__ seg_row, const int* __restrict__ col,
-                                           const double* __restrict__ val, const double* __restrict__ x,
-                                           double* __restrict__ y)
-{
-    constexpr int SEGS = THREADS / G;
-    const int sub = threadIdx.x % G;
-    const int seg = lo + blk * SEGS + threadIdx.x / G;
-    double acc0 = 0.0, acc1 = 0.0;
-    if (seg < hi) {
-        const int64_t b = seg_ptr[seg], e = seg_ptr[seg + 1];
-        int64_t k = b + sub;
-        for (; k + G < e; k += 2 * G) {
-            const int ca = col[k], cb = col[k + G];
-            const double va = val[k], vb = val[k + G];
-            acc0 = fma(va, x[ca], acc0);
-            acc1 = fma(vb, x[cb], acc1);
-        }
-        if (k < e) acc0 = fma(val[k], x[col[k]], acc0);
-    }
-    double acc = acc0 + acc1;
-#pragma unroll
-    for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, G);
-    if (sub == 0 && seg < hi) {
-        const int r = seg_row[seg];
-        if (r < 0)
-            unsafeAtomicAdd(&y[r & 0x7fffffff], acc);  // row split into several segments
-        else
-            y[r] += acc;  // rows are unique among unsplit segments (kernel.cu:69-77)
-    }
-}
-
+// Two-launch form (multi-GPU phase 2, or fuse_er = 2): one block per descriptor
+// {seg_lo, seg_hi, lanes per segment}, a single pass of same-bin segments each.
 template <int THREADS>
-__global__ __launch_bounds__(THREADS) void ehyb_er_kernel(int b0, int b1, int b2, int b3, int nb64, int nb16,
+__global__ __launch_bounds__(THREADS) void ehyb_er_kernel(const int4* __restrict__ blocks,
                                                           const int64_t* __restrict__ seg_ptr,
                                                           const int* __restrict__ seg_row,
                                                           const int* __restrict__ col,
                                                           const double* __restrict__ val,
                                                           const double* __restrict__ x, double* __restrict__ y)
 {
-    const int blk = blockIdx.x;
-    if (blk < nb64)
-        er_process<64, THREADS>(b0, b1, blk, seg_ptr, seg_row, col, val, x, y);
-    else if (blk < nb64 + nb16)
-        er_process<16, THREADS>(b1, b2, blk - nb64, seg_ptr, seg_row, col, val, x, y);
+    const int4 b = blocks[blockIdx.x];
+    if (b.z == 64)
+        er_bin<64, THREADS>(b.x, b.y, seg_ptr, seg_row, col, val, x, y);
+    else if (b.z == 16)
+        er_bin<16, THREADS>(b.x, b.y, seg_ptr, seg_row, col, val, x, y);
     else
-        er_process<4, THREADS>(b2, b3, blk - nb64 - nb16, seg_ptr, seg_row, col, val, x, y);
+        er_bin<4, THREADS>(b.x, b.y, seg_ptr, seg_row, col, val, x, y);
 }
 
 // streaming-read probe for the on-box bandwidth ceiling
@@ -318,23 +358,30 @@ __global__ __launch_bounds__(256) void ehyb_read_kernel(const double2* __restric
 }
 
 // ------------------------------------------------------------------ launches
-static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st)
+static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st, bool fuse)
 {
     const HostLayout& H = P->host;
-    const int n_items = (int)(H.items.size() / 4);
+    const int n_items = (int)(H.items.size() / 8);
     if (n_items == 0) return EHYB_OK;
     const size_t lds = (((size_t)H.lds_doubles * 8) + 15) / 16 * 16;
 #define ELL_ARGS                                                                                            \
     (const int4*)P->d_items, P->d_part_boundary, P->d_win_len, P->d_halo_ptr, P->d_halo_cols,               \
-        (const uint4*)P->d_slab_meta, P->d_lane_group, (const double2*)P->d_ell_val, P->d_ell_col, x, y
-    const int var = P->cfg.ell_variant;  // 1 simple, 2 pipelined, 3 simple + scalar staging (A/B arm)
-#define ELL_LAUNCH(T)                                                                                        \
+        (const uint4*)P->d_slab_meta, P->d_lane_group, (const double2*)P->d_ell_val, P->d_ell_col, x, y,    \
+        P->d_er_seg_ptr, P->d_er_seg_row, P->d_er_col, P->d_er_val
+    const int var = P->cfg.ell_variant;  // 1 simple, 2 pipelined, 3 simple + scalar staging (A/B arms)
+#define ELL_LAUNCH_F(T, F)                                                                                   \
     if (var == 2)                                                                                            \
-        hipLaunchKernelGGL(ehyb_ell_kernel_pipe<T>, dim3(n_items), dim3(T), lds, st, ELL_ARGS);              \
+        hipLaunchKernelGGL((ehyb_ell_kernel_pipe<T, F>), dim3(n_items), dim3(T), lds, st, ELL_ARGS);         \
     else if (var == 3)                                                                                       \
-        hipLaunchKernelGGL((ehyb_ell_kernel<T, false, true>), dim3(n_items), dim3(T), lds, st, ELL_ARGS, nullptr); \
+        hipLaunchKernelGGL((ehyb_ell_kernel<T, false, true, F>), dim3(n_items), dim3(T), lds, st, ELL_ARGS, nullptr); \
     else                                                                                                     \
-        hipLaunchKernelGGL((ehyb_ell_kernel<T, false, false>), dim3(n_items), dim3(T), lds, st, ELL_ARGS, nullptr);
+        hipLaunchKernelGGL((ehyb_ell_kernel<T, false, false, F>), dim3(n_items), dim3(T), lds, st, ELL_ARGS, nullptr);
+#define ELL_LAUNCH(T)            \
+    if (fuse) {                  \
+        ELL_LAUNCH_F(T, true)    \
+    } else {                     \
+        ELL_LAUNCH_F(T, false)   \
+    }
     switch (P->cfg.threads) {
         case 256: ELL_LAUNCH(256) break;
         case 512: ELL_LAUNCH(512) break;
@@ -342,6 +389,7 @@ static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st)
         default: EHYB_FAIL(EHYB_ERR_ARG, "ELL workgroup size %d not built (256/512/1024)", P->cfg.threads);
     }
 #undef ELL_LAUNCH
+#undef ELL_LAUNCH_F
 #undef ELL_ARGS
     HIP_TRY(hipGetLastError());
     return EHYB_OK;
@@ -350,17 +398,18 @@ static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st)
 static int launch_er(ehyb_plan* P, const double* x, double* y, hipStream_t st)
 {
     const HostLayout& H = P->host;
-    const int b0 = H.er_bins[0], b1 = H.er_bins[1], b2 = H.er_bins[2], b3 = H.er_bins[3];
-    if (b3 == 0) return EHYB_OK;
-    constexpr int T = 256;
-    const int nb64 = ((b1 - b0) + T / 64 - 1) / (T / 64);
-    const int nb16 = ((b2 - b1) + T / 16 - 1) / (T / 16);
-    const int nb4 = ((b3 - b2) + T / 4 - 1) / (T / 4);
-    hipLaunchKernelGGL(ehyb_er_kernel<T>, dim3(nb64 + nb16 + nb4), dim3(T), 0, st, b0, b1, b2, b3, nb64, nb16,
+    if (H.er_bins[3] == 0) return EHYB_OK;
+    const int n_blocks = (int)(H.er_blocks.size() / 4);
+    if (P->cfg.er_threads != 256) EHYB_FAIL(EHYB_ERR_ARG, "residual workgroup size %d not built (256)", P->cfg.er_threads);
+    hipLaunchKernelGGL(ehyb_er_kernel<256>, dim3(n_blocks), dim3(256), 0, st, (const int4*)P->d_er_blocks,
                        P->d_er_seg_ptr, P->d_er_seg_row, P->d_er_col, P->d_er_val, x, y);
     HIP_TRY(hipGetLastError());
     return EHYB_OK;
 }
+
+// The residual rides in the ELL launch unless the caller needs the two phases apart (multi-GPU
+// overlap: phase 1 reads only the rank's own x segment) or asked for the split form.
+static bool fuse_residual(const ehyb_plan* P) { return P->cfg.n_top <= 1 && P->cfg.fuse_er != 2; }
 
 template <class T>
 static int upload(T** dst, const std::vector<T>& src)
@@ -384,6 +433,8 @@ static void free_device(ehyb_plan* P)
     P->d_slab_pair_ptr = nullptr;
     P->d_slab_row = P->d_items = P->d_er_seg_row = P->d_er_col = nullptr;
     P->d_ell_val = P->d_er_val = nullptr;
+    if (P->d_er_blocks) (void)hipFree(P->d_er_blocks);
+    P->d_er_blocks = nullptr;
     P->d_ell_col = nullptr;
     P->d_lane_group = nullptr;
     P->d_slab_meta = nullptr;
@@ -484,7 +535,7 @@ int ehyb_debug_ell_stamps(ehyb_plan* P, const double* x, double* y, unsigned lon
 {
     if (!P || !P->uploaded || !out_host) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_debug_ell_stamps: bad arguments");
     const HostLayout& H = P->host;
-    const int n_items = (int)(H.items.size() / 4);
+    const int n_items = (int)(H.items.size() / 8);
     const size_t lds = (((size_t)H.lds_doubles * 8) + 15) / 16 * 16;
     unsigned long long* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, (size_t)n_items * 32));
@@ -495,7 +546,7 @@ int ehyb_debug_ell_stamps(ehyb_plan* P, const double* x, double* y, unsigned lon
     hipLaunchKernelGGL((ehyb_ell_kernel<T, true>), dim3(n_items), dim3(T), lds, 0, (const int4*)P->d_items,        \
                        P->d_part_boundary, P->d_win_len, P->d_halo_ptr, P->d_halo_cols,                           \
                        (const uint4*)P->d_slab_meta, P->d_lane_group, (const double2*)P->d_ell_val, P->d_ell_col, \
-                       x, y, d);
+                       x, y, P->d_er_seg_ptr, P->d_er_seg_row, P->d_er_col, P->d_er_val, d);
     switch (P->cfg.threads) {
         case 256: STAMP_LAUNCH(256) break;
         case 512: STAMP_LAUNCH(512) break;
@@ -541,18 +592,23 @@ int ehyb_plan_upload(ehyb_plan* P)
     UP(d_er_seg_row, er_seg_row)
     UP(d_er_col, er_col)
     UP(d_er_val, er_val)
+    UP(d_er_blocks, er_blocks)
 #undef UP
     // opt in to the full 160 KiB of LDS (the role of cudaFuncSetAttribute at kernel.cu:351,411)
     const int lds = (int)((((size_t)H.lds_doubles * 8) + 15) / 16 * 16);
-    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<256, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<256, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<512, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<512, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<1024, false, false>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<1024, false, true>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel_pipe<256>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel_pipe<512>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel_pipe<1024>, hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#define LDS_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
+#define LDS_ATTR_T(T)                                     \
+    LDS_ATTR((ehyb_ell_kernel<T, false, false, false>))   \
+    LDS_ATTR((ehyb_ell_kernel<T, false, false, true>))    \
+    LDS_ATTR((ehyb_ell_kernel<T, false, true, false>))    \
+    LDS_ATTR((ehyb_ell_kernel<T, false, true, true>))     \
+    LDS_ATTR((ehyb_ell_kernel_pipe<T, false>))            \
+    LDS_ATTR((ehyb_ell_kernel_pipe<T, true>))
+    LDS_ATTR_T(256)
+    LDS_ATTR_T(512)
+    LDS_ATTR_T(1024)
+#undef LDS_ATTR_T
+#undef LDS_ATTR
     P->uploaded = true;
     return EHYB_OK;
 }
@@ -570,7 +626,8 @@ int ehyb_spmv_phase(ehyb_plan* P, const double* x, double* y, void* stream, int 
     if (!P->uploaded) EHYB_FAIL(EHYB_ERR_STATE, "ehyb_spmv: plan not uploaded (no CPU fallback exists)");
     hipStream_t st = (hipStream_t)stream;
     int rc = EHYB_OK;
-    if (phase == 0 || phase == 1) rc = launch_ell(P, x, y, st);
+    if (phase == 0 && fuse_residual(P)) return launch_ell(P, x, y, st, true);  // one launch
+    if (phase == 0 || phase == 1) rc = launch_ell(P, x, y, st, false);
     if (rc == EHYB_OK && (phase == 0 || phase == 2)) rc = launch_er(P, x, y, st);
     return rc;
 }
@@ -606,10 +663,11 @@ int ehyb_spmv_bench(ehyb_plan* P, const double* x, double* y, void* stream, int 
         std::vector<hipEvent_t> ev((size_t)3 * n);
         for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
         for (int i = 0; i < n; ++i) {
+            const bool fused = fuse_residual(P);
             HIP_TRY(hipEventRecord(ev[3 * i + 0], st));
-            if ((rc = launch_ell(P, x, y, st)) != EHYB_OK) return rc;
+            if ((rc = launch_ell(P, x, y, st, fused)) != EHYB_OK) return rc;
             HIP_TRY(hipEventRecord(ev[3 * i + 1], st));
-            if ((rc = launch_er(P, x, y, st)) != EHYB_OK) return rc;
+            if (!fused && (rc = launch_er(P, x, y, st)) != EHYB_OK) return rc;
             HIP_TRY(hipEventRecord(ev[3 * i + 2], st));
         }
         HIP_TRY(hipEventSynchronize(ev.back()));

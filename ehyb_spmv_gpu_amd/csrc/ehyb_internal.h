@@ -39,6 +39,8 @@ struct Config {
     int er_threads;
     int ell_variant;
     int col_sharing;
+    int fuse_er;
+    int cap_split;
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -75,7 +77,7 @@ struct HostLayout {
     std::vector<uint8_t> lane_group;     // [n_slabs*64]
     std::vector<uint32_t> slab_meta;     // [n_slabs*4] {pair_ptr, col_ptr, first row, pairs<<8 | groups-1}
 
-    // ELL work items {part, slab_begin, slab_end, 0}
+    // work items {part, slab_begin, slab_end, 0, er_begin, er_b64, er_b16, er_end}
     std::vector<int32_t> items;
 
     // residual (CSR segments sorted by length, descending)
@@ -83,7 +85,8 @@ struct HostLayout {
     std::vector<int32_t> er_seg_row;  // [n_seg] row | 0x80000000 if the row is split
     std::vector<int32_t> er_col;
     std::vector<double> er_val;
-    int32_t er_bins[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // seg_begin of bins 0..3, then end, pad
+    int32_t er_bins[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [3] = number of segments
+    std::vector<int32_t> er_blocks;                 // {seg_lo, seg_hi, lanes per segment, 0} per block
 
     ehyb_stats stats{};
 };
@@ -140,4 +143,5 @@ struct ehyb_plan {
     int32_t* d_er_seg_row = nullptr;
     int32_t* d_er_col = nullptr;
     double* d_er_val = nullptr;
+    int32_t* d_er_blocks = nullptr;
 };

@@ -326,27 +326,106 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     }
     if (overflow) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: entry counts changed between passes");
 
-    // ---- pass 4: residual segments, longest first
+    // ---- work items: contiguous slab ranges of roughly equal cost.  The residual entries of
+    // an item's rows are charged to it (they are multiplied by the same workgroup).
+    std::vector<int64_t> slab_er(nslabs, 0);
+    for (int p = 0; p < np; ++p)
+        for (int r = pb[p]; r < pb[p + 1]; ++r)
+            slab_er[slab_base[p] + (r - pb[p]) / kSlabRows] += er_rp[r - row_begin + 1] - er_rp[r - row_begin];
+    std::vector<int32_t> item_of_slab(nslabs, 0);
+    {
+        auto slab_cost = [&](int64_t sidx) {
+            // streamed bytes: values + shared column words; residual entries cost an x gather each
+            const int64_t pairs = L->slab_pair_ptr[sidx + 1] - L->slab_pair_ptr[sidx];
+            const int64_t words = L->slab_col_ptr[sidx + 1] - L->slab_col_ptr[sidx];
+            return pairs * (kSlabRows * 16) + words * 4 + slab_er[sidx] * 40 + 1024;
+        };
+        int64_t total = 0;
+        std::vector<int64_t> pcost(np, 0);
+        for (int p = 0; p < np; ++p) {
+            for (int64_t sidx = slab_base[p]; sidx < slab_base[p + 1]; ++sidx) pcost[p] += slab_cost(sidx);
+            total += pcost[p];
+        }
+        // The grid must not exceed `want` = items_per_cu x 256 work items: with 2 workgroups resident
+        // per CU, 512 items run as one wave of workgroups but 513 need a second one (measured: 537
+        // items took 158 us where 507 took 136 us).  Pieces per partition k_p = round(cost_p/target),
+        // with the smallest target whose total stays within `want` (bisection; the count is monotone).
+        const int64_t want = std::max<int64_t>(1, (int64_t)cfg.items_per_cu * kNumCU);
+        const int waves = cfg.threads / 64;
+        auto pieces = [&](int p, int64_t target) {
+            int64_t ns = slab_base[p + 1] - slab_base[p];
+            if (ns == 0) return (int64_t)0;
+            int64_t k = std::max<int64_t>(1, (pcost[p] + target / 2) / target);
+            return std::min(k, std::max<int64_t>(1, ns / waves));  // at least one slab per wave
+        };
+        auto count = [&](int64_t target) {
+            int64_t c = 0;
+            for (int p = 0; p < np; ++p) c += pieces(p, target);
+            return c;
+        };
+        int64_t lo = std::max<int64_t>(1, total / want / 2), hi = std::max<int64_t>(lo, total);
+        while (count(hi) > want && hi < (int64_t)4e18 / 2) hi *= 2;  // more partitions than `want`: one item each
+        while (lo < hi) {
+            int64_t mid = lo + (hi - lo) / 2;
+            if (count(mid) <= want)
+                hi = mid;
+            else
+                lo = mid + 1;
+        }
+        const int64_t target = hi;
+        L->items.clear();
+        int64_t window_loads = 0;
+        for (int p = 0; p < np; ++p) {
+            int64_t ns = slab_base[p + 1] - slab_base[p];
+            if (ns == 0) continue;
+            int64_t k = pieces(p, target);
+            int64_t sidx = slab_base[p];
+            int64_t acc = 0;
+            for (int64_t q = 0; q < k; ++q) {
+                int64_t stop = pcost[p] * (q + 1) / k;
+                int64_t beg = sidx;
+                while (sidx < slab_base[p + 1] && (acc < stop || sidx == beg)) acc += slab_cost(sidx++);
+                if (q == k - 1) sidx = slab_base[p + 1];
+                if (sidx > beg) {
+                    const int32_t item = (int32_t)(L->items.size() / 8);
+                    for (int64_t t = beg; t < sidx; ++t) item_of_slab[t] = item;
+                    const int32_t rec[8] = {p, (int32_t)beg, (int32_t)sidx, 0, 0, 0, 0, 0};
+                    L->items.insert(L->items.end(), rec, rec + 8);
+                    window_loads += L->win_len[p] + (L->halo_ptr[p + 1] - L->halo_ptr[p]);
+                }
+            }
+        }
+        L->stats.window_loads = window_loads;
+    }
+    const int64_t n_items = (int64_t)L->items.size() / 8;
+
+    // ---- pass 4: residual segments, grouped by work item, longest first inside an item
     struct Seg {
         int32_t row;
+        int32_t item;
         int64_t begin;
         int32_t len;
     };
     std::vector<Seg> segs;
     int64_t rows_er = 0;
-    for (int r = 0; r < nrows; ++r) {
-        int64_t len = er_rp[r + 1] - er_rp[r];
-        if (len == 0) continue;
-        ++rows_er;
-        int pieces = (int)((len + cfg.er_seg_len - 1) / cfg.er_seg_len);
-        for (int q = 0; q < pieces; ++q) {
-            int64_t b = er_rp[r] + len * q / pieces, e2 = er_rp[r] + len * (q + 1) / pieces;
-            int32_t row = (row_begin + r) | (pieces > 1 ? (int32_t)0x80000000 : 0);
-            segs.push_back({row, b, (int32_t)(e2 - b)});
+    for (int p = 0; p < np; ++p)
+        for (int r = pb[p]; r < pb[p + 1]; ++r) {
+            const int rr = r - row_begin;
+            int64_t len = er_rp[rr + 1] - er_rp[rr];
+            if (len == 0) continue;
+            ++rows_er;
+            const int32_t item = item_of_slab[slab_base[p] + (r - pb[p]) / kSlabRows];
+            int pieces = (int)((len + cfg.er_seg_len - 1) / cfg.er_seg_len);
+            for (int q = 0; q < pieces; ++q) {
+                int64_t b = er_rp[rr] + len * q / pieces, e2 = er_rp[rr] + len * (q + 1) / pieces;
+                int32_t row = r | (pieces > 1 ? (int32_t)0x80000000 : 0);
+                segs.push_back({row, item, b, (int32_t)(e2 - b)});
+            }
         }
-    }
-    std::stable_sort(segs.begin(), segs.end(), [](const Seg& a, const Seg& b) { return a.len > b.len; });
+    std::stable_sort(segs.begin(), segs.end(),
+                     [](const Seg& a, const Seg& b) { return a.item != b.item ? a.item < b.item : a.len > b.len; });
     const int64_t nseg = (int64_t)segs.size();
+    if (nseg > 0x7FFFFFFFll) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: too many residual segments");
     L->er_seg_ptr.assign(nseg + 1, 0);
     L->er_seg_row.resize(nseg);
     for (int64_t i = 0; i < nseg; ++i) {
@@ -363,56 +442,36 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                   L->er_val.begin() + L->er_seg_ptr[i]);
     }
     {
-        // lanes per segment: 64 for len >= 128, 16 for 17..127, 4 for <= 16 (sorted descending)
-        int64_t b1 = 0, b2 = 0;
-        while (b1 < nseg && segs[b1].len >= 128) ++b1;
-        b2 = b1;
-        while (b2 < nseg && segs[b2].len > 16) ++b2;
-        if (nseg > 0x7FFFFFFFll) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: too many residual segments");
-        L->er_bins[0] = 0;
-        L->er_bins[1] = (int32_t)b1;
-        L->er_bins[2] = (int32_t)b2;
-        L->er_bins[3] = (int32_t)nseg;
-    }
-
-    // ---- ELL work items: contiguous slab ranges of roughly equal cost
-    {
-        auto slab_cost = [&](int64_t sidx) {
-            return (int64_t)(L->slab_pair_ptr[sidx + 1] - L->slab_pair_ptr[sidx]) * (2 * kSlabRows * 10) + 1024;
-        };
-        int64_t total = 0;
-        std::vector<int64_t> pcost(np, 0);
-        for (int p = 0; p < np; ++p) {
-            for (int64_t sidx = slab_base[p]; sidx < slab_base[p + 1]; ++sidx) pcost[p] += slab_cost(sidx);
-            total += pcost[p];
+        // item record words 4..7: segment range and its length bins -- 64 lanes per segment for
+        // len >= 128, 16 for 17..127, 4 for <= 16
+        int64_t i = 0;
+        for (int64_t it = 0; it < n_items; ++it) {
+            int32_t* rec = &L->items[(size_t)it * 8];
+            rec[4] = (int32_t)i;
+            while (i < nseg && segs[i].item == it && segs[i].len >= 128) ++i;
+            rec[5] = (int32_t)i;
+            while (i < nseg && segs[i].item == it && segs[i].len > 16) ++i;
+            rec[6] = (int32_t)i;
+            while (i < nseg && segs[i].item == it) ++i;
+            rec[7] = (int32_t)i;
         }
-        const int64_t want = (int64_t)cfg.items_per_cu * kNumCU;
-        const int64_t target = std::max<int64_t>(1, total / std::max<int64_t>(1, want));
-        const int waves = cfg.threads / 64;
-        L->items.clear();
-        int64_t window_loads = 0;
-        for (int p = 0; p < np; ++p) {
-            int64_t ns = slab_base[p + 1] - slab_base[p];
-            if (ns == 0) continue;
-            int64_t k = std::max<int64_t>(1, (pcost[p] + target / 2) / target);
-            k = std::min(k, std::max<int64_t>(1, ns / waves));  // at least one slab per wave
-            int64_t sidx = slab_base[p];
-            int64_t acc = 0;
-            for (int64_t q = 0; q < k; ++q) {
-                int64_t stop = pcost[p] * (q + 1) / k;
-                int64_t beg = sidx;
-                while (sidx < slab_base[p + 1] && (acc < stop || sidx == beg)) acc += slab_cost(sidx++);
-                if (q == k - 1) sidx = slab_base[p + 1];
-                if (sidx > beg) {
-                    L->items.push_back(p);
-                    L->items.push_back((int32_t)beg);
-                    L->items.push_back((int32_t)sidx);
-                    L->items.push_back(0);
-                    window_loads += L->win_len[p] + (L->halo_ptr[p + 1] - L->halo_ptr[p]);
+        if (i != nseg) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: residual segments not covered by the work items");
+        L->er_bins[0] = 0;
+        L->er_bins[3] = (int32_t)nseg;
+        // Flat block list for the stand-alone residual kernel (two-launch form): every block of
+        // er_threads threads gets one pass worth of same-bin segments {lo, hi, lanes, 0}.
+        L->er_blocks.clear();
+        const int lanes[3] = {64, 16, 4};
+        for (int64_t it = 0; it < n_items; ++it) {
+            const int32_t* rec = &L->items[(size_t)it * 8];
+            for (int b = 0; b < 3; ++b) {
+                const int per = cfg.er_threads / lanes[b];
+                for (int32_t lo = rec[4 + b]; lo < rec[5 + b]; lo += per) {
+                    const int32_t blk[4] = {lo, std::min(rec[5 + b], lo + per), lanes[b], 0};
+                    L->er_blocks.insert(L->er_blocks.end(), blk, blk + 4);
                 }
             }
         }
-        L->stats.window_loads = window_loads;
     }
 
     // ---- statistics (convert.c:140,310; spmv.cu:82)
@@ -429,7 +488,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     st.n_cols = n;
     st.n_parts = np;
     st.n_slabs = nslabs;
-    st.n_items = (int64_t)L->items.size() / 4;
+    st.n_items = n_items;
     st.halo_cols = L->halo_ptr[np];
     int maxrow = 0;
     for (int r = row_begin; r < row_end; ++r) maxrow = std::max(maxrow, rp[r + 1] - rp[r]);
@@ -437,10 +496,10 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     st.lds_bytes = (int64_t)L->lds_doubles * 8;
     st.bytes_alg = 12 * nnz + 4 * ((int64_t)nrows + 1) + 8 * (int64_t)n + 8 * (int64_t)nrows;
     int64_t halo_item_loads = st.window_loads;
-    for (size_t it = 0; it < L->items.size(); it += 4) halo_item_loads -= L->win_len[L->items[it]];
+    for (size_t it = 0; it < L->items.size(); it += 8) halo_item_loads -= L->win_len[L->items[it]];
     st.col_words = col_words;
     // values 8 B/element, shared column words 4 B, per slab a 16-byte record + 64-byte lane map
-    st.bytes_format = 8 * size_ell + 4 * col_words + 80 * nslabs + 16 * st.n_items + 8 * st.window_loads +
+    st.bytes_format = 8 * size_ell + 4 * col_words + 80 * nslabs + 32 * st.n_items + 8 * st.window_loads +
                       4 * halo_item_loads + 8 * (int64_t)nrows + 12 * nnz_er + 12 * nseg + 16 * nseg;
     if (nnz_ell + nnz_er != nnz) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: %lld + %lld != %lld", (long long)nnz_ell, (long long)nnz_er, (long long)nnz);
     if (cfg.verbose) {

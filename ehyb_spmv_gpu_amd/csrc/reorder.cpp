@@ -190,6 +190,70 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
             m->nParts = nparts;
         } else {
             rc = partition_graph(n, xadj.data(), adj.data(), nullptr, nparts, cap, c, part.data(), &cut);
+            // Capacity-aware refinement (halo window only): a partition whose own rows plus the
+            // distinct outside columns it references do not fit the LDS window would spill
+            // entries into the residual.  Such partitions -- and only those -- are bisected, which
+            // shrinks both their row count and their halo; on mesh-like matrices the residual
+            // (and its kernel launch) disappears.  Partitions that overflow by more than 1.5x
+            // (power-law graphs) are left alone: splitting cannot make them fit.
+            if (rc == EHYB_OK && c.window_mode == EHYB_WINDOW_HALO && c.cap_split != 2) {
+                for (int round = 0; round < 3; ++round) {
+                    std::vector<int> own(nparts, 0), demand(nparts, 0);
+                    for (int i = 0; i < n; ++i) own[part[i]]++;
+                    {
+                        // distinct outside columns per partition: sort (part, col) pairs
+                        std::vector<std::vector<int>> outside(nparts);
+                        for (int64_t k = 0; k < nnz; ++k) {
+                            int pi = part[m->I[k]];
+                            if (part[m->J[k]] != pi) outside[pi].push_back(m->J[k]);
+                        }
+#pragma omp parallel for schedule(dynamic, 4)
+                        for (int p = 0; p < nparts; ++p) {
+                            std::vector<int>& o = outside[p];
+                            std::sort(o.begin(), o.end());
+                            demand[p] = own[p] + 1 + (int)(std::unique(o.begin(), o.end()) - o.begin());
+                        }
+                    }
+                    std::vector<int> offenders;
+                    for (int p = 0; p < nparts; ++p)
+                        if (demand[p] > c.lds_doubles && demand[p] <= c.lds_doubles * 3 / 2 && own[p] >= 4 * kSlabRows)
+                            offenders.push_back(p);
+                    if (offenders.empty()) break;
+                    if (c.verbose) printf("capacity split round %d: %zu of %d partitions overflow the window\n", round, offenders.size(), nparts);
+                    std::vector<int> local(n, -1), spart;
+                    std::vector<int64_t> sx;
+                    std::vector<int> sa;
+                    std::vector<char> is_off(nparts, 0);
+                    for (int p : offenders) is_off[p] = 1;
+                    std::vector<std::vector<int>> members(nparts);
+                    for (int i = 0; i < n; ++i)
+                        if (is_off[part[i]]) {
+                            local[i] = (int)members[part[i]].size();
+                            members[part[i]].push_back(i);
+                        }
+                    for (int p : offenders) {
+                        const std::vector<int>& verts = members[p];
+                        const int nb = (int)verts.size();
+                        sx.assign((size_t)nb + 1, 0);
+                        sa.clear();
+                        for (int q = 0; q < nb; ++q) {
+                            int v = verts[q];
+                            for (int64_t e = xadj[v]; e < xadj[v + 1]; ++e)
+                                if (part[adj[e]] == p) sa.push_back(local[adj[e]]);
+                            sx[q + 1] = (int64_t)sa.size();
+                        }
+                        spart.assign(nb, 0);
+                        int64_t bcut = 0;
+                        rc = partition_graph(nb, sx.data(), sa.data(), nullptr, 2, (nb + 1) / 2 + std::max(8, nb / 40), c,
+                                             spart.data(), &bcut);
+                        if (rc != EHYB_OK) return rc;
+                        for (int q = 0; q < nb; ++q)
+                            if (spart[q] == 1) part[verts[q]] = nparts;
+                        ++nparts;
+                    }
+                    m->nParts = nparts;
+                }
+            }
         }
         if (rc != EHYB_OK) return rc;
         if (c.verbose)

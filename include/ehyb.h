@@ -86,7 +86,8 @@ typedef struct ehyb_config {
     int32_t ell_variant;   /* ELL kernel A/B arms: 0 = default (3), 1 = simple loop + 4-deep staging,
                               2 = software-pipelined loop, 3 = simple loop + scalar staging */
     int32_t col_sharing;   /* 0/1 = rows with the column list of the row above share its indices, 2 = off */
-    int32_t reserved[2];
+    int32_t fuse_er;       /* 1 = residual rides in the ELL launch (single GPU only), 0/2 = two launches */
+    int32_t cap_split;     /* 0/1 = bisect partitions whose halo overflows the window (reorder step), 2 = off */
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);
@@ -192,12 +193,14 @@ enum {
     EHYB_ARR_ELL_VAL       = 7, /* double [size_block_ell]  [pair][lane][2]                   */
     EHYB_ARR_ELL_COL       = 8, /* uint32 [col_words] two 16-bit window-local columns per word:
                                    word (pair k, group g) of slab s at SLAB_COL_PTR[s] + k*G_s + g  */
-    EHYB_ARR_ITEMS         = 9, /* int32  [n_items*4]  {partition, slab_begin, slab_end, 0}   */
+    EHYB_ARR_ITEMS         = 9, /* int32  [n_items*8]  {partition, slab_begin, slab_end, 0, er_begin,
+                                   er_end_len>=128, er_end_len>16, er_end}: the residual segments of
+                                   the item's rows, longest first                                   */
     EHYB_ARR_ER_SEG_PTR    = 10,/* int64  [er_segments+1]                                     */
     EHYB_ARR_ER_SEG_ROW    = 11,/* int32  [er_segments] bit31 set: row has several segments   */
     EHYB_ARR_ER_COL        = 12,/* int32  [size_er]    global column                          */
     EHYB_ARR_ER_VAL        = 13,/* double [size_er]                                           */
-    EHYB_ARR_ER_BINS       = 14,/* int32  [8]  {seg_begin[4 bins] .. } see DESIGN.md          */
+    EHYB_ARR_ER_BINS       = 14,/* int32  [8]  {0, -, -, er_segments, ...}                        */
     EHYB_ARR_SLAB_COL_PTR  = 15,/* uint32 [n_slabs+1]  prefix of pairs * groups               */
     EHYB_ARR_LANE_GROUP    = 16,/* uint8  [n_slabs*64] column-list group of every lane        */
     EHYB_ARR_SLAB_META     = 17 /* uint32 [n_slabs*4]  {pair_ptr, col_ptr, row, pairs<<8|G-1}: what the kernel reads */

@@ -160,9 +160,21 @@ def walk_plan(plan, x):
     scp = plan.array("slab_col_ptr").astype(np.int64)
     lane_group = plan.array("lane_group").astype(np.int64).reshape(-1, 64)
     meta = plan.array("slab_meta").astype(np.int64).reshape(-1, 4)
-    items = plan.array("items").reshape(-1, 4)
+    items = plan.array("items").reshape(-1, 8)
     written = np.zeros(n, dtype=np.int32)
-    for p, s0, s1, _ in items:
+    seg_ptr = plan.array("er_seg_ptr")
+    seg_row = plan.array("er_seg_row")
+    seg_done = np.zeros(len(seg_row), dtype=np.int32)
+    for p, s0, s1, _, e0, e64, e16, e1 in items:
+        # the item's residual segments: rows inside the item's slab range, bins by length
+        assert e0 <= e64 <= e16 <= e1
+        if e1 > e0:
+            lens = np.diff(seg_ptr[e0:e1 + 1])
+            assert np.all(lens[:e64 - e0] >= 128) and np.all((lens[e64 - e0:e16 - e0] > 16) & (lens[e64 - e0:e16 - e0] < 128))
+            assert np.all(lens[e16 - e0:] <= 16) and np.all(lens >= 1)
+            rows = seg_row[e0:e1] & 0x7FFFFFFF
+            assert rows.min() >= slab_row[s0] and rows.max() < min(int(slab_row[s1 - 1]) + 64, int(pb[p + 1]))
+            seg_done[e0:e1] += 1
         ps, pe = int(pb[p]), int(pb[p + 1])
         wl = int(win_len[p])
         base = ps & ~1  # the LDS image starts at the even row at or below the partition start
@@ -184,10 +196,9 @@ def walk_plan(plan, x):
             cnt = min(64, pe - r0)
             y[r0:r0 + cnt] = acc[:cnt]
             written[r0:r0 + cnt] += 1
-    seg_ptr = plan.array("er_seg_ptr")
-    seg_row = plan.array("er_seg_row")
     er_col = plan.array("er_col")
     er_val = plan.array("er_val")
+    assert np.all(seg_done == 1), "every residual segment belongs to exactly one work item"
     if len(seg_row):
         prod = er_val * x[er_col]
         sums = np.add.reduceat(prod, seg_ptr[:-1]) if len(prod) else np.zeros(0)

@@ -84,21 +84,27 @@ def test_structural_invariants(E, O, mode):
             seen += k
     assert seen == st["nnz_ell"]                                                  # (i)
     seg_ptr, seg_row = plan.array("er_seg_ptr"), plan.array("er_seg_row")
-    assert np.all(np.diff(np.diff(seg_ptr)) <= 0), "segments sorted by length, longest first"
-    assert np.diff(seg_ptr).max() <= cfg.er_seg_len
+    assert np.diff(seg_ptr).max() <= cfg.er_seg_len and np.diff(seg_ptr).min() >= 1
     rows = seg_row & 0x7FFFFFFF
     uniq, counts = np.unique(rows, return_counts=True)
     split = set(uniq[counts > 1].tolist())
     assert split == set(rows[seg_row < 0].tolist())                               # (iv) + split flag
     assert len(uniq) == st["rows_er"]
     bins = plan.array("er_bins")
-    assert bins[0] == 0 and bins[3] == len(seg_row) and bins[1] <= bins[2] <= bins[3]
-    items = plan.array("items").reshape(-1, 4)
+    assert bins[0] == 0 and bins[3] == len(seg_row)
+    items = plan.array("items").reshape(-1, 8)
     covered = np.zeros(len(srow), dtype=int)
-    for p, s0, s1, _ in items:
+    nxt = 0
+    for p, s0, s1, _, e0, e64, e16, e1 in items:
         assert s0 < s1 and np.all(spart[s0:s1] == p)
         covered[s0:s1] += 1
+        assert e0 == nxt and e0 <= e64 <= e16 <= e1                              # segments grouped by item
+        lens = np.diff(seg_ptr[e0:e1 + 1])
+        assert np.all(np.diff(lens) <= 0), "longest first inside an item"
+        nxt = e1
+    assert nxt == len(seg_row)
     assert np.all(covered == 1), "work items tile the slabs exactly once"
+    assert len(items) <= max(cfg.items_per_cu * 256, st["n_parts"]), "the grid never exceeds the resident-slot budget"
     del A
 
 
@@ -112,7 +118,7 @@ def test_shared_column_lists(E, O):
     off = E.Plan(c.m, E.make_config(col_sharing=2, **kw), upload=False)
     s_on, s_off = on.stats, off.stats
     # sharing off: one word per stored pair and (valid) lane
-    assert 0.98 * s_off["size_block_ell"] <= s_off["col_words"] * 2 <= s_off["size_block_ell"]
+    assert 0.93 * s_off["size_block_ell"] <= s_off["col_words"] * 2 <= s_off["size_block_ell"]
     assert s_on["col_words"] < 0.36 * s_off["col_words"]              # groups of 3 (+ partial groups at slab edges)
     assert s_on["size_block_ell"] == s_off["size_block_ell"] and s_on["nnz_er"] == s_off["nnz_er"]
     g = (on.array("slab_meta").reshape(-1, 4)[:, 3] & 0xFF) + 1

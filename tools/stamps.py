@@ -58,7 +58,7 @@ def main():
     s = out.reshape(-1, 4).astype(np.int64)
     t0 = s[:, 0].min()
     start, staged, end, xcc = (s[:, 0] - t0) / 100.0, (s[:, 1] - t0) / 100.0, (s[:, 2] - t0) / 100.0, s[:, 3]
-    items = plan.array("items").reshape(-1, 4)
+    items = plan.array("items").reshape(-1, 8)
     spp = plan.array("slab_pair_ptr").astype(np.int64)
     pairs = spp[items[:, 2]] - spp[items[:, 1]]
     print(f"items {n_items}  kernel span {end.max():.1f} us")

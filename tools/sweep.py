@@ -28,6 +28,8 @@ def main():
     ap.add_argument("--items", default="4")
     ap.add_argument("--mode", default="2")
     ap.add_argument("--sharing", default="1", help="col_sharing values: 1 on, 2 off")
+    ap.add_argument("--fuse", default="1", help="fuse_er values: 1 residual in the ELL launch, 2 two launches ('sh' column prints sharing*10+fuse)")
+    ap.add_argument("--capsplit", type=int, default=1, help="cap_split of the reorder step: 1 on, 2 off")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--rounds", type=int, default=2)
     args = ap.parse_args()
@@ -43,7 +45,7 @@ def main():
         for lds in ints(args.lds):
             for frac in ints(args.rows_frac):
                 part_rows = max(64, lds * frac // 1000 // 64 * 64)
-                cfg0 = E.make_config(lds_doubles=lds, part_rows=part_rows, window_mode=mode)
+                cfg0 = E.make_config(lds_doubles=lds, part_rows=part_rows, window_mode=mode, cap_split=args.capsplit)
                 t0 = time.time()
                 m = E.Matrix.generate(gen, *gargs, cfg=cfg0)
                 n, nnz = m.n, m.nnz
@@ -57,9 +59,10 @@ def main():
                     for var in ints(args.variants):
                         for ipc in ints(args.items):
                             for sh in ints(args.sharing):
-                                cfg = E.make_config(lds_doubles=lds, part_rows=part_rows, window_mode=mode, threads=threads,
-                                                    ell_variant=var, items_per_cu=ipc, col_sharing=sh)
-                                plans.append(((threads, var, ipc, sh), E.Plan(m, cfg)))
+                                for fu in ints(args.fuse):
+                                    cfg = E.make_config(lds_doubles=lds, part_rows=part_rows, window_mode=mode, threads=threads,
+                                                        ell_variant=var, items_per_cu=ipc, col_sharing=sh, fuse_er=fu)
+                                    plans.append(((threads, var, ipc, sh * 10 + fu), E.Plan(m, cfg)))
                 ref = None
                 best = {}
                 for rnd in range(args.rounds):
