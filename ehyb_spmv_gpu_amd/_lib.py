@@ -52,6 +52,8 @@ class Config(C.Structure):
         ("col_sharing", C.c_int32),
         ("fuse_er", C.c_int32),
         ("cap_split", C.c_int32),
+        ("hub_rule", C.c_int32),
+        ("reserved", C.c_int32 * 7),
     ]
 
 

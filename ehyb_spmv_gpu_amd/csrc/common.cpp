@@ -56,6 +56,7 @@ Config resolve_config(const ehyb_config* in)
     // loses badly on residual-heavy inputs, where the flat residual kernel has far more parallelism
     c.fuse_er = z.fuse_er == 1 ? 1 : 2;
     c.cap_split = z.cap_split == 2 ? 2 : 1;
+    c.hub_rule = z.hub_rule == 2 ? 2 : 1;
     return c;
 }
 

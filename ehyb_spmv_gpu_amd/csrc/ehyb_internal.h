@@ -41,6 +41,7 @@ struct Config {
     int col_sharing;
     int fuse_er;
     int cap_split;
+    int hub_rule;
 };
 Config resolve_config(const ehyb_config* cfg);
 

@@ -117,6 +117,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     std::vector<PartScratch> ps(np);
     std::vector<int32_t> cnt_ell(nrows, 0);
     std::vector<uint8_t> lead_row(nrows, 1);
+    std::vector<uint8_t> row_to_er(nrows, 0);  // whole row in the residual (hub rows)
     const bool share = cfg.col_sharing != 2;
     L->win_len.assign(np, 0);
     int bad_col = 0, bad_row = 0;
@@ -187,9 +188,43 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                         ++c;
                 }
                 cnt_ell[r - row_begin] = c;
-                uint32_t w2 = (uint32_t)(c + 1) / 2;
-                uint32_t& sw = S.slab_w2[(r - s) / kSlabRows];
-                if (w2 > sw) sw = w2;
+            }
+            // Slab widths.  A slab is as wide as its longest row, so a few very long rows (R-MAT
+            // hubs) would pad 60-odd short rows up to their length.  Per slab the rows are taken
+            // longest first and moved to the residual -- whole row, the CSR segments handle any
+            // length -- while that lowers the bytes moved: ELL costs 64 x width x ~9 B, a residual
+            // entry ~30 B (12 streamed + an uncoalesced 8-byte gather of x).  This is the intent
+            // of the reference's long-row path (rows with > 512 in-window entries,
+            // convert.c:92-101), which it never launches.
+            for (int q = 0; q < nslab; ++q) {
+                const int r0 = s + q * kSlabRows, r1 = std::min(e, r0 + kSlabRows);
+                int idx[kSlabRows];
+                int m_rows = r1 - r0;
+                for (int i = 0; i < m_rows; ++i) idx[i] = r0 + i;
+                std::sort(idx, idx + m_rows, [&](int a, int b) {
+                    int ca = cnt_ell[a - row_begin], cb = cnt_ell[b - row_begin];
+                    return ca != cb ? ca > cb : a < b;
+                });
+                int64_t best_cost = -1, cost0 = 0, moved = 0;
+                int best_j = 0;
+                for (int j = 0; j <= m_rows && cfg.hub_rule != 2; ++j) {  // rows idx[0..j) go to the residual
+                    const int width = j < m_rows ? (cnt_ell[idx[j] - row_begin] + 1) / 2 * 2 : 0;
+                    const int64_t cost = moved * 30 + (int64_t)j * 2048 + (int64_t)kSlabRows * width * 9;
+                    if (j == 0) cost0 = cost;
+                    if (best_cost < 0 || cost < best_cost) best_cost = cost, best_j = j;
+                    if (j < m_rows) moved += cnt_ell[idx[j] - row_begin];
+                    if (width == 0) break;
+                }
+                // only a clear win (> 25 % fewer bytes) is worth residual rows: mildly ragged slabs
+                // stay pure ELL (an empty residual also saves the second launch)
+                if (best_cost * 4 > cost0 * 3) best_j = 0;
+                for (int j = 0; j < best_j; ++j) {
+                    cnt_ell[idx[j] - row_begin] = 0;
+                    row_to_er[idx[j] - row_begin] = 1;
+                }
+                uint32_t w2 = 0;
+                for (int r = r0; r < r1; ++r) w2 = std::max(w2, (uint32_t)(cnt_ell[r - row_begin] + 1) / 2);
+                S.slab_w2[q] = w2;
             }
             // Column-list sharing: a row whose column sequence equals that of the row above it
             // (same slab) joins that row's group and stores no column indices of its own.
@@ -197,7 +232,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             S.slab_g.assign(nslab, 0);
             for (int r = s; r < e; ++r) {
                 bool lead = true;
-                if (share && (r - s) % kSlabRows != 0) {
+                if (share && (r - s) % kSlabRows != 0 && !row_to_er[r - row_begin] && !row_to_er[r - 1 - row_begin]) {
                     const int len = rp[r + 1] - rp[r];
                     lead = len != rp[r] - rp[r - 1] ||
                            (len > 0 && memcmp(m->J + rp[r], m->J + rp[r - 1], sizeof(int) * (size_t)len) != 0);
@@ -299,7 +334,9 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 int local = -1;
                 // window-local index: the LDS image starts at the even row at or below s, so the
                 // staging loads of the kernel are 16-byte aligned (x is hipMalloc-aligned)
-                if (j >= s && j < s + wlen)
+                if (row_to_er[r - row_begin])
+                    local = -1;  // hub row: every entry goes to the residual
+                else if (j >= s && j < s + wlen)
                     local = j - (s & ~1);
                 else if (halo_mode && !S.halo.empty()) {
                     int h = halo_lookup(S.halo, j);

@@ -472,7 +472,20 @@ int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vw
     fine.vw = vwgt;
 
     if (cfg.partitioner == EHYB_PART_CONTIGUOUS) {
-        // equal-weight contiguous blocks of the given numbering
+        // contiguous blocks of the given numbering.  Unit weights: equal chunks rounded up to whole
+        // 64-row slabs (so block-structured inputs keep their alignment: config 3's 1024-row blocks
+        // stay inside one window); weighted: equal-weight blocks.
+        if (!vwgt) {
+            int64_t chunk = (((int64_t)n + nparts - 1) / nparts + kSlabRows - 1) / kSlabRows * kSlabRows;
+            if (chunk > cap) chunk = cap;
+            for (int v = 0; v < n; ++v) part[v] = (int)std::min<int64_t>(v / chunk, nparts - 1);
+            int64_t last = n - chunk * (nparts - 1);
+            if (last > cap) {  // rounding down to the cap left too much for the last block: spread evenly
+                for (int v = 0; v < n; ++v) part[v] = (int)((int64_t)v * nparts / n);
+            }
+            if (edgecut) *edgecut = edge_cut(fine, part);
+            return EHYB_OK;
+        }
         int64_t acc = 0;
         int p = 0;
         int64_t in_p = 0;
