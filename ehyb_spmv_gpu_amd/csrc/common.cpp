@@ -54,7 +54,7 @@ Config resolve_config(const ehyb_config* in)
     c.col_sharing = z.col_sharing == 2 ? 2 : 1;
     // measured (tools/sweep.py --fuse 1,2): the fused tail saves ~1 % at best on the bench matrix and
     // loses badly on residual-heavy inputs, where the flat residual kernel has far more parallelism
-    c.fuse_er = z.fuse_er == 1 ? 1 : 2;
+    c.fuse_er = (z.fuse_er == 1 || z.fuse_er == 2) ? z.fuse_er : 0;  // 0 = automatic (ehyb_hip.hip: fuse_residual)
     c.cap_split = z.cap_split == 2 ? 2 : 1;
     c.hub_rule = z.hub_rule == 2 ? 2 : 1;
     return c;

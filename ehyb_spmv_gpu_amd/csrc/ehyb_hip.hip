@@ -407,9 +407,18 @@ static int launch_er(ehyb_plan* P, const double* x, double* y, hipStream_t st)
     return EHYB_OK;
 }
 
-// The residual rides in the ELL launch unless the caller needs the two phases apart (multi-GPU
-// overlap: phase 1 reads only the rank's own x segment) or asked for the split form.
-static bool fuse_residual(const ehyb_plan* P) { return P->cfg.n_top <= 1 && P->cfg.fuse_er != 2; }
+// Where the residual runs.  Two launches need a second ~8 us kernel boundary but give the residual
+// thousands of independent blocks; the fused tail costs nothing when the residual is tiny and
+// serialises it behind each workgroup's slabs when it is not (measured: tools/sweep.py --fuse).
+// fuse_er: 1 = always fused, 2 = never, 0 = automatic: fused iff the residual holds < 0.2 % of
+// the entries.  Multi-GPU plans keep the phases apart (phase 1 reads only the rank's x segment).
+static bool fuse_residual(const ehyb_plan* P)
+{
+    if (P->cfg.n_top > 1 || P->cfg.fuse_er == 2) return false;
+    if (P->cfg.fuse_er == 1) return true;
+    const ehyb_stats& st = P->host.stats;
+    return st.nnz_er * 500 < st.nnz;
+}
 
 template <class T>
 static int upload(T** dst, const std::vector<T>& src)

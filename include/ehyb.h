@@ -86,7 +86,8 @@ typedef struct ehyb_config {
     int32_t ell_variant;   /* ELL kernel A/B arms: 0 = default (3), 1 = simple loop + 4-deep staging,
                               2 = software-pipelined loop, 3 = simple loop + scalar staging */
     int32_t col_sharing;   /* 0/1 = rows with the column list of the row above share its indices, 2 = off */
-    int32_t fuse_er;       /* 1 = residual rides in the ELL launch (single GPU only), 0/2 = two launches */
+    int32_t fuse_er;       /* residual placement: 0 = automatic (inside the ELL launch iff it holds < 0.2 %
+                              of the entries), 1 = always inside (single GPU only), 2 = own launch     */
     int32_t cap_split;     /* 0/1 = bisect partitions whose halo overflows the window (reorder step), 2 = off */
     int32_t hub_rule;      /* 0/1 = rows that would pad their slab by > 25 % go to the residual whole
                               (the reference's long-row intent, convert.c:92-101), 2 = off          */
