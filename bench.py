@@ -70,12 +70,21 @@ def main():
             raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the EHYB multiply has no CPU fallback")
+    # EHYB_BENCH_ONE_DEVICE=1 + EHYB_BENCH_BACKEND=gloo: all ranks on cuda:0 over gloo -- a functional
+    # test of the N > 1 path on a one-GPU box (not a measurement; RCCL refuses shared devices).
+    one_device = os.environ.get("EHYB_BENCH_ONE_DEVICE") == "1"
+    backend = os.environ.get("EHYB_BENCH_BACKEND", "nccl")
+    if one_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     def log(*a):
         if rank == 0:
@@ -97,6 +106,12 @@ def main():
     # ---- CPU baseline on the un-permuted matrix (rank 0, N = 1 only): the oracle, timed
     cpu_baseline = None
     x = E.x_glibc(n)
+    y_cpu = scale = None
+    if rank == 0 and world > 1:
+        from oracle import oracle as O
+
+        y_cpu = O.spmv_coo(n, m.I, m.J, m.V, x)  # checker for the sharded result (not timed)
+        scale = O.abs_rowsum(n, m.I, m.J, m.V, x)
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import oracle as O
 
@@ -113,8 +128,6 @@ def main():
         }
         scale = O.abs_rowsum(n, m.I, m.J, m.V, x)
         log(f"[bench] cpu baseline: {cpu_baseline['value']} GFLOP/s on {cores} threads")
-    else:
-        y_cpu = scale = None
 
     # ---- host pre-step: partition + permute (matrixReorder), then this rank's plan
     t0 = time.time()
@@ -157,6 +170,10 @@ def main():
 
     # ---- parity of what was just timed (rank-local rows) against the CPU oracle
     parity = None
+    if world > 1:
+        # every rank holds its own y rows: collect all segments (same exchange as for x)
+        D.exchange_segments(y_d, row_cuts, rank)
+        torch.cuda.synchronize()
     if y_cpu is not None:
         from oracle import oracle as O
 

@@ -42,7 +42,9 @@ Config resolve_config(const ehyb_config* in)
     c.part_rows = std::max(kSlabRows, round_down(c.part_rows, kSlabRows));
     c.threads = z.threads > 0 ? z.threads : 1024;  // 2 workgroups x 16 waves per CU at the default window
     c.threads = std::min(1024, std::max(64, round_down(c.threads, 64)));
-    c.items_per_cu = z.items_per_cu > 0 ? z.items_per_cu : 3;  // measured best (profiles/r01_sweep_*.txt)
+    // 2 workgroups are resident per CU: 2 items per CU = exactly one wave of workgroups.  Measured:
+    // 512 and 1024 items are good, 768 (one and a half waves) loses up to 12 % (tools/sweep.py).
+    c.items_per_cu = z.items_per_cu > 0 ? z.items_per_cu : 2;
     c.partitioner = z.partitioner;
     c.er_seg_len = z.er_seg_len > 0 ? std::max(64, z.er_seg_len) : 4096;
     c.host_threads = z.host_threads;
