@@ -297,6 +297,17 @@ class Plan:
                                         C.byref(r) if per_kernel else None), "ehyb_spmv_bench")
         return {"ms_total": t.value, "ms_ell_avg": e.value, "ms_er_avg": r.value}
 
+    def cg(self, b, x0=None, max_iter=1000, rtol=1e-10, check_every=10):
+        """ehyb_cg: conjugate gradients on the device (b, x in the permuted numbering).
+        -> (x, iterations, relative residual)"""
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        db, dx = DeviceBuffer(self.n).upload(b), DeviceBuffer(self.n)
+        dx.upload(np.zeros(self.n) if x0 is None else x0)
+        it, rel = C.c_int(0), C.c_double(0)
+        _check(self.lib.ehyb_cg(self.h, C.c_void_p(db.ptr), C.c_void_p(dx.ptr), max_iter, rtol, check_every, None,
+                                C.byref(it), C.byref(rel)), "ehyb_cg")
+        return dx.download(), it.value, rel.value
+
     def destroy(self):
         if self.h:
             self.lib.ehyb_plan_destroy(self.h)

@@ -252,6 +252,22 @@ int ehyb_dev_sync(void);
 /* Streaming-read ceiling of this device: sums `bytes` of doubles `iters` times, returns GB/s. */
 int ehyb_measure_read_bw(size_t bytes, int iters, double* gbps);
 
+/* ------------------------------------------------ iterative caller */
+
+/*
+ * Unpreconditioned conjugate gradients for A x = b on the plan's (symmetric positive definite)
+ * matrix, entirely on the device: x_dev starts as the initial guess and ends as the solution,
+ * both in the permuted numbering.  This is the solver the reference was cut down from (its
+ * leftovers: kernelMyxpy y = x + gamma*y, kernel.cu:288-296; initialize_all, kernel.cu:20-31;
+ * the PRECOND/FACT switches of cb_s) and the caller for which "x changes every multiply" matters.
+ * One ehyb_spmv plus three fused vector kernels per iteration; scalars stay on the device, the
+ * host looks at the residual every `check_every` iterations (<= 0: 10).
+ * Stops when ||r|| <= rtol * ||b|| or after max_iter iterations.  Outputs may be NULL.
+ * Needs a plan over all rows (single GPU).
+ */
+int ehyb_cg(ehyb_plan* plan, const double* b_dev, double* x_dev, int max_iter, double rtol,
+            int check_every, void* stream, int* iters_done, double* rel_residual);
+
 /* -------------------------------------------- harness pieces (solver_test.c) */
 
 /*

@@ -1,0 +1,91 @@
+"""The iterative caller: device-resident CG on the plan API, where the x of
+every multiply differs -- the case in which the reference's "residual computed once" defect
+(spmv.cu:41 vs kernel.cu:171-176) would give wrong answers."""
+import numpy as np
+import pytest
+import scipy.sparse as sp
+import scipy.sparse.linalg as spla
+
+pytestmark = pytest.mark.gpu
+
+
+def spd_matrix(nx, ny, extra, seed):
+    """2-D 5-point Laplacian + a few random symmetric couplings, made strictly diagonally dominant."""
+    rng = np.random.default_rng(seed)
+    n = nx * ny
+    idx = np.arange(n).reshape(ny, nx)
+    r = np.concatenate([idx[:, :-1].ravel(), idx[:-1, :].ravel(), rng.integers(0, n, extra)])
+    c = np.concatenate([idx[:, 1:].ravel(), idx[1:, :].ravel(), rng.integers(0, n, extra)])
+    keep = r != c
+    r, c = r[keep], c[keep]
+    v = -rng.uniform(0.5, 1.5, len(r))
+    A = sp.coo_matrix((np.concatenate([v, v]), (np.concatenate([r, c]), np.concatenate([c, r]))), shape=(n, n)).tocsr()
+    A.sum_duplicates()
+    d = np.asarray(abs(A).sum(axis=1)).ravel() + 0.05
+    return (A + sp.diags(d)).tocsr()
+
+
+def cpu_cg(A, b, max_iter, rtol):
+    """The same recurrences on the CPU (the checker), iteration for iteration."""
+    x = np.zeros_like(b)
+    r = b.copy()
+    p = r.copy()
+    rs = r @ r
+    bb = b @ b
+    hist = [np.sqrt(rs / bb)]
+    it = 0
+    while it < max_iter and np.sqrt(rs / bb) > rtol:
+        q = A @ p
+        alpha = rs / (p @ q)
+        x += alpha * p
+        r -= alpha * q
+        rs_new = r @ r
+        p = r + (rs_new / rs) * p
+        rs = rs_new
+        it += 1
+        hist.append(np.sqrt(rs / bb))
+    return x, it, hist
+
+
+@pytest.mark.parametrize("mode,lds", [(2, 2048), (1, 512)])
+def test_cg_matches_cpu_and_scipy(E, O, gpu, mode, lds):
+    A = spd_matrix(120, 100, 3000, 1)
+    n = A.shape[0]
+    cfg = E.make_config(window_mode=mode, lds_doubles=lds)
+    m = E.Matrix.from_csr(A.indptr, A.indices, A.data, cfg, symmetric=True)
+    m.reorder(cfg)
+    perm = m.reorder_list.copy()
+    plan = E.Plan(m, cfg)
+    if mode == 1:
+        assert plan.stats["nnz_er"] > 0, "this arm must exercise the residual on every iteration"
+    b = O.x_glibc(n) + 0.3
+    xp, iters, rel = plan.cg(E.vector_reorder(b, perm), max_iter=400, rtol=1e-10, check_every=1)
+    x = E.vector_recover(xp, perm)
+    x_cpu, it_cpu, hist = cpu_cg(A, b, 400, 1e-10)
+    assert rel <= 1e-10 and abs(iters - it_cpu) <= 2, (iters, it_cpu, rel)
+    assert np.linalg.norm(A @ x - b) <= 2e-10 * np.linalg.norm(b)
+    assert np.linalg.norm(x - x_cpu) <= 1e-8 * np.linalg.norm(x_cpu)
+    x_sp, info = spla.cg(A, b, rtol=1e-12, maxiter=2000)
+    assert info == 0 and np.linalg.norm(x - x_sp) <= 1e-7 * np.linalg.norm(x_sp)
+
+
+def test_cg_stops_at_max_iter_and_reports_breakdown(E, O, gpu):
+    A = spd_matrix(60, 50, 500, 2)
+    cfg = E.make_config(lds_doubles=1024)
+    m = E.Matrix.from_csr(A.indptr, A.indices, A.data, cfg, symmetric=True)
+    m.reorder(cfg)
+    plan = E.Plan(m, cfg)
+    b = E.vector_reorder(np.ones(A.shape[0]), m.reorder_list)
+    _, iters, rel = plan.cg(b, max_iter=7, rtol=1e-30, check_every=3)
+    assert iters == 7 and 0 < rel < 1
+    # an indefinite matrix breaks CG down: reported as an error, not a silent NaN
+    B = (sp.diags(np.r_[np.ones(A.shape[0] // 2), -np.ones(A.shape[0] - A.shape[0] // 2)]) @ A).tocsr()
+    B = ((B + B.T) * 0.5).tocsr()
+    mb = E.Matrix.from_csr(B.indptr, B.indices, B.data, cfg, symmetric=True)
+    mb.reorder(cfg)
+    pb = E.Plan(mb, cfg)
+    try:
+        _, it2, rel2 = pb.cg(E.vector_reorder(np.ones(A.shape[0]), mb.reorder_list), max_iter=200, rtol=1e-12)
+        assert not np.isnan(rel2)
+    except E.EhybError as e:
+        assert "breakdown" in str(e)
