@@ -134,7 +134,11 @@ __device__ __forceinline__ void er_item(const int4 er, const int64_t* __restrict
 // ------------------------------------------------------------------ ELL kernel
 // STAMP = true is a diagnostic instantiation (tools/ only): thread 0 of every workgroup records
 // the 100 MHz wall clock at entry, after staging and at exit into a buffer of its own.
-template <int THREADS, bool STAMP = false, bool SCALAR_STAGE = false, bool FUSE_ER = false>
+// EARLY = true shortens the cold-start chain of dependent misses (item -> partition arrays ->
+// x / halo-index loads -> gathers -> barrier -> slab record -> lane map -> values: 7 hops): the
+// partition scalars come with the item (item_part) and the first slab's record and lane map are
+// requested before the window is staged, so they arrive while it is being filled.
+template <int THREADS, bool STAMP = false, bool SCALAR_STAGE = false, bool FUSE_ER = false, bool EARLY = false>
 __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
     const int4* __restrict__ items, const int* __restrict__ part_boundary, const int* __restrict__ win_len,
     const int* __restrict__ halo_ptr, const int* __restrict__ halo_cols,
@@ -142,17 +146,33 @@ __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
     const double2* __restrict__ ell_val, const uint32_t* __restrict__ ell_col, const double* __restrict__ x,
     double* __restrict__ y, const int64_t* __restrict__ er_seg_ptr, const int* __restrict__ er_seg_row,
     const int* __restrict__ er_col, const double* __restrict__ er_val,
-    unsigned long long* __restrict__ stamps = nullptr)
+    unsigned long long* __restrict__ stamps = nullptr, const int4* __restrict__ item_part = nullptr)
 {
     extern __shared__ __attribute__((aligned(16))) double win[];
     if (STAMP && threadIdx.x == 0) stamps[4 * blockIdx.x + 0] = wall_clock64();
     const int4 it = items[2 * blockIdx.x];
     const int p = it.x;
-    const int ps = part_boundary[p];
-    const int pe = part_boundary[p + 1];
-    const int wl = win_len[p];
-    const int hb = halo_ptr[p];
-    const int hn = halo_ptr[p + 1] - hb;
+    int ps, pe, wl, hb, hn;
+    if (EARLY) {
+        const int4 a = item_part[2 * blockIdx.x], b = item_part[2 * blockIdx.x + 1];
+        ps = a.x, pe = a.y, wl = a.z, hb = a.w, hn = b.x;
+    } else {
+        ps = part_boundary[p];
+        pe = part_boundary[p + 1];
+        wl = win_len[p];
+        hb = halo_ptr[p];
+        hn = halo_ptr[p + 1] - hb;
+    }
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    constexpr int WAVES = THREADS / 64;
+    const int s_first = it.y + wave;
+    uint4 sm_first = make_uint4(0, 0, 0, 0);
+    uint32_t lg_first = 0;
+    if (EARLY && s_first < it.z) {
+        sm_first = slab_meta[s_first];
+        lg_first = lane_group[(size_t)s_first * 64 + lane];
+    }
 
     if (SCALAR_STAGE) {  // A/B arm: one dependent load per thread per pass
         const int base = ps & ~1, cnt = wl + (ps & 1);
@@ -164,17 +184,15 @@ __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
     __syncthreads();
     if (STAMP && threadIdx.x == 0) stamps[4 * blockIdx.x + 1] = wall_clock64();
 
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int WAVES = THREADS / 64;
-
-    for (int s = it.y + wave; s < it.z; s += WAVES) {
+    for (int s = s_first; s < it.z; s += WAVES) {
         // slab record {first value pair, first column word, first row, pairs << 8 | groups - 1}
-        const uint4 sm = slab_meta[s];
+        const bool first = EARLY && s == s_first;
+        const uint4 sm = first ? sm_first : slab_meta[s];
+        const uint32_t lg = first ? lg_first : (uint32_t)lane_group[(size_t)s * 64 + lane];
         const int np = (int)(sm.w >> 8);
         const int G = (int)(sm.w & 0xffu) + 1;  // lanes with equal column lists share one word per pair
         const double2* __restrict__ v = ell_val + (size_t)sm.x * 64 + lane;
-        const uint32_t* __restrict__ c = ell_col + sm.y + lane_group[(size_t)s * 64 + lane];
+        const uint32_t* __restrict__ c = ell_col + sm.y + lg;
         double acc0 = 0.0, acc1 = 0.0;
         int k = 0;
         for (; k + 4 <= np; k += 4) {
@@ -374,6 +392,9 @@ static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st, 
         hipLaunchKernelGGL((ehyb_ell_kernel_pipe<T, F>), dim3(n_items), dim3(T), lds, st, ELL_ARGS);         \
     else if (var == 3)                                                                                       \
         hipLaunchKernelGGL((ehyb_ell_kernel<T, false, true, F>), dim3(n_items), dim3(T), lds, st, ELL_ARGS, nullptr); \
+    else if (var == 4)                                                                                       \
+        hipLaunchKernelGGL((ehyb_ell_kernel<T, false, true, F, true>), dim3(n_items), dim3(T), lds, st, ELL_ARGS,  \
+                           nullptr, (const int4*)P->d_item_part);                                            \
     else                                                                                                     \
         hipLaunchKernelGGL((ehyb_ell_kernel<T, false, false, F>), dim3(n_items), dim3(T), lds, st, ELL_ARGS, nullptr);
 #define ELL_LAUNCH(T)            \
@@ -444,6 +465,8 @@ static void free_device(ehyb_plan* P)
     P->d_ell_val = P->d_er_val = nullptr;
     if (P->d_er_blocks) (void)hipFree(P->d_er_blocks);
     P->d_er_blocks = nullptr;
+    if (P->d_item_part) (void)hipFree(P->d_item_part);
+    P->d_item_part = nullptr;
     P->d_ell_col = nullptr;
     P->d_lane_group = nullptr;
     P->d_slab_meta = nullptr;
@@ -602,6 +625,22 @@ int ehyb_plan_upload(ehyb_plan* P)
     UP(d_er_col, er_col)
     UP(d_er_val, er_val)
     UP(d_er_blocks, er_blocks)
+    {
+        // partition scalars per work item {first row, end row, contiguous window length, halo start}, {halo count}
+        std::vector<int32_t> ip(H.items.size());
+        for (size_t it = 0; it < H.items.size() / 8; ++it) {
+            const int p = H.items[8 * it];
+            ip[8 * it + 0] = H.part_boundary[p];
+            ip[8 * it + 1] = H.part_boundary[p + 1];
+            ip[8 * it + 2] = H.win_len[p];
+            ip[8 * it + 3] = H.halo_ptr[p];
+            ip[8 * it + 4] = H.halo_ptr[p + 1] - H.halo_ptr[p];
+        }
+        if ((rc = upload(&P->d_item_part, ip)) != EHYB_OK) {
+            free_device(P);
+            return rc;
+        }
+    }
 #undef UP
     // opt in to the full 160 KiB of LDS (the role of cudaFuncSetAttribute at kernel.cu:351,411)
     const int lds = (int)((((size_t)H.lds_doubles * 8) + 15) / 16 * 16);
@@ -611,6 +650,8 @@ int ehyb_plan_upload(ehyb_plan* P)
     LDS_ATTR((ehyb_ell_kernel<T, false, false, true>))    \
     LDS_ATTR((ehyb_ell_kernel<T, false, true, false>))    \
     LDS_ATTR((ehyb_ell_kernel<T, false, true, true>))     \
+    LDS_ATTR((ehyb_ell_kernel<T, false, true, false, true>)) \
+    LDS_ATTR((ehyb_ell_kernel<T, false, true, true, true>))  \
     LDS_ATTR((ehyb_ell_kernel_pipe<T, false>))            \
     LDS_ATTR((ehyb_ell_kernel_pipe<T, true>))
     LDS_ATTR_T(256)

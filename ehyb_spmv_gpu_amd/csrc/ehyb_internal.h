@@ -145,4 +145,5 @@ struct ehyb_plan {
     int32_t* d_er_col = nullptr;
     double* d_er_val = nullptr;
     int32_t* d_er_blocks = nullptr;
+    int32_t* d_item_part = nullptr;  // per item {ps, pe, win_len, halo_begin}, {halo_count}
 };

@@ -1,0 +1,48 @@
+"""The harness binary end to end (reference usage: ./spmv.out -i 2000 -m audikw_1, README.md:10):
+`solver_test -m <name> -i <iters>` reads ./read/<name>.mtx, follows the banner for symmetric vs
+general, runs the whole path and compares with its in-line CPU product."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+BIN = os.path.join(ROOT, "ehyb_spmv_gpu_amd", "solver_test")
+
+pytestmark = pytest.mark.gpu
+
+
+def _run(args, cwd):
+    return subprocess.run([BIN] + args, cwd=cwd, capture_output=True, text=True, timeout=600)
+
+
+def test_cli_symmetric_mtx_bcsstk17_sized(E, gpu, tmp_path):
+    """BASELINE config 1's size (bcsstk17: 10,974 rows, 428,650 entries) as a symmetric .mtx."""
+    (tmp_path / "read").mkdir()
+    m = E.Matrix.generate("fem3d", 10974, 3, 62, 59, 250000, 1, 17)   # one 62 x 59 layer of 3-dof nodes
+    assert m.n == 10974 and 350_000 < m.nnz < 520_000
+    m.write_mtx(tmp_path / "read" / "bcsstk17_like.mtx", symmetric_lower_only=True)
+    p = _run(["-i", "200", "-m", "bcsstk17_like"], tmp_path)
+    out = p.stdout
+    assert p.returncode == 0, out[-2000:] + p.stderr[-2000:]
+    assert "filename is ./read/bcsstk17_like.mtx" in out and "read symmetric matrix" in out
+    assert "sizeER is" in out and "iter is 200, time is" in out and "GPU Gflops is" in out   # spmv.cu:82,121
+    assert "diff is" in out and "PASSED" in out                                             # solver_test.c:28
+
+
+def test_cli_general_mtx_and_reference_window(E, gpu, tmp_path):
+    (tmp_path / "read").mkdir()
+    m = E.Matrix.generate("rmat", 12, 1 << 15, 3)
+    m.write_mtx(tmp_path / "read" / "g.mtx")
+    p = _run(["-i", "20", "-m", "g", "-w", "1", "-l", "1024"], tmp_path)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-2000:]
+    assert "read unsymmetric matrix" in p.stdout and "PASSED" in p.stdout
+
+
+def test_cli_usage_errors(gpu, tmp_path):
+    p = _run(["-i", "10"], tmp_path)                       # no matrix: solver_test.c:318-321
+    assert p.returncode != 0 and "file name or max iteration number missing" in p.stdout
+    p = _run(["-i", "10", "-m", "does_not_exist"], tmp_path)
+    assert p.returncode != 0 and "file read error" in p.stdout    # solver_test.c:328-331
+    p = _run(["-i", "5", "-g", "stencil2d:40:30:5:100"], tmp_path)
+    assert p.returncode == 0 and "PASSED" in p.stdout
