@@ -1,24 +1,31 @@
 // HIP kernels for gfx950 (MI355X, CDNA4) and the device half of the C-ABI.
 //
 // Kernels (replace reference kernel.cu:43-284):
-//   ehyb_ell_kernel  one workgroup per work item {partition, slab range}:
+//   ehyb_ell_kernel  one workgroup per work item = a run of 64-row slabs of (nearly) equal byte
+//                    count, cut into segments at partition boundaries.  Per segment:
 //                      1. stage the partition's x-window into LDS -- contiguous own segment
 //                         (coalesced) + gathered halo columns (the "explicit cache",
 //                         kernel.cu:137-141, grown to <= 160 KiB per workgroup);
-//                      2. each wave64 walks 64-row slabs: per lane one row, per step one
-//                         16-byte value pair (global_load_dwordx4, 1 KiB per wave) and one
-//                         4-byte pair of 16-bit window-local columns, two LDS gathers
-//                         (ds_read_b64) and two fp64 FMAs (kernel.cu:150-163);
+//                      2. every wave64 takes slabs from an LDS counter (the reference's per-block
+//                         work queue, kernel.cu:142,164-166 -- here re-armed per segment, so
+//                         nothing survives a launch); per lane one row, per step one 16-byte
+//                         value pair (global_load_dwordx4, 1 KiB per wave) and one 4-byte word
+//                         holding two 16-bit window-local columns (shared by lanes with equal
+//                         column lists), two LDS gathers (ds_read_b64) and two fp64 FMAs
+//                         (kernel.cu:150-163);
 //                      3. y[row] = dot, 512 B coalesced per slab.
-//                    Static slab->wave assignment (slabs of a partition are sorted by width),
-//                    so no work-queue atomics (kernel.cu:142,164-166) and nothing to reset.
 //   ehyb_er_kernel   CSR residual: G lanes per segment (64/16/4 by segment length), strided
 //                    coalesced (col,val) reads, x gathered from global memory (L2/MALL),
 //                    wavefront shuffle reduction, y[row] += sum -- or one fp64 atomic per
 //                    segment for rows split into several segments (the working form of
 //                    kernel.cu:43-67 longRowKernel).  Runs on every multiply (the reference
-//                    skips it after the first launch: SURVEY 8 a-10 item 1).
-// No MFMA: 2 flops per 10-12 streamed bytes, HBM-bound.
+//                    skips it after the first launch: SURVEY 8 a-10 item 1); as its own launch or,
+//                    when tiny, as the tail of the ELL workgroups.
+// No MFMA: 2 flops per 8.7-10 streamed bytes, HBM-bound.
+//
+// Arms tried and dropped (measurements in DESIGN.md): software-pipelined slab walk with ping-pong
+// register groups, 4-deep unrolled double2 staging, early slab-record loads.  None beat this loop
+// at 32 waves per CU; the decisive levers were bytes (shared column lists) and scheduling.
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -36,47 +43,6 @@ using namespace ehyb;
             return _e == hipErrorNoDevice ? EHYB_ERR_NO_DEVICE : EHYB_ERR_HIP;                \
         }                                                                                     \
     } while (0)
-
-// ------------------------------------------------------------------ window staging
-// The LDS image of a partition's window starts at the even row at or below the partition start
-// (the layout builder numbers window-local columns from there), so the contiguous part moves
-// as 16-byte aligned double2 loads and ds_write_b128; up to four loads per thread are issued
-// before the first LDS write.  Halo columns follow: index load, x gather, LDS write, again four
-// deep.  win[0] may hold x[ps-1] when ps is odd; no entry refers to it.
-template <int THREADS>
-__device__ __forceinline__ void stage_window(double* __restrict__ win, const double* __restrict__ x, int ps,
-                                             int wl, const int* __restrict__ hc, int hn)
-{
-    const int base = ps & ~1;
-    const int cnt = wl + (ps & 1);
-    const int n2 = cnt >> 1;
-    const double2* __restrict__ x2 = reinterpret_cast<const double2*>(x + base);
-    double2* __restrict__ w2 = reinterpret_cast<double2*>(win);
-    for (int i0 = threadIdx.x; i0 < n2; i0 += 4 * THREADS) {
-        double2 a[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i0 + j * THREADS < n2) a[j] = x2[i0 + j * THREADS];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i0 + j * THREADS < n2) w2[i0 + j * THREADS] = a[j];
-    }
-    if ((cnt & 1) && threadIdx.x == 0) win[cnt - 1] = x[base + cnt - 1];
-    double* __restrict__ wh = win + cnt;
-    for (int i0 = threadIdx.x; i0 < hn; i0 += 4 * THREADS) {
-        int c[4];
-        double a[4];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i0 + j * THREADS < hn) c[j] = hc[i0 + j * THREADS];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i0 + j * THREADS < hn) a[j] = x[c[j]];
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-            if (i0 + j * THREADS < hn) wh[i0 + j * THREADS] = a[j];
-    }
-}
 
 // ------------------------------------------------------------------ residual tail
 // The residual segments of a work item's rows, multiplied by the whole workgroup: G lanes per
@@ -132,89 +98,82 @@ __device__ __forceinline__ void er_item(const int4 er, const int64_t* __restrict
 }
 
 // ------------------------------------------------------------------ ELL kernel
-// STAMP = true is a diagnostic instantiation (tools/ only): thread 0 of every workgroup records
-// the 100 MHz wall clock at entry, after staging and at exit into a buffer of its own.
-// EARLY = true shortens the cold-start chain of dependent misses (item -> partition arrays ->
-// x / halo-index loads -> gathers -> barrier -> slab record -> lane map -> values: 7 hops): the
-// partition scalars come with the item (item_part) and the first slab's record and lane map are
-// requested before the window is staged, so they arrive while it is being filled.
-template <int THREADS, bool STAMP = false, bool SCALAR_STAGE = false, bool FUSE_ER = false, bool EARLY = false>
+// items[2b]   = {first segment, end segment, -, -}      items[2b+1] = residual bins of the item
+// segs[2g]    = {partition, first slab, end slab, halo count}
+// segs[2g+1]  = {first row, end row, contiguous window length, halo start}
+// DYN:   waves take slabs from the LDS counter (false: static round-robin, the A/B arm).
+// STAMP: diagnostic instantiation (tools/stamps.py only): thread 0 records the 100 MHz wall
+//        clock at entry, after the first staging and at exit into a buffer of its own.
+template <int THREADS, bool DYN, bool STAMP, bool FUSE_ER>
 __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
-    const int4* __restrict__ items, const int* __restrict__ part_boundary, const int* __restrict__ win_len,
-    const int* __restrict__ halo_ptr, const int* __restrict__ halo_cols,
+    const int4* __restrict__ items, const int4* __restrict__ segs, const int* __restrict__ halo_cols,
     const uint4* __restrict__ slab_meta, const uint8_t* __restrict__ lane_group,
     const double2* __restrict__ ell_val, const uint32_t* __restrict__ ell_col, const double* __restrict__ x,
     double* __restrict__ y, const int64_t* __restrict__ er_seg_ptr, const int* __restrict__ er_seg_row,
-    const int* __restrict__ er_col, const double* __restrict__ er_val,
-    unsigned long long* __restrict__ stamps = nullptr, const int4* __restrict__ item_part = nullptr)
+    const int* __restrict__ er_col, const double* __restrict__ er_val, int win_cap,
+    unsigned long long* __restrict__ stamps)
 {
     extern __shared__ __attribute__((aligned(16))) double win[];
+    int* next_slab = reinterpret_cast<int*>(win + win_cap);  // one word behind the window
     if (STAMP && threadIdx.x == 0) stamps[4 * blockIdx.x + 0] = wall_clock64();
     const int4 it = items[2 * blockIdx.x];
-    const int p = it.x;
-    int ps, pe, wl, hb, hn;
-    if (EARLY) {
-        const int4 a = item_part[2 * blockIdx.x], b = item_part[2 * blockIdx.x + 1];
-        ps = a.x, pe = a.y, wl = a.z, hb = a.w, hn = b.x;
-    } else {
-        ps = part_boundary[p];
-        pe = part_boundary[p + 1];
-        wl = win_len[p];
-        hb = halo_ptr[p];
-        hn = halo_ptr[p + 1] - hb;
-    }
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     constexpr int WAVES = THREADS / 64;
-    const int s_first = it.y + wave;
-    uint4 sm_first = make_uint4(0, 0, 0, 0);
-    uint32_t lg_first = 0;
-    if (EARLY && s_first < it.z) {
-        sm_first = slab_meta[s_first];
-        lg_first = lane_group[(size_t)s_first * 64 + lane];
-    }
 
-    if (SCALAR_STAGE) {  // A/B arm: one dependent load per thread per pass
+    for (int sg = it.x; sg < it.y; ++sg) {
+        const int4 a = segs[2 * sg], b = segs[2 * sg + 1];
+        const int sb = a.y, se = a.z, hn = a.w;
+        const int ps = b.x, pe = b.y, wl = b.z, hb = b.w;
+        if (sg > it.x) __syncthreads();  // every wave is done with the previous window and counter
+
+        // The LDS image starts at the even row at or below the partition start (the layout
+        // builder numbers window-local columns from there); win[0] may hold x[ps-1], unused.
         const int base = ps & ~1, cnt = wl + (ps & 1);
         for (int i = threadIdx.x; i < cnt; i += THREADS) win[i] = x[base + i];
         for (int i = threadIdx.x; i < hn; i += THREADS) win[cnt + i] = x[halo_cols[hb + i]];
-    } else {
-        stage_window<THREADS>(win, x, ps, wl, halo_cols + hb, hn);
-    }
-    __syncthreads();
-    if (STAMP && threadIdx.x == 0) stamps[4 * blockIdx.x + 1] = wall_clock64();
+        if (DYN && threadIdx.x == 0) *next_slab = sb + WAVES;  // slabs sb..sb+WAVES-1 are pre-assigned
+        __syncthreads();
+        if (STAMP && sg == it.x && threadIdx.x == 0) stamps[4 * blockIdx.x + 1] = wall_clock64();
 
-    for (int s = s_first; s < it.z; s += WAVES) {
-        // slab record {first value pair, first column word, first row, pairs << 8 | groups - 1}
-        const bool first = EARLY && s == s_first;
-        const uint4 sm = first ? sm_first : slab_meta[s];
-        const uint32_t lg = first ? lg_first : (uint32_t)lane_group[(size_t)s * 64 + lane];
-        const int np = (int)(sm.w >> 8);
-        const int G = (int)(sm.w & 0xffu) + 1;  // lanes with equal column lists share one word per pair
-        const double2* __restrict__ v = ell_val + (size_t)sm.x * 64 + lane;
-        const uint32_t* __restrict__ c = ell_col + sm.y + lg;
-        double acc0 = 0.0, acc1 = 0.0;
-        int k = 0;
-        for (; k + 4 <= np; k += 4) {
-            const double2 v0 = v[(k + 0) * 64], v1 = v[(k + 1) * 64], v2 = v[(k + 2) * 64], v3 = v[(k + 3) * 64];
-            const uint32_t c0 = c[(k + 0) * G], c1 = c[(k + 1) * G], c2 = c[(k + 2) * G], c3 = c[(k + 3) * G];
-            acc0 = fma(v0.x, win[c0 & 0xffffu], acc0);
-            acc1 = fma(v0.y, win[c0 >> 16], acc1);
-            acc0 = fma(v1.x, win[c1 & 0xffffu], acc0);
-            acc1 = fma(v1.y, win[c1 >> 16], acc1);
-            acc0 = fma(v2.x, win[c2 & 0xffffu], acc0);
-            acc1 = fma(v2.y, win[c2 >> 16], acc1);
-            acc0 = fma(v3.x, win[c3 & 0xffffu], acc0);
-            acc1 = fma(v3.y, win[c3 >> 16], acc1);
+        int s = sb + wave;
+        while (s < se) {
+            // slab record {first value pair, first column word, first row, pairs << 8 | groups - 1}
+            const uint4 sm = slab_meta[s];
+            const int np = (int)(sm.w >> 8);
+            const int G = (int)(sm.w & 0xffu) + 1;  // lanes with equal column lists share one word per pair
+            const double2* __restrict__ v = ell_val + (size_t)sm.x * 64 + lane;
+            const uint32_t* __restrict__ c = ell_col + sm.y + lane_group[(size_t)s * 64 + lane];
+            double acc0 = 0.0, acc1 = 0.0;
+            int k = 0;
+            for (; k + 4 <= np; k += 4) {
+                const double2 v0 = v[(k + 0) * 64], v1 = v[(k + 1) * 64], v2 = v[(k + 2) * 64], v3 = v[(k + 3) * 64];
+                const uint32_t c0 = c[(k + 0) * G], c1 = c[(k + 1) * G], c2 = c[(k + 2) * G], c3 = c[(k + 3) * G];
+                acc0 = fma(v0.x, win[c0 & 0xffffu], acc0);
+                acc1 = fma(v0.y, win[c0 >> 16], acc1);
+                acc0 = fma(v1.x, win[c1 & 0xffffu], acc0);
+                acc1 = fma(v1.y, win[c1 >> 16], acc1);
+                acc0 = fma(v2.x, win[c2 & 0xffffu], acc0);
+                acc1 = fma(v2.y, win[c2 >> 16], acc1);
+                acc0 = fma(v3.x, win[c3 & 0xffffu], acc0);
+                acc1 = fma(v3.y, win[c3 >> 16], acc1);
+            }
+            for (; k < np; ++k) {
+                const double2 v0 = v[k * 64];
+                const uint32_t c0 = c[k * G];
+                acc0 = fma(v0.x, win[c0 & 0xffffu], acc0);
+                acc1 = fma(v0.y, win[c0 >> 16], acc1);
+            }
+            const int row = (int)sm.z + lane;
+            if (row < pe) y[row] = acc0 + acc1;
+            if (DYN) {
+                int nx = 0;
+                if (lane == 0) nx = atomicAdd(next_slab, 1);
+                s = __builtin_amdgcn_readfirstlane(nx);
+            } else {
+                s += WAVES;
+            }
         }
-        for (; k < np; ++k) {
-            const double2 v0 = v[k * 64];
-            const uint32_t c0 = c[k * G];
-            acc0 = fma(v0.x, win[c0 & 0xffffu], acc0);
-            acc1 = fma(v0.y, win[c0 >> 16], acc1);
-        }
-        const int row = (int)sm.z + lane;
-        if (row < pe) y[row] = acc0 + acc1;
     }
     if (FUSE_ER) {  // residual of this item's rows in the same launch (no second kernel boundary)
         const int4 er = items[2 * blockIdx.x + 1];
@@ -234,118 +193,9 @@ __global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
     }
 }
 
-// ------------------------------------------------------------------ ELL kernel, pipelined
-// Same arithmetic as ehyb_ell_kernel.  Differences, all about keeping HBM requests in flight:
-//   * window staging issues 4 independent loads per thread before the first LDS write;
-//   * the slab walk is one software-pipelined stream of 4-pair groups: the loads of group g+1
-//     (possibly the first group of the wave's next slab) are issued before group g is
-//     consumed, so a wave always has 4 x (1 KiB + 256 B) outstanding, also across slabs;
-//   * a slab's last group is predicated (wave-uniform) instead of falling into a scalar tail.
-struct EllGroup {
-    double2 v[4];
-    uint32_t c[4];
-};
-
-// Unconditional loads: pair indices past the slab's last pair are clamped onto it (same cache
-// lines, no extra HBM traffic) and masked out when consumed, so the loop body stays one basic
-// block and the compiler can count outstanding loads exactly.
-__device__ __forceinline__ void ell_load(EllGroup& g, const double2* __restrict__ v,
-                                         const uint32_t* __restrict__ c, int k, int last, int G)
-{
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const int idx = min(k + j, last);  // scalar
-        g.v[j] = v[(size_t)idx * 64];
-        g.c[j] = c[(size_t)idx * G];
-    }
-}
-
-template <int THREADS, bool FUSE_ER = false>
-__global__ __launch_bounds__(THREADS) void ehyb_ell_kernel_pipe(
-    const int4* __restrict__ items, const int* __restrict__ part_boundary, const int* __restrict__ win_len,
-    const int* __restrict__ halo_ptr, const int* __restrict__ halo_cols,
-    const uint4* __restrict__ slab_meta, const uint8_t* __restrict__ lane_group,
-    const double2* __restrict__ ell_val, const uint32_t* __restrict__ ell_col, const double* __restrict__ x,
-    double* __restrict__ y, const int64_t* __restrict__ er_seg_ptr, const int* __restrict__ er_seg_row,
-    const int* __restrict__ er_col, const double* __restrict__ er_val)
-{
-    extern __shared__ __attribute__((aligned(16))) double win[];
-    const int4 it = items[2 * blockIdx.x];
-    const int p = it.x;
-    const int ps = part_boundary[p];
-    const int pe = part_boundary[p + 1];
-    const int wl = win_len[p];
-    const int hb = halo_ptr[p];
-    const int hn = halo_ptr[p + 1] - hb;
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int WAVES = THREADS / 64;
-
-    stage_window<THREADS>(win, x, ps, wl, halo_cols + hb, hn);
-    __syncthreads();
-
-    int s = it.y + wave;
-    if (s < it.z) {
-    uint4 sm = slab_meta[s];
-    int np = (int)(sm.w >> 8);
-    EllGroup ga, gb;  // ping-pong register sets: no copies, so no wait before the next issue
-    ell_load(ga, ell_val + (size_t)sm.x * 64 + lane, ell_col + sm.y + lane_group[(size_t)s * 64 + lane], 0,
-             max(np - 1, 0), (int)(sm.w & 0xffu) + 1);
-    int row0 = (int)sm.z;
-
-    double acc0 = 0.0, acc1 = 0.0;
-    int k = 0;
-    // One pipeline step: issue the loads of the group after CUR into NXT, then consume CUR.
-#define ELL_STEP(CUR, NXT)                                                                        \
-    {                                                                                             \
-        const bool slab_end = k + 4 >= np;                                                        \
-        const int ns = slab_end ? s + WAVES : s;                                                  \
-        const bool has_next = ns < it.z;                                                          \
-        const int ms = has_next ? ns : s; /* keep the prefetch addresses valid at the very end */ \
-        const uint4 qm = slab_meta[ms];                                                           \
-        const int nnp = (int)(qm.w >> 8);                                                         \
-        const int nk = slab_end ? 0 : k + 4;                                                      \
-        ell_load(NXT, ell_val + (size_t)qm.x * 64 + lane,                                         \
-                 ell_col + qm.y + lane_group[(size_t)ms * 64 + lane], nk, max(nnp - 1, 0),        \
-                 (int)(qm.w & 0xffu) + 1);                                                        \
-        _Pragma("unroll") for (int j = 0; j < 4; ++j)                                             \
-        {                                                                                         \
-            const bool live = k + j < np; /* wave-uniform mask of the clamped pairs */            \
-            const double vx = live ? CUR.v[j].x : 0.0;                                            \
-            const double vy = live ? CUR.v[j].y : 0.0;                                            \
-            acc0 = fma(vx, win[CUR.c[j] & 0xffffu], acc0);                                        \
-            acc1 = fma(vy, win[CUR.c[j] >> 16], acc1);                                            \
-        }                                                                                         \
-        if (slab_end) {                                                                           \
-            const int row = row0 + lane;                                                          \
-            if (row < pe) y[row] = acc0 + acc1;                                                   \
-            acc0 = 0.0;                                                                           \
-            acc1 = 0.0;                                                                           \
-            if (!has_next) break;                                                                 \
-        }                                                                                         \
-        s = ns;                                                                                   \
-        k = nk;                                                                                   \
-        np = nnp;                                                                                 \
-        row0 = (int)qm.z;                                                                         \
-    }
-    for (;;) {
-        ELL_STEP(ga, gb)
-        ELL_STEP(gb, ga)
-    }
-#undef ELL_STEP
-    }
-    if (FUSE_ER) {
-        const int4 er = items[2 * blockIdx.x + 1];
-        if (er.w > er.x) {
-            __syncthreads();
-            er_item<THREADS>(er, er_seg_ptr, er_seg_row, er_col, er_val, x, y);
-        }
-    }
-}
-
 // ------------------------------------------------------------------ residual kernel
-// Two-launch form (multi-GPU phase 2, or fuse_er = 2): one block per descriptor
-// {seg_lo, seg_hi, lanes per segment}, a single pass of same-bin segments each.
+// Two-launch form (multi-GPU phase 2, or a residual too large to ride in the ELL launch): one
+// block per descriptor {seg_lo, seg_hi, lanes per segment}, a single pass of same-bin segments.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void ehyb_er_kernel(const int4* __restrict__ blocks,
                                                           const int64_t* __restrict__ seg_ptr,
@@ -376,33 +226,29 @@ __global__ __launch_bounds__(256) void ehyb_read_kernel(const double2* __restric
 }
 
 // ------------------------------------------------------------------ launches
+static size_t ell_lds_bytes(const HostLayout& H) { return ((size_t)H.lds_doubles + 1) / 2 * 16 + 16; }
+static int ell_win_cap(const HostLayout& H) { return (H.lds_doubles + 1) / 2 * 2; }
+
+#define ELL_ARGS(P, x, y)                                                                                     \
+    (const int4*)(P)->d_items, (const int4*)(P)->d_segs, (P)->d_halo_cols, (const uint4*)(P)->d_slab_meta,    \
+        (P)->d_lane_group, (const double2*)(P)->d_ell_val, (P)->d_ell_col, x, y, (P)->d_er_seg_ptr,           \
+        (P)->d_er_seg_row, (P)->d_er_col, (P)->d_er_val, ell_win_cap((P)->host)
+
 static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st, bool fuse)
 {
     const HostLayout& H = P->host;
     const int n_items = (int)(H.items.size() / 8);
     if (n_items == 0) return EHYB_OK;
-    const size_t lds = (((size_t)H.lds_doubles * 8) + 15) / 16 * 16;
-#define ELL_ARGS                                                                                            \
-    (const int4*)P->d_items, P->d_part_boundary, P->d_win_len, P->d_halo_ptr, P->d_halo_cols,               \
-        (const uint4*)P->d_slab_meta, P->d_lane_group, (const double2*)P->d_ell_val, P->d_ell_col, x, y,    \
-        P->d_er_seg_ptr, P->d_er_seg_row, P->d_er_col, P->d_er_val
-    const int var = P->cfg.ell_variant;  // 1 simple, 2 pipelined, 3 simple + scalar staging (A/B arms)
-#define ELL_LAUNCH_F(T, F)                                                                                   \
-    if (var == 2)                                                                                            \
-        hipLaunchKernelGGL((ehyb_ell_kernel_pipe<T, F>), dim3(n_items), dim3(T), lds, st, ELL_ARGS);         \
-    else if (var == 3)                                                                                       \
-        hipLaunchKernelGGL((ehyb_ell_kernel<T, false, true, F>), dim3(n_items), dim3(T), lds, st, ELL_ARGS, nullptr); \
-    else if (var == 4)                                                                                       \
-        hipLaunchKernelGGL((ehyb_ell_kernel<T, false, true, F, true>), dim3(n_items), dim3(T), lds, st, ELL_ARGS,  \
-                           nullptr, (const int4*)P->d_item_part);                                            \
-    else                                                                                                     \
-        hipLaunchKernelGGL((ehyb_ell_kernel<T, false, false, F>), dim3(n_items), dim3(T), lds, st, ELL_ARGS, nullptr);
-#define ELL_LAUNCH(T)            \
-    if (fuse) {                  \
-        ELL_LAUNCH_F(T, true)    \
-    } else {                     \
-        ELL_LAUNCH_F(T, false)   \
-    }
+    const size_t lds = ell_lds_bytes(H);
+    const bool dyn = P->cfg.ell_variant != 3;  // 3 = static round-robin slabs (A/B arm)
+#define ELL_LAUNCH_DF(T, D, F)                                                                               \
+    hipLaunchKernelGGL((ehyb_ell_kernel<T, D, false, F>), dim3(n_items), dim3(T), lds, st, ELL_ARGS(P, x, y), \
+                       (unsigned long long*)nullptr);
+#define ELL_LAUNCH(T)                                 \
+    if (dyn && fuse) { ELL_LAUNCH_DF(T, true, true) } \
+    else if (dyn) { ELL_LAUNCH_DF(T, true, false) }   \
+    else if (fuse) { ELL_LAUNCH_DF(T, false, true) }  \
+    else { ELL_LAUNCH_DF(T, false, false) }
     switch (P->cfg.threads) {
         case 256: ELL_LAUNCH(256) break;
         case 512: ELL_LAUNCH(512) break;
@@ -410,8 +256,7 @@ static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st, 
         default: EHYB_FAIL(EHYB_ERR_ARG, "ELL workgroup size %d not built (256/512/1024)", P->cfg.threads);
     }
 #undef ELL_LAUNCH
-#undef ELL_LAUNCH_F
-#undef ELL_ARGS
+#undef ELL_LAUNCH_DF
     HIP_TRY(hipGetLastError());
     return EHYB_OK;
 }
@@ -453,24 +298,13 @@ static int upload(T** dst, const std::vector<T>& src)
 
 static void free_device(ehyb_plan* P)
 {
-    void* ptrs[] = {P->d_lane_group,    P->d_slab_meta,
-                    P->d_part_boundary, P->d_win_len,     P->d_halo_ptr,  P->d_halo_cols, P->d_slab_pair_ptr,
-                    P->d_slab_row,      P->d_ell_val,     P->d_ell_col,   P->d_items,     P->d_er_seg_ptr,
-                    P->d_er_seg_row,    P->d_er_col,      P->d_er_val};
-    for (void* q : ptrs)
-        if (q) (void)hipFree(q);
-    P->d_part_boundary = P->d_win_len = P->d_halo_ptr = P->d_halo_cols = nullptr;
-    P->d_slab_pair_ptr = nullptr;
-    P->d_slab_row = P->d_items = P->d_er_seg_row = P->d_er_col = nullptr;
-    P->d_ell_val = P->d_er_val = nullptr;
-    if (P->d_er_blocks) (void)hipFree(P->d_er_blocks);
-    P->d_er_blocks = nullptr;
-    if (P->d_item_part) (void)hipFree(P->d_item_part);
-    P->d_item_part = nullptr;
-    P->d_ell_col = nullptr;
-    P->d_lane_group = nullptr;
-    P->d_slab_meta = nullptr;
-    P->d_er_seg_ptr = nullptr;
+    void** ptrs[] = {(void**)&P->d_halo_cols,  (void**)&P->d_ell_val,   (void**)&P->d_ell_col,    (void**)&P->d_lane_group,
+                     (void**)&P->d_slab_meta,  (void**)&P->d_items,     (void**)&P->d_segs,       (void**)&P->d_er_seg_ptr,
+                     (void**)&P->d_er_seg_row, (void**)&P->d_er_col,    (void**)&P->d_er_val,     (void**)&P->d_er_blocks};
+    for (void** q : ptrs) {
+        if (*q) (void)hipFree(*q);
+        *q = nullptr;
+    }
     P->uploaded = false;
 }
 
@@ -561,24 +395,25 @@ int ehyb_measure_read_bw(size_t bytes, int iters, double* gbps)
     return EHYB_OK;
 }
 
-// Diagnostic (tools/stamps.py): one launch of the stamped instantiation of the simple ELL kernel.
+// Diagnostic (tools/stamps.py): one launch of the stamped instantiation of the ELL kernel.
 // out[4*i + {0,1,2,3}] = entry / staged / exit wall-clock ticks (100 MHz) and XCC id of item i.
 int ehyb_debug_ell_stamps(ehyb_plan* P, const double* x, double* y, unsigned long long* out_host)
 {
     if (!P || !P->uploaded || !out_host) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_debug_ell_stamps: bad arguments");
     const HostLayout& H = P->host;
     const int n_items = (int)(H.items.size() / 8);
-    const size_t lds = (((size_t)H.lds_doubles * 8) + 15) / 16 * 16;
+    const size_t lds = ell_lds_bytes(H);
+    const bool dyn = P->cfg.ell_variant != 3;
     unsigned long long* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, (size_t)n_items * 32));
     HIP_TRY(hipMemset(d, 0, (size_t)n_items * 32));
-#define STAMP_LAUNCH(T)                                                                                          \
-    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<T, true>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)lds));                                                                        \
-    hipLaunchKernelGGL((ehyb_ell_kernel<T, true>), dim3(n_items), dim3(T), lds, 0, (const int4*)P->d_items,        \
-                       P->d_part_boundary, P->d_win_len, P->d_halo_ptr, P->d_halo_cols,                           \
-                       (const uint4*)P->d_slab_meta, P->d_lane_group, (const double2*)P->d_ell_val, P->d_ell_col, \
-                       x, y, P->d_er_seg_ptr, P->d_er_seg_row, P->d_er_col, P->d_er_val, d);
+#define STAMP_LAUNCH_D(T, D)                                                                                      \
+    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<T, D, true, false>,                                  \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
+    hipLaunchKernelGGL((ehyb_ell_kernel<T, D, true, false>), dim3(n_items), dim3(T), lds, 0, ELL_ARGS(P, x, y), d);
+#define STAMP_LAUNCH(T)                    \
+    if (dyn) { STAMP_LAUNCH_D(T, true) }   \
+    else { STAMP_LAUNCH_D(T, false) }
     switch (P->cfg.threads) {
         case 256: STAMP_LAUNCH(256) break;
         case 512: STAMP_LAUNCH(512) break;
@@ -586,6 +421,7 @@ int ehyb_debug_ell_stamps(ehyb_plan* P, const double* x, double* y, unsigned lon
         default: EHYB_FAIL(EHYB_ERR_ARG, "workgroup size %d not built", P->cfg.threads);
     }
 #undef STAMP_LAUNCH
+#undef STAMP_LAUNCH_D
     HIP_TRY(hipGetLastError());
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out_host, d, (size_t)n_items * 32, hipMemcpyDeviceToHost));
@@ -609,51 +445,27 @@ int ehyb_plan_upload(ehyb_plan* P)
         free_device(P);                        \
         return rc;                             \
     }
-    UP(d_part_boundary, part_boundary)
-    UP(d_win_len, win_len)
-    UP(d_halo_ptr, halo_ptr)
     UP(d_halo_cols, halo_cols)
-    UP(d_slab_pair_ptr, slab_pair_ptr)
-    UP(d_slab_row, slab_row)
     UP(d_ell_val, ell_val)
     UP(d_ell_col, ell_col)
     UP(d_lane_group, lane_group)
     UP(d_slab_meta, slab_meta)
     UP(d_items, items)
+    UP(d_segs, segs)
     UP(d_er_seg_ptr, er_seg_ptr)
     UP(d_er_seg_row, er_seg_row)
     UP(d_er_col, er_col)
     UP(d_er_val, er_val)
     UP(d_er_blocks, er_blocks)
-    {
-        // partition scalars per work item {first row, end row, contiguous window length, halo start}, {halo count}
-        std::vector<int32_t> ip(H.items.size());
-        for (size_t it = 0; it < H.items.size() / 8; ++it) {
-            const int p = H.items[8 * it];
-            ip[8 * it + 0] = H.part_boundary[p];
-            ip[8 * it + 1] = H.part_boundary[p + 1];
-            ip[8 * it + 2] = H.win_len[p];
-            ip[8 * it + 3] = H.halo_ptr[p];
-            ip[8 * it + 4] = H.halo_ptr[p + 1] - H.halo_ptr[p];
-        }
-        if ((rc = upload(&P->d_item_part, ip)) != EHYB_OK) {
-            free_device(P);
-            return rc;
-        }
-    }
 #undef UP
     // opt in to the full 160 KiB of LDS (the role of cudaFuncSetAttribute at kernel.cu:351,411)
-    const int lds = (int)((((size_t)H.lds_doubles * 8) + 15) / 16 * 16);
+    const int lds = (int)ell_lds_bytes(H);
 #define LDS_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-#define LDS_ATTR_T(T)                                     \
-    LDS_ATTR((ehyb_ell_kernel<T, false, false, false>))   \
-    LDS_ATTR((ehyb_ell_kernel<T, false, false, true>))    \
-    LDS_ATTR((ehyb_ell_kernel<T, false, true, false>))    \
-    LDS_ATTR((ehyb_ell_kernel<T, false, true, true>))     \
-    LDS_ATTR((ehyb_ell_kernel<T, false, true, false, true>)) \
-    LDS_ATTR((ehyb_ell_kernel<T, false, true, true, true>))  \
-    LDS_ATTR((ehyb_ell_kernel_pipe<T, false>))            \
-    LDS_ATTR((ehyb_ell_kernel_pipe<T, true>))
+#define LDS_ATTR_T(T)                                    \
+    LDS_ATTR((ehyb_ell_kernel<T, true, false, false>))   \
+    LDS_ATTR((ehyb_ell_kernel<T, true, false, true>))    \
+    LDS_ATTR((ehyb_ell_kernel<T, false, false, false>))  \
+    LDS_ATTR((ehyb_ell_kernel<T, false, false, true>))
     LDS_ATTR_T(256)
     LDS_ATTR_T(512)
     LDS_ATTR_T(1024)

@@ -78,8 +78,11 @@ struct HostLayout {
     std::vector<uint8_t> lane_group;     // [n_slabs*64]
     std::vector<uint32_t> slab_meta;     // [n_slabs*4] {pair_ptr, col_ptr, first row, pairs<<8 | groups-1}
 
-    // work items {part, slab_begin, slab_end, 0, er_begin, er_b64, er_b16, er_end}
+    // work items {seg_begin, seg_end, slab_begin, slab_end, er_begin, er_b64, er_b16, er_end}: a run of
+    // slabs of (nearly) equal cost; it is cut into segments where it crosses a partition boundary
     std::vector<int32_t> items;
+    // segments {partition, slab_begin, slab_end, halo_count, first row, end row, win_len, halo_begin}
+    std::vector<int32_t> segs;
 
     // residual (CSR segments sorted by length, descending)
     std::vector<int64_t> er_seg_ptr;  // [n_seg+1]
@@ -128,13 +131,9 @@ struct ehyb_plan {
     ehyb::HostLayout host;
     bool uploaded = false;
     int device = -1;
-    // device arrays (same names as HostLayout)
-    int32_t* d_part_boundary = nullptr;
-    int32_t* d_win_len = nullptr;
-    int32_t* d_halo_ptr = nullptr;
+    // device arrays (same names as HostLayout; what the kernels do not read stays on the host)
     int32_t* d_halo_cols = nullptr;
-    uint32_t* d_slab_pair_ptr = nullptr;
-    int32_t* d_slab_row = nullptr;
+    int32_t* d_segs = nullptr;
     double* d_ell_val = nullptr;
     uint32_t* d_ell_col = nullptr;
     uint8_t* d_lane_group = nullptr;
@@ -145,5 +144,4 @@ struct ehyb_plan {
     int32_t* d_er_col = nullptr;
     double* d_er_val = nullptr;
     int32_t* d_er_blocks = nullptr;
-    int32_t* d_item_part = nullptr;  // per item {ps, pe, win_len, halo_begin}, {halo_count}
 };

@@ -60,7 +60,9 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         if (rp[i + 1] < rp[i]) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: rowIdx not monotone at row %d", i);
     if (cfg.host_threads > 0) omp_set_num_threads(cfg.host_threads);
 
-    const int lds = cfg.lds_doubles;
+    // Window capacity: two doubles of the LDS budget hold the slab counter of the ELL kernel, so a
+    // 10,240-double budget is exactly 80 KiB and two workgroups still fit one CU's 160 KiB.
+    const int lds = std::max(kSlabRows, cfg.lds_doubles - 2);
     const bool halo_mode = cfg.window_mode == EHYB_WINDOW_HALO;
 
     // ---- partitions: the caller's, cut down to the window capacity where needed
@@ -377,60 +379,52 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             const int64_t words = L->slab_col_ptr[sidx + 1] - L->slab_col_ptr[sidx];
             return pairs * (kSlabRows * 16) + words * 4 + slab_er[sidx] * 40 + 1024;
         };
-        int64_t total = 0;
-        std::vector<int64_t> pcost(np, 0);
-        for (int p = 0; p < np; ++p) {
-            for (int64_t sidx = slab_base[p]; sidx < slab_base[p + 1]; ++sidx) pcost[p] += slab_cost(sidx);
-            total += pcost[p];
-        }
-        // The grid must not exceed `want` = items_per_cu x 256 work items: with 2 workgroups resident
-        // per CU, 512 items run as one wave of workgroups but 513 need a second one (measured: 537
-        // items took 158 us where 507 took 136 us).  Pieces per partition k_p = round(cost_p/target),
-        // with the smallest target whose total stays within `want` (bisection; the count is monotone).
+        // Work items: the global slab sequence cut into `want` = items_per_cu x 256 runs of equal cost
+        // (2 workgroups are resident per CU, so 512 items are exactly one wave of workgroups; 513
+        // would need a second one -- measured 158 us vs 136 us).  A run that crosses a partition
+        // boundary becomes several segments, each with its own window.  Cuts within `snap` slabs of
+        // a partition boundary move onto it: a window staged for a handful of slabs is wasted.
+        // Inside a workgroup the waves take slabs from an LDS counter, so only the byte count of an
+        // item matters, not how its slab count divides by the number of waves.
+        std::vector<int64_t> prefix(nslabs + 1, 0);
+        for (int64_t sidx = 0; sidx < nslabs; ++sidx) prefix[sidx + 1] = prefix[sidx] + slab_cost(sidx);
+        const int64_t total = prefix[nslabs];
         const int64_t want = std::max<int64_t>(1, (int64_t)cfg.items_per_cu * kNumCU);
-        const int waves = cfg.threads / 64;
-        auto pieces = [&](int p, int64_t target) {
-            int64_t ns = slab_base[p + 1] - slab_base[p];
-            if (ns == 0) return (int64_t)0;
-            int64_t k = std::max<int64_t>(1, (pcost[p] + target / 2) / target);
-            return std::min(k, std::max<int64_t>(1, ns / waves));  // at least one slab per wave
-        };
-        auto count = [&](int64_t target) {
-            int64_t c = 0;
-            for (int p = 0; p < np; ++p) c += pieces(p, target);
-            return c;
-        };
-        int64_t lo = std::max<int64_t>(1, total / want / 2), hi = std::max<int64_t>(lo, total);
-        while (count(hi) > want && hi < (int64_t)4e18 / 2) hi *= 2;  // more partitions than `want`: one item each
-        while (lo < hi) {
-            int64_t mid = lo + (hi - lo) / 2;
-            if (count(mid) <= want)
-                hi = mid;
-            else
-                lo = mid + 1;
-        }
-        const int64_t target = hi;
-        L->items.clear();
-        int64_t window_loads = 0;
-        for (int p = 0; p < np; ++p) {
-            int64_t ns = slab_base[p + 1] - slab_base[p];
-            if (ns == 0) continue;
-            int64_t k = pieces(p, target);
-            int64_t sidx = slab_base[p];
-            int64_t acc = 0;
-            for (int64_t q = 0; q < k; ++q) {
-                int64_t stop = pcost[p] * (q + 1) / k;
-                int64_t beg = sidx;
-                while (sidx < slab_base[p + 1] && (acc < stop || sidx == beg)) acc += slab_cost(sidx++);
-                if (q == k - 1) sidx = slab_base[p + 1];
-                if (sidx > beg) {
-                    const int32_t item = (int32_t)(L->items.size() / 8);
-                    for (int64_t t = beg; t < sidx; ++t) item_of_slab[t] = item;
-                    const int32_t rec[8] = {p, (int32_t)beg, (int32_t)sidx, 0, 0, 0, 0, 0};
-                    L->items.insert(L->items.end(), rec, rec + 8);
-                    window_loads += L->win_len[p] + (L->halo_ptr[p + 1] - L->halo_ptr[p]);
-                }
+        const int64_t snap = 5;
+        std::vector<int64_t> cuts;
+        cuts.push_back(0);
+        for (int64_t i = 1; i < want && nslabs > 0; ++i) {
+            const int64_t goal = total / want * i + total % want * i / want;
+            int64_t c = std::lower_bound(prefix.begin(), prefix.end(), goal) - prefix.begin();
+            c = std::min<int64_t>(c, nslabs);
+            if (c < nslabs) {
+                const int p = L->slab_part[c];
+                if (c - slab_base[p] < snap)
+                    c = slab_base[p];
+                else if (slab_base[p + 1] - c < snap)
+                    c = slab_base[p + 1];
             }
+            if (c > cuts.back() && c < nslabs) cuts.push_back(c);
+        }
+        if (nslabs > 0) cuts.push_back(nslabs);
+        L->items.clear();
+        L->segs.clear();
+        int64_t window_loads = 0;
+        for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+            const int32_t item = (int32_t)i;
+            const int32_t seg_begin = (int32_t)(L->segs.size() / 8);
+            for (int64_t c = cuts[i]; c < cuts[i + 1];) {
+                const int p = L->slab_part[c];
+                const int64_t e = std::min<int64_t>(cuts[i + 1], slab_base[p + 1]);
+                const int32_t hb = L->halo_ptr[p], hn = L->halo_ptr[p + 1] - L->halo_ptr[p];
+                const int32_t seg[8] = {p, (int32_t)c, (int32_t)e, hn, pb[p], pb[p + 1], L->win_len[p], hb};
+                L->segs.insert(L->segs.end(), seg, seg + 8);
+                window_loads += L->win_len[p] + hn;
+                for (int64_t t = c; t < e; ++t) item_of_slab[t] = item;
+                c = e;
+            }
+            const int32_t rec[8] = {seg_begin, (int32_t)(L->segs.size() / 8), (int32_t)cuts[i], (int32_t)cuts[i + 1], 0, 0, 0, 0};
+            L->items.insert(L->items.end(), rec, rec + 8);
         }
         L->stats.window_loads = window_loads;
     }
@@ -533,10 +527,10 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     st.lds_bytes = (int64_t)L->lds_doubles * 8;
     st.bytes_alg = 12 * nnz + 4 * ((int64_t)nrows + 1) + 8 * (int64_t)n + 8 * (int64_t)nrows;
     int64_t halo_item_loads = st.window_loads;
-    for (size_t it = 0; it < L->items.size(); it += 8) halo_item_loads -= L->win_len[L->items[it]];
+    for (size_t sg = 0; sg < L->segs.size(); sg += 8) halo_item_loads -= L->segs[sg + 6];
     st.col_words = col_words;
     // values 8 B/element, shared column words 4 B, per slab a 16-byte record + 64-byte lane map
-    st.bytes_format = 8 * size_ell + 4 * col_words + 80 * nslabs + 32 * st.n_items + 8 * st.window_loads +
+    st.bytes_format = 8 * size_ell + 4 * col_words + 80 * nslabs + 32 * st.n_items + 32 * (int64_t)(L->segs.size() / 8) + 8 * st.window_loads +
                       4 * halo_item_loads + 8 * (int64_t)nrows + 12 * nnz_er + 12 * nseg + 16 * nseg;
     if (nnz_ell + nnz_er != nnz) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: %lld + %lld != %lld", (long long)nnz_ell, (long long)nnz_er, (long long)nnz);
     if (cfg.verbose) {

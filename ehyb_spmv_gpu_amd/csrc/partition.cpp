@@ -476,8 +476,10 @@ int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vw
         // 64-row slabs (so block-structured inputs keep their alignment: config 3's 1024-row blocks
         // stay inside one window); weighted: equal-weight blocks.
         if (!vwgt) {
-            int64_t chunk = (((int64_t)n + nparts - 1) / nparts + kSlabRows - 1) / kSlabRows * kSlabRows;
-            if (chunk > cap) chunk = cap;
+            // fill every block to the cap (rounded down to whole slabs): block-structured inputs whose
+            // block size divides the cap keep whole blocks inside one window
+            int64_t chunk = cap >= kSlabRows ? cap / kSlabRows * kSlabRows : cap;
+            if (chunk * nparts < n) chunk = cap;
             for (int v = 0; v < n; ++v) part[v] = (int)std::min<int64_t>(v / chunk, nparts - 1);
             int64_t last = n - chunk * (nparts - 1);
             if (last > cap) {  // rounding down to the cap left too much for the last block: spread evenly

@@ -216,7 +216,7 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
                     }
                     std::vector<int> offenders;
                     for (int p = 0; p < nparts; ++p)
-                        if (demand[p] > c.lds_doubles && demand[p] <= c.lds_doubles * 3 / 2 && own[p] >= 4 * kSlabRows)
+                        if (demand[p] > c.lds_doubles - 2 && demand[p] <= c.lds_doubles * 3 / 2 && own[p] >= 4 * kSlabRows)
                             offenders.push_back(p);
                     if (offenders.empty()) break;
                     if (c.verbose) printf("capacity split round %d: %zu of %d partitions overflow the window\n", round, offenders.size(), nparts);
@@ -292,7 +292,7 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
 #pragma omp for schedule(dynamic, 4)
             for (int p = 0; p < nparts; ++p) {
                 const int own = pb[p + 1] - pb[p];
-                const int hcap = c.lds_doubles - own - (pb[p] & 1);
+                const int hcap = c.lds_doubles - 2 - own - (pb[p] & 1);  // 2 doubles hold the kernel's slab counter
                 if (hcap <= 0) continue;
                 cand.clear();
                 for (int q = pb[p]; q < pb[p + 1]; ++q) {

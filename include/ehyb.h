@@ -197,9 +197,10 @@ enum {
     EHYB_ARR_ELL_VAL       = 7, /* double [size_block_ell]  [pair][lane][2]                   */
     EHYB_ARR_ELL_COL       = 8, /* uint32 [col_words] two 16-bit window-local columns per word:
                                    word (pair k, group g) of slab s at SLAB_COL_PTR[s] + k*G_s + g  */
-    EHYB_ARR_ITEMS         = 9, /* int32  [n_items*8]  {partition, slab_begin, slab_end, 0, er_begin,
-                                   er_end_len>=128, er_end_len>16, er_end}: the residual segments of
-                                   the item's rows, longest first                                   */
+    EHYB_ARR_ITEMS         = 9, /* int32  [n_items*8]  one workgroup's work: {seg_begin, seg_end, slab_begin,
+                                   slab_end, er_begin, er_end_len>=128, er_end_len>16, er_end} -- a run
+                                   of slabs of equal cost (cut into SEGS at partition boundaries) and
+                                   the residual segments of its rows, longest first                 */
     EHYB_ARR_ER_SEG_PTR    = 10,/* int64  [er_segments+1]                                     */
     EHYB_ARR_ER_SEG_ROW    = 11,/* int32  [er_segments] bit31 set: row has several segments   */
     EHYB_ARR_ER_COL        = 12,/* int32  [size_er]    global column                          */
@@ -207,7 +208,9 @@ enum {
     EHYB_ARR_ER_BINS       = 14,/* int32  [8]  {0, -, -, er_segments, ...}                        */
     EHYB_ARR_SLAB_COL_PTR  = 15,/* uint32 [n_slabs+1]  prefix of pairs * groups               */
     EHYB_ARR_LANE_GROUP    = 16,/* uint8  [n_slabs*64] column-list group of every lane        */
-    EHYB_ARR_SLAB_META     = 17 /* uint32 [n_slabs*4]  {pair_ptr, col_ptr, row, pairs<<8|G-1}: what the kernel reads */
+    EHYB_ARR_SLAB_META     = 17,/* uint32 [n_slabs*4]  {pair_ptr, col_ptr, row, pairs<<8|G-1}: what the kernel reads */
+    EHYB_ARR_SEGS          = 18 /* int32  [n_segs*8]   {partition, slab_begin, slab_end, halo_count, first row,
+                                   end row, win_len, halo_begin}: one LDS window staging each       */
 };
 int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int64_t* count);
 

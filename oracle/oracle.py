@@ -161,11 +161,18 @@ def walk_plan(plan, x):
     lane_group = plan.array("lane_group").astype(np.int64).reshape(-1, 64)
     meta = plan.array("slab_meta").astype(np.int64).reshape(-1, 4)
     items = plan.array("items").reshape(-1, 8)
+    segs = plan.array("segs").reshape(-1, 8)
+    slab_part = plan.array("slab_part")
     written = np.zeros(n, dtype=np.int32)
     seg_ptr = plan.array("er_seg_ptr")
     seg_row = plan.array("er_seg_row")
     seg_done = np.zeros(len(seg_row), dtype=np.int32)
-    for p, s0, s1, _, e0, e64, e16, e1 in items:
+    next_seg, next_slab = 0, 0
+    for g0, g1, is0, is1, e0, e64, e16, e1 in items:
+        # an item = consecutive segments covering the consecutive slabs [is0, is1)
+        assert g0 == next_seg and g1 > g0 and is0 == next_slab and is1 > is0
+        assert segs[g0, 1] == is0 and segs[g1 - 1, 2] == is1
+        next_seg, next_slab = g1, is1
         # the item's residual segments: rows inside the item's slab range, bins by length
         assert e0 <= e64 <= e16 <= e1
         if e1 > e0:
@@ -173,29 +180,35 @@ def walk_plan(plan, x):
             assert np.all(lens[:e64 - e0] >= 128) and np.all((lens[e64 - e0:e16 - e0] > 16) & (lens[e64 - e0:e16 - e0] < 128))
             assert np.all(lens[e16 - e0:] <= 16) and np.all(lens >= 1)
             rows = seg_row[e0:e1] & 0x7FFFFFFF
-            assert rows.min() >= slab_row[s0] and rows.max() < min(int(slab_row[s1 - 1]) + 64, int(pb[p + 1]))
+            last_p = segs[g1 - 1, 0]
+            assert rows.min() >= slab_row[is0] and rows.max() < min(int(slab_row[is1 - 1]) + 64, int(pb[last_p + 1]))
             seg_done[e0:e1] += 1
-        ps, pe = int(pb[p]), int(pb[p + 1])
-        wl = int(win_len[p])
-        base = ps & ~1  # the LDS image starts at the even row at or below the partition start
-        win = np.concatenate([x[base:ps + wl], x[halo_cols[halo_ptr[p]:halo_ptr[p + 1]]]])
-        for s in range(s0, s1):
-            p0, p1 = spp[s], spp[s + 1]
-            acc = np.zeros(64, dtype=np.float64)
-            # the 16-byte record the kernel reads must agree with the prefix arrays
-            assert meta[s, 0] == p0 and meta[s, 1] == scp[s] and meta[s, 2] == slab_row[s] and meta[s, 3] >> 8 == p1 - p0
-            if p1 > p0:
-                G = int(meta[s, 3] & 0xFF) + 1
-                assert (scp[s + 1] - scp[s]) == (p1 - p0) * G
-                v = ell_val[p0 * 128:p1 * 128].reshape(p1 - p0, 64, 2)
-                words = ell_col[scp[s]:scp[s + 1]].reshape(p1 - p0, G)[:, lane_group[s]]  # [pair][lane]
-                c = np.stack([words & 0xFFFF, words >> 16], axis=2)
-                assert c.max() < len(win), "window-local column outside the window"
-                acc = (v * win[c]).sum(axis=(0, 2))
-            r0 = int(slab_row[s])
-            cnt = min(64, pe - r0)
-            y[r0:r0 + cnt] = acc[:cnt]
-            written[r0:r0 + cnt] += 1
+        for g in range(g0, g1):
+            p, s0, s1, hn, ps, pe, wl, hb = (int(v) for v in segs[g])
+            if g > g0:
+                assert s0 == segs[g - 1, 2] and p > segs[g - 1, 0], "segments of an item are consecutive and cut at partition boundaries"
+            assert np.all(slab_part[s0:s1] == p) and s1 > s0
+            # the partition scalars carried by the segment record are the partition arrays' values
+            assert (ps, pe, wl, hb, hn) == (int(pb[p]), int(pb[p + 1]), int(win_len[p]), int(halo_ptr[p]), int(halo_ptr[p + 1] - halo_ptr[p]))
+            base = ps & ~1  # the LDS image starts at the even row at or below the partition start
+            win = np.concatenate([x[base:ps + wl], x[halo_cols[hb:hb + hn]]])
+            for s in range(s0, s1):
+                p0, p1 = spp[s], spp[s + 1]
+                acc = np.zeros(64, dtype=np.float64)
+                # the 16-byte record the kernel reads must agree with the prefix arrays
+                assert meta[s, 0] == p0 and meta[s, 1] == scp[s] and meta[s, 2] == slab_row[s] and meta[s, 3] >> 8 == p1 - p0
+                if p1 > p0:
+                    G = int(meta[s, 3] & 0xFF) + 1
+                    assert (scp[s + 1] - scp[s]) == (p1 - p0) * G
+                    v = ell_val[p0 * 128:p1 * 128].reshape(p1 - p0, 64, 2)
+                    words = ell_col[scp[s]:scp[s + 1]].reshape(p1 - p0, G)[:, lane_group[s]]  # [pair][lane]
+                    c = np.stack([words & 0xFFFF, words >> 16], axis=2)
+                    assert c.max() < len(win), "window-local column outside the window"
+                    acc = (v * win[c]).sum(axis=(0, 2))
+                r0 = int(slab_row[s])
+                cnt = min(64, pe - r0)
+                y[r0:r0 + cnt] = acc[:cnt]
+                written[r0:r0 + cnt] += 1
     er_col = plan.array("er_col")
     er_val = plan.array("er_val")
     assert np.all(seg_done == 1), "every residual segment belongs to exactly one work item"

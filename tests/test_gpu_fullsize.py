@@ -46,7 +46,8 @@ def test_config2_audikw_like_full(E, O, gpu):
 def test_config3_banded_4m_pure_ell(E, O, gpu):
     """4,194,304 rows x 32 entries, block-circulant band: zero residual, zero padding -- the input the
     reference rejects (convert.c:136-139) and cannot size (int16 window, solver_test.c:160)."""
-    cfg = E.make_config(window_mode=1, lds_doubles=20480, partitioner=E.EHYB_PART_CONTIGUOUS)
+    # 19 x 1024 rows per partition: whole 1024-row blocks, inside the 20,478-double window
+    cfg = E.make_config(window_mode=1, lds_doubles=20480, part_rows=19456, partitioner=E.EHYB_PART_CONTIGUOUS)
     c = Case(E, O, "banded", (1 << 22, 32, 1024), cfg)
     assert c.nnz == 134217728
     plan = E.Plan(c.m, cfg)

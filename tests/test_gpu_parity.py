@@ -82,7 +82,7 @@ def test_long_rows_split_with_atomics(E, O, gpu):
 
 def test_empty_residual(E, O, gpu):
     """Pure ELL (config 3's shape): the reference exit(0)s here (convert.c:136-139)."""
-    cfg = E.make_config(window_mode=1, lds_doubles=4096, partitioner=E.EHYB_PART_CONTIGUOUS)
+    cfg = E.make_config(window_mode=1, lds_doubles=4096, part_rows=3072, partitioner=E.EHYB_PART_CONTIGUOUS)
     c = Case(E, O, "banded", (1 << 15, 32, 1024), cfg)
     plan = E.Plan(c.m, cfg)
     st = plan.stats

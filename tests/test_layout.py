@@ -101,18 +101,23 @@ def test_structural_invariants(E, O, mode):
     bins = plan.array("er_bins")
     assert bins[0] == 0 and bins[3] == len(seg_row)
     items = plan.array("items").reshape(-1, 8)
+    segs = plan.array("segs").reshape(-1, 8)
     covered = np.zeros(len(srow), dtype=int)
     nxt = 0
-    for p, s0, s1, _, e0, e64, e16, e1 in items:
-        assert s0 < s1 and np.all(spart[s0:s1] == p)
-        covered[s0:s1] += 1
-        assert e0 == nxt and e0 <= e64 <= e16 <= e1                              # segments grouped by item
+    cost = []
+    for g0, g1, s0, s1, e0, e64, e16, e1 in items:
+        assert s0 < s1 and g0 < g1 and segs[g0, 1] == s0 and segs[g1 - 1, 2] == s1
+        for p, a, b, hn, ps, pe, wlen, hb in segs[g0:g1]:
+            assert np.all(spart[a:b] == p) and (ps, pe) == (pb[p], pb[p + 1])
+            covered[a:b] += 1
+        assert e0 == nxt and e0 <= e64 <= e16 <= e1                              # residual segments grouped by item
         lens = np.diff(seg_ptr[e0:e1 + 1])
         assert np.all(np.diff(lens) <= 0), "longest first inside an item"
         nxt = e1
+        cost.append(int(spp[s1] - spp[s0]))
     assert nxt == len(seg_row)
     assert np.all(covered == 1), "work items tile the slabs exactly once"
-    assert len(items) <= max(cfg.items_per_cu * 256, st["n_parts"]), "the grid never exceeds the resident-slot budget"
+    assert len(items) <= cfg.items_per_cu * 256, "the grid never exceeds the resident-slot budget"
     del A
 
 
@@ -155,7 +160,8 @@ def test_reference_window_rule_matches_restated_convert(E, O, seed):
             cols.append(j)
     A = sp.coo_matrix((rng.uniform(-1, 1, len(rows)), (rows, cols)), shape=(n, n)).tocsr()
     A.sort_indices()
-    cfg = E.make_config(window_mode=1, lds_doubles=cache, hub_rule=2)  # the reference has no working long-row rule
+    # the reference has no working long-row rule; 2 doubles of the LDS budget hold the slab counter
+    cfg = E.make_config(window_mode=1, lds_doubles=cache + 2, hub_rule=2)
     m = E.Matrix.from_csr(A.indptr, A.indices, A.data, cfg)
     pb = np.arange(0, n + 1, size, dtype=np.int32)
     m.c.nParts = len(pb) - 1

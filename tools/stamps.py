@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--part-rows", type=int, default=0)
     ap.add_argument("--threads", type=int, default=1024)
     ap.add_argument("--items", type=int, default=2)
+    ap.add_argument("--variant", type=int, default=0, help="0/5 dynamic slab hand-out, 3 static round-robin")
     args = ap.parse_args()
     import numpy as np
 
@@ -34,7 +35,7 @@ def main():
         print(f"streaming read of {mb} MiB: {bw.value:.0f} GB/s")
 
     gen, gargs, _ = B.WORKLOADS[args.workload]
-    kw = dict(lds_doubles=args.lds, threads=args.threads, items_per_cu=args.items, ell_variant=1)
+    kw = dict(lds_doubles=args.lds, threads=args.threads, items_per_cu=args.items, ell_variant=args.variant)
     if args.part_rows:
         kw["part_rows"] = args.part_rows
     cfg = E.make_config(**kw)
@@ -60,7 +61,7 @@ def main():
     start, staged, end, xcc = (s[:, 0] - t0) / 100.0, (s[:, 1] - t0) / 100.0, (s[:, 2] - t0) / 100.0, s[:, 3]
     items = plan.array("items").reshape(-1, 8)
     spp = plan.array("slab_pair_ptr").astype(np.int64)
-    pairs = spp[items[:, 2]] - spp[items[:, 1]]
+    pairs = spp[items[:, 3]] - spp[items[:, 2]]
     print(f"items {n_items}  kernel span {end.max():.1f} us")
     print(f"start   : min {start.min():.1f} med {np.median(start):.1f} max {start.max():.1f} us")
     print(f"staging : min {(staged - start).min():.1f} med {np.median(staged - start):.1f} max {(staged - start).max():.1f} us")
@@ -74,7 +75,7 @@ def main():
             print(f"  xcc {xc}: {sel.sum():4d} WGs, end med {np.median(end[sel]):.1f} max {end[sel].max():.1f} us, bytes {pairs[sel].sum() * 64 * 20 / 1e6:.1f} MB")
     late = np.argsort(-end)[:8]
     for i in late:
-        print(f"  late item {i}: part {items[i, 0]} slabs {items[i, 2] - items[i, 1]} pairs {pairs[i]} start {start[i]:.1f} staged {staged[i]:.1f} end {end[i]:.1f} xcc {xcc[i]}")
+        print(f"  late item {i}: segments {items[i, 1] - items[i, 0]} slabs {items[i, 3] - items[i, 2]} pairs {pairs[i]} start {start[i]:.1f} staged {staged[i]:.1f} end {end[i]:.1f} xcc {xcc[i]}")
 
 
 if __name__ == "__main__":
