@@ -61,11 +61,12 @@ _STAT_NAMES = [
     "nnz", "nnz_ell", "nnz_er", "ell_padding", "size_block_ell", "size_er", "rows_er",
     "er_segments", "n_rows", "n_cols", "n_parts", "n_slabs", "n_items", "halo_cols",
     "window_loads", "bytes_format", "bytes_alg", "max_row", "lds_bytes", "col_words",
+    "er_inline",
 ]
 
 
 class Stats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in _STAT_NAMES] + [("reserved", C.c_int64 * 4)]
+    _fields_ = [(n, C.c_int64) for n in _STAT_NAMES] + [("reserved", C.c_int64 * 3)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n in _STAT_NAMES}

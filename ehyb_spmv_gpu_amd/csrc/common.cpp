@@ -52,7 +52,7 @@ Config resolve_config(const ehyb_config* in)
     c.seed = z.seed;
     c.n_top = z.n_top > 1 ? z.n_top : 1;
     c.er_threads = z.er_threads > 0 ? std::min(1024, std::max(64, round_down(z.er_threads, 64))) : 256;
-    c.ell_variant = z.ell_variant > 0 ? z.ell_variant : 3;
+    c.ell_variant = z.ell_variant == 3 ? 3 : 1;
     c.col_sharing = z.col_sharing == 2 ? 2 : 1;
     // measured (tools/sweep.py --fuse 1,2): the fused tail saves ~1 % at best on the bench matrix and
     // loses badly on residual-heavy inputs, where the flat residual kernel has far more parallelism

@@ -86,109 +86,131 @@ __device__ __forceinline__ void er_bin(int lo, int hi, const int64_t* __restrict
     }
 }
 
-template <int THREADS>
-__device__ __forceinline__ void er_item(const int4 er, const int64_t* __restrict__ seg_ptr,
-                                        const int* __restrict__ seg_row, const int* __restrict__ col,
-                                        const double* __restrict__ val, const double* __restrict__ x,
-                                        double* __restrict__ y)
-{
-    er_bin<64, THREADS>(er.x, er.y, seg_ptr, seg_row, col, val, x, y);
-    er_bin<16, THREADS>(er.y, er.z, seg_ptr, seg_row, col, val, x, y);
-    er_bin<4, THREADS>(er.z, er.w, seg_ptr, seg_row, col, val, x, y);
-}
-
 // ------------------------------------------------------------------ ELL kernel
 // items[2b]   = {first segment, end segment, -, -}      items[2b+1] = residual bins of the item
 // segs[2g]    = {partition, first slab, end slab, halo count}
 // segs[2g+1]  = {first row, end row, contiguous window length, halo start}
-// DYN:   waves take slabs from the LDS counter (false: static round-robin, the A/B arm).
-// STAMP: diagnostic instantiation (tools/stamps.py only): thread 0 records the 100 MHz wall
-//        clock at entry, after the first staging and at exit into a buffer of its own.
-template <int THREADS, bool DYN, bool STAMP, bool FUSE_ER>
-__global__ __launch_bounds__(THREADS) void ehyb_ell_kernel(
-    const int4* __restrict__ items, const int4* __restrict__ segs, const int* __restrict__ halo_cols,
-    const uint4* __restrict__ slab_meta, const uint8_t* __restrict__ lane_group,
-    const double2* __restrict__ ell_val, const uint32_t* __restrict__ ell_col, const double* __restrict__ x,
-    double* __restrict__ y, const int64_t* __restrict__ er_seg_ptr, const int* __restrict__ er_seg_row,
-    const int* __restrict__ er_col, const double* __restrict__ er_val, int win_cap,
-    unsigned long long* __restrict__ stamps)
+// DYN   waves take slabs from an LDS counter (the reference's per-block queue, kernel.cu:142,
+//       164-166; here re-armed per segment) -- the default; false: slabs dealt round-robin (A/B arm).
+//       A third arm -- global per-segment counters plus idle workgroups helping the busiest segment
+//       -- was measured and dropped: the device-scope atomic per slab cost 6 % by itself and the
+//       helping, at ~2 slabs per wave, evened the finish times without shortening the launch.
+// STAMP:   diagnostic instantiation (tools/stamps.py only): thread 0 records the 100 MHz wall clock
+//          at entry, after the first staging and at exit into a buffer of its own.
+// INLINE_ER: slabs also multiply the residual pairs stored behind their ELL pairs (tiny residuals).
+struct EllArgs {
+    const int4* __restrict__ items;
+    const int4* __restrict__ segs;
+    const int* __restrict__ halo_cols;
+    const uint4* __restrict__ slab_meta;
+    const uint8_t* __restrict__ lane_group;
+    const double2* __restrict__ ell_val;
+    const uint32_t* __restrict__ ell_col;
+    const double* __restrict__ x;
+    double* __restrict__ y;
+    int win_cap;
+    unsigned long long* __restrict__ stamps;
+};
+
+template <bool INLINE_ER>
+__device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restrict__ win, int s, int pe, int lane)
 {
-    extern __shared__ __attribute__((aligned(16))) double win[];
-    int* next_slab = reinterpret_cast<int*>(win + win_cap);  // one word behind the window
-    if (STAMP && threadIdx.x == 0) stamps[4 * blockIdx.x + 0] = wall_clock64();
-    const int4 it = items[2 * blockIdx.x];
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    constexpr int WAVES = THREADS / 64;
-
-    for (int sg = it.x; sg < it.y; ++sg) {
-        const int4 a = segs[2 * sg], b = segs[2 * sg + 1];
-        const int sb = a.y, se = a.z, hn = a.w;
-        const int ps = b.x, pe = b.y, wl = b.z, hb = b.w;
-        if (sg > it.x) __syncthreads();  // every wave is done with the previous window and counter
-
-        // The LDS image starts at the even row at or below the partition start (the layout
-        // builder numbers window-local columns from there); win[0] may hold x[ps-1], unused.
-        const int base = ps & ~1, cnt = wl + (ps & 1);
-        for (int i = threadIdx.x; i < cnt; i += THREADS) win[i] = x[base + i];
-        for (int i = threadIdx.x; i < hn; i += THREADS) win[cnt + i] = x[halo_cols[hb + i]];
-        if (DYN && threadIdx.x == 0) *next_slab = sb + WAVES;  // slabs sb..sb+WAVES-1 are pre-assigned
-        __syncthreads();
-        if (STAMP && sg == it.x && threadIdx.x == 0) stamps[4 * blockIdx.x + 1] = wall_clock64();
-
-        int s = sb + wave;
-        while (s < se) {
-            // slab record {first value pair, first column word, first row, pairs << 8 | groups - 1}
-            const uint4 sm = slab_meta[s];
-            const int np = (int)(sm.w >> 8);
-            const int G = (int)(sm.w & 0xffu) + 1;  // lanes with equal column lists share one word per pair
-            const double2* __restrict__ v = ell_val + (size_t)sm.x * 64 + lane;
-            const uint32_t* __restrict__ c = ell_col + sm.y + lane_group[(size_t)s * 64 + lane];
-            double acc0 = 0.0, acc1 = 0.0;
-            int k = 0;
-            for (; k + 4 <= np; k += 4) {
-                const double2 v0 = v[(k + 0) * 64], v1 = v[(k + 1) * 64], v2 = v[(k + 2) * 64], v3 = v[(k + 3) * 64];
-                const uint32_t c0 = c[(k + 0) * G], c1 = c[(k + 1) * G], c2 = c[(k + 2) * G], c3 = c[(k + 3) * G];
-                acc0 = fma(v0.x, win[c0 & 0xffffu], acc0);
-                acc1 = fma(v0.y, win[c0 >> 16], acc1);
-                acc0 = fma(v1.x, win[c1 & 0xffffu], acc0);
-                acc1 = fma(v1.y, win[c1 >> 16], acc1);
-                acc0 = fma(v2.x, win[c2 & 0xffffu], acc0);
-                acc1 = fma(v2.y, win[c2 >> 16], acc1);
-                acc0 = fma(v3.x, win[c3 & 0xffffu], acc0);
-                acc1 = fma(v3.y, win[c3 >> 16], acc1);
-            }
-            for (; k < np; ++k) {
-                const double2 v0 = v[k * 64];
-                const uint32_t c0 = c[k * G];
-                acc0 = fma(v0.x, win[c0 & 0xffffu], acc0);
-                acc1 = fma(v0.y, win[c0 >> 16], acc1);
-            }
-            const int row = (int)sm.z + lane;
-            if (row < pe) y[row] = acc0 + acc1;
-            if (DYN) {
-                int nx = 0;
-                if (lane == 0) nx = atomicAdd(next_slab, 1);
-                s = __builtin_amdgcn_readfirstlane(nx);
-            } else {
-                s += WAVES;
-            }
+    // slab record {first value pair, first column word, first row, pairs << 16 | residual pairs << 8 | groups - 1}
+    const uint4 sm = A.slab_meta[s];
+    const int np = (int)(sm.w >> 16);
+    const int G = (int)(sm.w & 0x3fu) + 1;  // lanes with equal column lists share one word per pair
+    const double2* __restrict__ v = A.ell_val + (size_t)sm.x * 64 + lane;
+    const uint32_t* __restrict__ c = A.ell_col + sm.y + A.lane_group[(size_t)s * 64 + lane];
+    double acc0 = 0.0, acc1 = 0.0;
+    if (INLINE_ER) {
+        // Inline residual (tiny residuals only): `ner` more pairs behind the slab's ELL pairs, their
+        // columns global -- [pair][2][lane] 32-bit words behind the slab's shared column words.
+        // First, so that the loads are in flight while the ELL pairs stream; only the gather of x
+        // from global memory (L2) waits for them.  No second launch, no read-modify-write of y.
+        const int ner = (int)(sm.w >> 8) & 0xff;
+        const double2* __restrict__ ve = v + (size_t)np * 64;
+        const uint32_t* __restrict__ ce = A.ell_col + sm.y + (size_t)np * G + lane;
+        for (int q = 0; q < ner; ++q) {
+            const double2 vv = ve[q * 64];
+            const uint32_t ca = ce[q * 128], cb = ce[q * 128 + 64];
+            acc0 = fma(vv.x, A.x[ca], acc0);
+            acc1 = fma(vv.y, A.x[cb], acc1);
         }
     }
-    if (FUSE_ER) {  // residual of this item's rows in the same launch (no second kernel boundary)
-        const int4 er = items[2 * blockIdx.x + 1];
-        if (er.w > er.x) {  // workgroup-uniform
-            __syncthreads();  // the y stores above are complete and visible to the workgroup
-            er_item<THREADS>(er, er_seg_ptr, er_seg_row, er_col, er_val, x, y);
+    int k = 0;
+    for (; k + 4 <= np; k += 4) {
+        const double2 v0 = v[(k + 0) * 64], v1 = v[(k + 1) * 64], v2 = v[(k + 2) * 64], v3 = v[(k + 3) * 64];
+        const uint32_t c0 = c[(k + 0) * G], c1 = c[(k + 1) * G], c2 = c[(k + 2) * G], c3 = c[(k + 3) * G];
+        acc0 = fma(v0.x, win[c0 & 0xffffu], acc0);
+        acc1 = fma(v0.y, win[c0 >> 16], acc1);
+        acc0 = fma(v1.x, win[c1 & 0xffffu], acc0);
+        acc1 = fma(v1.y, win[c1 >> 16], acc1);
+        acc0 = fma(v2.x, win[c2 & 0xffffu], acc0);
+        acc1 = fma(v2.y, win[c2 >> 16], acc1);
+        acc0 = fma(v3.x, win[c3 & 0xffffu], acc0);
+        acc1 = fma(v3.y, win[c3 >> 16], acc1);
+    }
+    for (; k < np; ++k) {
+        const double2 v0 = v[k * 64];
+        const uint32_t c0 = c[k * G];
+        acc0 = fma(v0.x, win[c0 & 0xffffu], acc0);
+        acc1 = fma(v0.y, win[c0 >> 16], acc1);
+    }
+    const int row = (int)sm.z + lane;
+    if (row < pe) A.y[row] = acc0 + acc1;
+}
+
+// Stage the window of segment g and multiply its slabs.
+template <int THREADS, bool DYN, bool INLINE_ER>
+__device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict__ win, int* __restrict__ next_slab,
+                                            int g, int lane, int wave)
+{
+    constexpr int WAVES = THREADS / 64;
+    const int4 a = A.segs[2 * g], b = A.segs[2 * g + 1];
+    const int sb = a.y, se = a.z, hn = a.w;
+    const int ps = b.x, pe = b.y, wl = b.z, hb = b.w;
+    __syncthreads();  // every wave is done with the previous window and counter
+    // The LDS image starts at the even row at or below the partition start (the layout builder
+    // numbers window-local columns from there); win[0] may hold x[ps-1], unused.
+    const int base = ps & ~1, cnt = wl + (ps & 1);
+    for (int i = threadIdx.x; i < cnt; i += THREADS) win[i] = A.x[base + i];
+    for (int i = threadIdx.x; i < hn; i += THREADS) win[cnt + i] = A.x[A.halo_cols[hb + i]];
+    if (DYN && threadIdx.x == 0) *next_slab = sb + WAVES;  // slabs sb..sb+WAVES-1 are pre-assigned
+    __syncthreads();
+    int s = sb + wave;
+    while (s < se) {
+        ell_slab<INLINE_ER>(A, win, s, pe, lane);
+        if (DYN) {
+            int nx = 0;
+            if (lane == 0) nx = atomicAdd(next_slab, 1);
+            s = __builtin_amdgcn_readfirstlane(nx);
+        } else {
+            s += WAVES;
         }
+    }
+}
+
+template <int THREADS, bool DYN, bool STAMP, bool INLINE_ER>
+// 8 waves per SIMD (<= 64 VGPRs): two 1024-thread workgroups per CU, the occupancy the 80 KiB window is sized for
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void ehyb_ell_kernel(const EllArgs A)
+{
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    int* next_slab = reinterpret_cast<int*>(win + A.win_cap);  // one word behind the window
+    if (STAMP && threadIdx.x == 0) A.stamps[4 * blockIdx.x + 0] = wall_clock64();
+    const int4 it = A.items[2 * blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    for (int sg = it.x; sg < it.y; ++sg) {
+        ell_segment<THREADS, DYN, INLINE_ER>(A, win, next_slab, sg, lane, wave);
+        if (STAMP && sg == it.x && threadIdx.x == 0) A.stamps[4 * blockIdx.x + 1] = wall_clock64();
     }
     if (STAMP) {
         __syncthreads();
         if (threadIdx.x == 0) {
-            stamps[4 * blockIdx.x + 2] = wall_clock64();
+            A.stamps[4 * blockIdx.x + 2] = wall_clock64();
             unsigned xcc;
             asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
-            stamps[4 * blockIdx.x + 3] = xcc;
+            A.stamps[4 * blockIdx.x + 3] = xcc;
         }
     }
 }
@@ -229,26 +251,46 @@ __global__ __launch_bounds__(256) void ehyb_read_kernel(const double2* __restric
 static size_t ell_lds_bytes(const HostLayout& H) { return ((size_t)H.lds_doubles + 1) / 2 * 16 + 16; }
 static int ell_win_cap(const HostLayout& H) { return (H.lds_doubles + 1) / 2 * 2; }
 
-#define ELL_ARGS(P, x, y)                                                                                     \
-    (const int4*)(P)->d_items, (const int4*)(P)->d_segs, (P)->d_halo_cols, (const uint4*)(P)->d_slab_meta,    \
-        (P)->d_lane_group, (const double2*)(P)->d_ell_val, (P)->d_ell_col, x, y, (P)->d_er_seg_ptr,           \
-        (P)->d_er_seg_row, (P)->d_er_col, (P)->d_er_val, ell_win_cap((P)->host)
+static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long long* stamps)
+{
+    EllArgs A;
+    A.items = (const int4*)P->d_items;
+    A.segs = (const int4*)P->d_segs;
+    A.halo_cols = P->d_halo_cols;
+    A.slab_meta = (const uint4*)P->d_slab_meta;
+    A.lane_group = P->d_lane_group;
+    A.ell_val = (const double2*)P->d_ell_val;
+    A.ell_col = P->d_ell_col;
+    A.x = x;
+    A.y = y;
+    A.win_cap = ell_win_cap(P->host);
+    A.stamps = stamps;
+    return A;
+}
 
-static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st, bool fuse)
+// ell_variant: 0/1 = LDS slab counter (default), 3 = static round-robin (A/B arm, tools/sweep.py --variants)
+
+template <bool STAMP>
+static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t st, bool inl, unsigned long long* stamps)
 {
     const HostLayout& H = P->host;
     const int n_items = (int)(H.items.size() / 8);
     if (n_items == 0) return EHYB_OK;
     const size_t lds = ell_lds_bytes(H);
-    const bool dyn = P->cfg.ell_variant != 3;  // 3 = static round-robin slabs (A/B arm)
-#define ELL_LAUNCH_DF(T, D, F)                                                                               \
-    hipLaunchKernelGGL((ehyb_ell_kernel<T, D, false, F>), dim3(n_items), dim3(T), lds, st, ELL_ARGS(P, x, y), \
-                       (unsigned long long*)nullptr);
-#define ELL_LAUNCH(T)                                 \
-    if (dyn && fuse) { ELL_LAUNCH_DF(T, true, true) } \
-    else if (dyn) { ELL_LAUNCH_DF(T, true, false) }   \
-    else if (fuse) { ELL_LAUNCH_DF(T, false, true) }  \
-    else { ELL_LAUNCH_DF(T, false, false) }
+    const bool dyn = P->cfg.ell_variant != 3;
+    const EllArgs A = ell_args(P, x, y, stamps);
+#define ELL_GO(T, M, I)                                                                                      \
+    {                                                                                                        \
+        if (STAMP) HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<T, M, STAMP, I>,                 \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
+        hipLaunchKernelGGL((ehyb_ell_kernel<T, M, STAMP, I>), dim3(n_items), dim3(T), lds, st, A);           \
+    }
+#define ELL_MODE(T, I)           \
+    if (dyn) ELL_GO(T, true, I)  \
+    else ELL_GO(T, false, I)
+#define ELL_LAUNCH(T)            \
+    if (inl) { ELL_MODE(T, true) } \
+    else { ELL_MODE(T, false) }
     switch (P->cfg.threads) {
         case 256: ELL_LAUNCH(256) break;
         case 512: ELL_LAUNCH(512) break;
@@ -256,9 +298,15 @@ static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st, 
         default: EHYB_FAIL(EHYB_ERR_ARG, "ELL workgroup size %d not built (256/512/1024)", P->cfg.threads);
     }
 #undef ELL_LAUNCH
-#undef ELL_LAUNCH_DF
+#undef ELL_MODE
+#undef ELL_GO
     HIP_TRY(hipGetLastError());
     return EHYB_OK;
+}
+
+static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st, bool inl)
+{
+    return launch_ell_impl<false>(P, x, y, st, inl, nullptr);
 }
 
 static int launch_er(ehyb_plan* P, const double* x, double* y, hipStream_t st)
@@ -273,18 +321,13 @@ static int launch_er(ehyb_plan* P, const double* x, double* y, hipStream_t st)
     return EHYB_OK;
 }
 
-// Where the residual runs.  Two launches need a second ~8 us kernel boundary but give the residual
-// thousands of independent blocks; the fused tail costs nothing when the residual is tiny and
-// serialises it behind each workgroup's slabs when it is not (measured: tools/sweep.py --fuse).
-// fuse_er: 1 = always fused, 2 = never, 0 = automatic: fused iff the residual holds < 0.2 % of
+// Where the residual runs (decided by the layout builder, HostLayout::inline_er).  Its own launch
+// costs a second ~8 us kernel boundary but gives the residual thousands of independent blocks;
+// inline -- every ELL lane adds its row's few residual entries before writing y -- costs nothing
+// when the residual is tiny and would serialise a divergent per-lane loop when it is not.
+// fuse_er: 1 = always inline, 2 = never, 0 = automatic: inline iff the residual holds < 0.2 % of
 // the entries.  Multi-GPU plans keep the phases apart (phase 1 reads only the rank's x segment).
-static bool fuse_residual(const ehyb_plan* P)
-{
-    if (P->cfg.n_top > 1 || P->cfg.fuse_er == 2) return false;
-    if (P->cfg.fuse_er == 1) return true;
-    const ehyb_stats& st = P->host.stats;
-    return st.nnz_er * 500 < st.nnz;
-}
+static bool fuse_residual(const ehyb_plan* P) { return P->host.inline_er; }
 
 template <class T>
 static int upload(T** dst, const std::vector<T>& src)
@@ -400,29 +443,12 @@ int ehyb_measure_read_bw(size_t bytes, int iters, double* gbps)
 int ehyb_debug_ell_stamps(ehyb_plan* P, const double* x, double* y, unsigned long long* out_host)
 {
     if (!P || !P->uploaded || !out_host) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_debug_ell_stamps: bad arguments");
-    const HostLayout& H = P->host;
-    const int n_items = (int)(H.items.size() / 8);
-    const size_t lds = ell_lds_bytes(H);
-    const bool dyn = P->cfg.ell_variant != 3;
+    const int n_items = (int)(P->host.items.size() / 8);
     unsigned long long* d = nullptr;
     HIP_TRY(hipMalloc((void**)&d, (size_t)n_items * 32));
     HIP_TRY(hipMemset(d, 0, (size_t)n_items * 32));
-#define STAMP_LAUNCH_D(T, D)                                                                                      \
-    HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<T, D, true, false>,                                  \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));                           \
-    hipLaunchKernelGGL((ehyb_ell_kernel<T, D, true, false>), dim3(n_items), dim3(T), lds, 0, ELL_ARGS(P, x, y), d);
-#define STAMP_LAUNCH(T)                    \
-    if (dyn) { STAMP_LAUNCH_D(T, true) }   \
-    else { STAMP_LAUNCH_D(T, false) }
-    switch (P->cfg.threads) {
-        case 256: STAMP_LAUNCH(256) break;
-        case 512: STAMP_LAUNCH(512) break;
-        case 1024: STAMP_LAUNCH(1024) break;
-        default: EHYB_FAIL(EHYB_ERR_ARG, "workgroup size %d not built", P->cfg.threads);
-    }
-#undef STAMP_LAUNCH
-#undef STAMP_LAUNCH_D
-    HIP_TRY(hipGetLastError());
+    int rc = launch_ell_impl<true>(P, x, y, nullptr, P->host.inline_er, d);
+    if (rc != EHYB_OK) return rc;
     HIP_TRY(hipDeviceSynchronize());
     HIP_TRY(hipMemcpy(out_host, d, (size_t)n_items * 32, hipMemcpyDeviceToHost));
     (void)hipFree(d);
@@ -461,11 +487,11 @@ int ehyb_plan_upload(ehyb_plan* P)
     // opt in to the full 160 KiB of LDS (the role of cudaFuncSetAttribute at kernel.cu:351,411)
     const int lds = (int)ell_lds_bytes(H);
 #define LDS_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-#define LDS_ATTR_T(T)                                    \
-    LDS_ATTR((ehyb_ell_kernel<T, true, false, false>))   \
-    LDS_ATTR((ehyb_ell_kernel<T, true, false, true>))    \
-    LDS_ATTR((ehyb_ell_kernel<T, false, false, false>))  \
-    LDS_ATTR((ehyb_ell_kernel<T, false, false, true>))
+#define LDS_ATTR_T(T)                                   \
+    LDS_ATTR((ehyb_ell_kernel<T, false, false, false>)) \
+    LDS_ATTR((ehyb_ell_kernel<T, false, false, true>))  \
+    LDS_ATTR((ehyb_ell_kernel<T, true, false, false>))  \
+    LDS_ATTR((ehyb_ell_kernel<T, true, false, true>))
     LDS_ATTR_T(256)
     LDS_ATTR_T(512)
     LDS_ATTR_T(1024)

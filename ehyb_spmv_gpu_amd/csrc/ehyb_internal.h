@@ -76,7 +76,7 @@ struct HostLayout {
     std::vector<uint32_t> ell_col;
     std::vector<uint32_t> slab_col_ptr;  // [n_slabs+1] prefix of pairs*groups
     std::vector<uint8_t> lane_group;     // [n_slabs*64]
-    std::vector<uint32_t> slab_meta;     // [n_slabs*4] {pair_ptr, col_ptr, first row, pairs<<8 | groups-1}
+    std::vector<uint32_t> slab_meta;     // [n_slabs*4] {pair_ptr, col_ptr, first row, pairs<<16 | er_pairs<<8 | groups-1}
 
     // work items {seg_begin, seg_end, slab_begin, slab_end, er_begin, er_b64, er_b16, er_end}: a run of
     // slabs of (nearly) equal cost; it is cut into segments where it crosses a partition boundary
@@ -91,6 +91,9 @@ struct HostLayout {
     std::vector<double> er_val;
     int32_t er_bins[8] = {0, 0, 0, 0, 0, 0, 0, 0};  // [3] = number of segments
     std::vector<int32_t> er_blocks;                 // {seg_lo, seg_hi, lanes per segment, 0} per block
+    // inline form: the residual is also stored as extra pairs behind each slab's ELL pairs
+    // (slab_meta word 3, bits 8..15) and the ELL launch multiplies it
+    bool inline_er = false;
 
     ehyb_stats stats{};
 };

@@ -34,6 +34,7 @@ struct PartScratch {
     std::vector<int32_t> halo;       // chosen outside columns, ascending
     std::vector<uint32_t> slab_w2;   // pairs per slab
     std::vector<uint32_t> slab_g;    // column-list groups per slab
+    std::vector<uint32_t> slab_ner;  // residual pairs per slab (inline form only)
 };
 
 inline int halo_lookup(const std::vector<int32_t>& halo, int col)
@@ -247,6 +248,38 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     if (bad_col) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: column index outside [0,%d)", n);
     if (bad_row) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: I[k] does not match the row rowIdx places it in");
 
+    // residual row pointer (row order)
+    std::vector<int64_t> er_rp(nrows + 1, 0);
+    for (int r = 0; r < nrows; ++r) {
+        int len = rp[row_begin + r + 1] - rp[row_begin + r];
+        er_rp[r + 1] = er_rp[r] + (len - cnt_ell[r]);
+    }
+    const int64_t nnz_er = er_rp[nrows];
+    const int64_t nnz = (int64_t)rp[row_end] - rp[row_begin];
+    const int64_t nnz_ell = nnz - nnz_er;
+
+    // ---- inline form of a tiny residual.  The residual entries of a slab's rows are stored as
+    // extra pairs behind the slab's ELL pairs -- values in the same stream, columns as two global
+    // 32-bit indices per lane and pair -- and the ELL lanes multiply them straight from global x
+    // before writing y: one launch, no read-modify-write of y.  A dependent chain (row pointer ->
+    // column -> x) at the end of the slab cost 7 % of the launch when tried; with the slice every
+    // address follows from the slab record and only the x gather waits for a load.
+    // The CSR segments are built as well, so the two-phase call of the same plan still works.
+    L->inline_er = cfg.n_top <= 1 && nnz_er > 0 && (cfg.fuse_er == 1 || (cfg.fuse_er != 2 && nnz_er * 500 < nnz));
+    if (L->inline_er) {
+        const int max_ner = cfg.fuse_er == 1 ? 255 : 8;
+        for (int p = 0; p < np && L->inline_er; ++p) {
+            PartScratch& S = ps[p];
+            S.slab_ner.assign(S.slab_w2.size(), 0);
+            for (int r = pb[p]; r < pb[p + 1]; ++r) {
+                const int64_t c = er_rp[r - row_begin + 1] - er_rp[r - row_begin];
+                uint32_t& ner = S.slab_ner[(r - pb[p]) / kSlabRows];
+                ner = std::max<uint32_t>(ner, (uint32_t)std::min<int64_t>((c + 1) / 2, 1 << 20));
+                if ((int)ner > max_ner) L->inline_er = false;  // a long residual row: the CSR kernel is the better tool
+            }
+        }
+    }
+
     // ---- pass 2: prefix sums
     L->halo_ptr.assign(np + 1, 0);
     std::vector<int64_t> slab_base(np + 1, 0);
@@ -265,6 +298,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     L->slab_part.resize(nslabs);
     L->slab_col_ptr.assign(nslabs + 1, 0);
     L->slab_meta.assign((size_t)nslabs * 4, 0);
+    int64_t ell_pairs = 0, er_inline_pairs = 0;
     {
         uint64_t acc = 0, acc_c = 0;
         for (int p = 0; p < np; ++p) {
@@ -272,18 +306,25 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             for (size_t q = 0; q < ps[p].slab_w2.size(); ++q) {
                 int64_t sidx = slab_base[p] + (int64_t)q;
                 const uint32_t w2 = ps[p].slab_w2[q], g = std::max<uint32_t>(1, ps[p].slab_g[q]);
+                const uint32_t ner = L->inline_er ? ps[p].slab_ner[q] : 0;
                 L->slab_pair_ptr[sidx] = (uint32_t)acc;
                 L->slab_col_ptr[sidx] = (uint32_t)acc_c;
                 L->slab_row[sidx] = pb[p] + (int32_t)q * kSlabRows;
                 L->slab_part[sidx] = p;
                 // what the kernel reads per slab: one 16-byte record
-                if (w2 >= (1u << 24)) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: slab wider than 2^25 entries");
+                // (a row has at most one entry per window column, so 2^16 pairs are out of reach
+                // unless the input repeats coordinates)
+                if (w2 >= (1u << 16)) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: slab wider than 2^17 entries");
                 L->slab_meta[4 * sidx + 0] = (uint32_t)acc;
                 L->slab_meta[4 * sidx + 1] = (uint32_t)acc_c;
                 L->slab_meta[4 * sidx + 2] = (uint32_t)L->slab_row[sidx];
-                L->slab_meta[4 * sidx + 3] = (w2 << 8) | (g - 1);
-                acc += w2;
-                acc_c += (uint64_t)w2 * g;
+                L->slab_meta[4 * sidx + 3] = (w2 << 16) | (ner << 8) | (g - 1);
+                // value stream: w2 ELL pairs then ner residual pairs, 64 lanes x 2 each;
+                // column stream: w2 x g shared words then ner x 128 global columns
+                acc += w2 + ner;
+                acc_c += (uint64_t)w2 * g + (uint64_t)ner * 2 * kSlabRows;
+                ell_pairs += w2;
+                er_inline_pairs += ner;
                 if (acc > 0xFFFFFFFFull || acc_c > 0xFFFFFFFFull)
                     EHYB_FAIL(EHYB_ERR_ARG, "build_layout: ELL part too large for 32-bit offsets");
             }
@@ -291,21 +332,12 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         L->slab_pair_ptr[nslabs] = (uint32_t)acc;
         L->slab_col_ptr[nslabs] = (uint32_t)acc_c;
     }
-    const int64_t size_ell = (int64_t)L->slab_pair_ptr[nslabs] * 2 * kSlabRows;
+    const int64_t size_ell = ell_pairs * 2 * kSlabRows;                   // ELL elements incl. padding
+    const int64_t size_stream = (int64_t)L->slab_pair_ptr[nslabs] * 2 * kSlabRows;  // + inline residual pairs
     const int64_t col_words = (int64_t)L->slab_col_ptr[nslabs];
 
-    // residual row pointer (row order)
-    std::vector<int64_t> er_rp(nrows + 1, 0);
-    for (int r = 0; r < nrows; ++r) {
-        int len = rp[row_begin + r + 1] - rp[row_begin + r];
-        er_rp[r + 1] = er_rp[r] + (len - cnt_ell[r]);
-    }
-    const int64_t nnz_er = er_rp[nrows];
-    const int64_t nnz = (int64_t)rp[row_end] - rp[row_begin];
-    const int64_t nnz_ell = nnz - nnz_er;
-
     // ---- pass 3: fill
-    L->ell_val.assign((size_t)size_ell, 0.0);
+    L->ell_val.assign((size_t)size_stream, 0.0);
     L->ell_col.assign((size_t)col_words, 0);
     L->lane_group.assign((size_t)nslabs * kSlabRows, 0);
     std::vector<int32_t> tcol((size_t)nnz_er);
@@ -321,9 +353,10 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             const int64_t sidx = slab_base[p] + (r - s) / kSlabRows;
             const int lane = (r - s) % kSlabRows;
             const uint64_t pp = L->slab_pair_ptr[sidx];
-            const uint32_t w2 = L->slab_pair_ptr[sidx + 1] - L->slab_pair_ptr[sidx];
+            const uint32_t w2 = L->slab_meta[4 * sidx + 3] >> 16;
+            const uint32_t ner = (L->slab_meta[4 * sidx + 3] >> 8) & 0xFF;
             const uint64_t cp = L->slab_col_ptr[sidx];
-            const uint32_t G = (L->slab_meta[4 * sidx + 3] & 0xFF) + 1;
+            const uint32_t G = (L->slab_meta[4 * sidx + 3] & 0x3F) + 1;
             const bool lead = lead_row[r - row_begin] != 0;
             gid = lane == 0 ? 0 : gid + (lead ? 1 : 0);
             L->lane_group[(size_t)sidx * kSlabRows + lane] = (uint8_t)gid;
@@ -357,6 +390,15 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 } else {
                     tcol[(size_t)k_er] = j;
                     tval[(size_t)k_er] = m->V[k];
+                    if (L->inline_er) {
+                        const uint32_t ke = (uint32_t)(k_er - er_rp[r - row_begin]);
+                        if (ke >= 2 * ner) {
+                            overflow = 1;
+                            continue;
+                        }
+                        L->ell_val[(size_t)(((pp + w2 + ke / 2) * kSlabRows + lane) * 2 + (ke & 1))] = m->V[k];
+                        L->ell_col[(size_t)(cp + (uint64_t)w2 * G + (uint64_t)(ke / 2) * 2 * kSlabRows + (ke & 1) * kSlabRows + lane)] = (uint32_t)j;
+                    }
                     ++k_er;
                 }
             }
@@ -504,7 +546,6 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             }
         }
     }
-
     // ---- statistics (convert.c:140,310; spmv.cu:82)
     ehyb_stats& st = L->stats;
     st.nnz = nnz;
@@ -529,9 +570,12 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     int64_t halo_item_loads = st.window_loads;
     for (size_t sg = 0; sg < L->segs.size(); sg += 8) halo_item_loads -= L->segs[sg + 6];
     st.col_words = col_words;
-    // values 8 B/element, shared column words 4 B, per slab a 16-byte record + 64-byte lane map
+    st.er_inline = L->inline_er ? er_inline_pairs * 2 * kSlabRows : 0;
+    // values 8 B/element, shared column words 4 B, per slab a 16-byte record + 64-byte lane map;
+    // the residual either as inline pairs (their columns are part of col_words) or as CSR segments
     st.bytes_format = 8 * size_ell + 4 * col_words + 80 * nslabs + 32 * st.n_items + 32 * (int64_t)(L->segs.size() / 8) + 8 * st.window_loads +
-                      4 * halo_item_loads + 8 * (int64_t)nrows + 12 * nnz_er + 12 * nseg + 16 * nseg;
+                      4 * halo_item_loads + 8 * (int64_t)nrows +
+                      (L->inline_er ? 8 * st.er_inline + 8 * nnz_er : 12 * nnz_er + 12 * nseg + 16 * nseg);
     if (nnz_ell + nnz_er != nnz) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: %lld + %lld != %lld", (long long)nnz_ell, (long long)nnz_er, (long long)nnz);
     if (cfg.verbose) {
         printf("toER is %lld, kernel calculation is %lld\n", (long long)nnz_er, (long long)nnz_ell);

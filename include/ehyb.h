@@ -83,8 +83,8 @@ typedef struct ehyb_config {
     int32_t seed;          /* partitioner tie-breaking seed (deterministic per seed)      */
     int32_t n_top;         /* top-level row blocks (one per GPU); 0/1 = single GPU        */
     int32_t er_threads;    /* residual workgroup size                                     */
-    int32_t ell_variant;   /* ELL kernel A/B arms: 0 = default (3), 1 = simple loop + 4-deep staging,
-                              2 = software-pipelined loop, 3 = simple loop + scalar staging */
+    int32_t ell_variant;   /* how ELL slabs reach the waves of a workgroup: 0/1 = LDS counter (default),
+                              3 = static round-robin (A/B arm)                                   */
     int32_t col_sharing;   /* 0/1 = rows with the column list of the row above share its indices, 2 = off */
     int32_t fuse_er;       /* residual placement: 0 = automatic (inside the ELL launch iff it holds < 0.2 %
                               of the entries), 1 = always inside (single GPU only), 2 = own launch     */
@@ -181,7 +181,9 @@ typedef struct ehyb_stats {
     int64_t max_row;        /* longest row                                            */
     int64_t lds_bytes;      /* dynamic LDS per ELL workgroup                          */
     int64_t col_words;      /* stored 4-byte column words (2 x 16 bit) after sharing  */
-    int64_t reserved[4];
+    int64_t er_inline;      /* stored inline-residual elements incl. padding; > 0: the residual rides in
+                               the ELL launch (ehyb_spmv is one launch), see EHYB_ARR_SLAB_META */
+    int64_t reserved[3];
 } ehyb_stats;
 int ehyb_plan_stats(const ehyb_plan* plan, ehyb_stats* out);
 
@@ -208,7 +210,11 @@ enum {
     EHYB_ARR_ER_BINS       = 14,/* int32  [8]  {0, -, -, er_segments, ...}                        */
     EHYB_ARR_SLAB_COL_PTR  = 15,/* uint32 [n_slabs+1]  prefix of pairs * groups               */
     EHYB_ARR_LANE_GROUP    = 16,/* uint8  [n_slabs*64] column-list group of every lane        */
-    EHYB_ARR_SLAB_META     = 17,/* uint32 [n_slabs*4]  {pair_ptr, col_ptr, row, pairs<<8|G-1}: what the kernel reads */
+    EHYB_ARR_SLAB_META     = 17,/* uint32 [n_slabs*4]  {pair_ptr, col_ptr, row, pairs<<16 | er_pairs<<8 | G-1}:
+                                   what the kernel reads.  er_pairs > 0 only in the inline-residual form
+                                   (stats.er_inline): behind the slab's `pairs` ELL pairs the value stream
+                                   holds er_pairs more pairs [pair][lane][2], and behind its pairs*G column
+                                   words the column stream holds [er pair][2][lane] GLOBAL 32-bit columns */
     EHYB_ARR_SEGS          = 18 /* int32  [n_segs*8]   {partition, slab_begin, slab_end, halo_count, first row,
                                    end row, win_len, halo_begin}: one LDS window staging each       */
 };

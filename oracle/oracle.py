@@ -167,6 +167,8 @@ def walk_plan(plan, x):
     seg_ptr = plan.array("er_seg_ptr")
     seg_row = plan.array("er_seg_row")
     seg_done = np.zeros(len(seg_row), dtype=np.int32)
+    inline = plan.stats["er_inline"] > 0
+    y_inl = np.zeros(n)
     next_seg, next_slab = 0, 0
     for g0, g1, is0, is1, e0, e64, e16, e1 in items:
         # an item = consecutive segments covering the consecutive slabs [is0, is1)
@@ -193,15 +195,17 @@ def walk_plan(plan, x):
             base = ps & ~1  # the LDS image starts at the even row at or below the partition start
             win = np.concatenate([x[base:ps + wl], x[halo_cols[hb:hb + hn]]])
             for s in range(s0, s1):
-                p0, p1 = spp[s], spp[s + 1]
+                # record word 3: ELL pairs << 16 | inline residual pairs << 8 | column groups - 1
+                npairs, ner, G = int(meta[s, 3] >> 16), int(meta[s, 3] >> 8) & 0xFF, int(meta[s, 3] & 0x3F) + 1
+                p0, p1 = int(spp[s]), int(spp[s]) + npairs
                 acc = np.zeros(64, dtype=np.float64)
                 # the 16-byte record the kernel reads must agree with the prefix arrays
-                assert meta[s, 0] == p0 and meta[s, 1] == scp[s] and meta[s, 2] == slab_row[s] and meta[s, 3] >> 8 == p1 - p0
+                assert meta[s, 0] == p0 and meta[s, 1] == scp[s] and meta[s, 2] == slab_row[s] and spp[s + 1] == p1 + ner
+                assert (scp[s + 1] - scp[s]) == npairs * G + ner * 128
+                assert ner == 0 or inline, "inline residual pairs only in the inline form"
                 if p1 > p0:
-                    G = int(meta[s, 3] & 0xFF) + 1
-                    assert (scp[s + 1] - scp[s]) == (p1 - p0) * G
-                    v = ell_val[p0 * 128:p1 * 128].reshape(p1 - p0, 64, 2)
-                    words = ell_col[scp[s]:scp[s + 1]].reshape(p1 - p0, G)[:, lane_group[s]]  # [pair][lane]
+                    v = ell_val[p0 * 128:p1 * 128].reshape(npairs, 64, 2)
+                    words = ell_col[scp[s]:scp[s] + npairs * G].reshape(npairs, G)[:, lane_group[s]]  # [pair][lane]
                     c = np.stack([words & 0xFFFF, words >> 16], axis=2)
                     assert c.max() < len(win), "window-local column outside the window"
                     acc = (v * win[c]).sum(axis=(0, 2))
@@ -209,9 +213,21 @@ def walk_plan(plan, x):
                 cnt = min(64, pe - r0)
                 y[r0:r0 + cnt] = acc[:cnt]
                 written[r0:r0 + cnt] += 1
+                if ner:
+                    # inline residual: values behind the ELL pairs, global columns [pair][2][lane]
+                    # behind the shared column words; lanes past the partition end hold zeros
+                    ve = ell_val[p1 * 128:(p1 + ner) * 128].reshape(ner, 64, 2)
+                    ce = ell_col[scp[s] + npairs * G:scp[s + 1]].reshape(ner, 2, 64).transpose(0, 2, 1)
+                    assert ce.max() < n and not np.any(ve[:, cnt:, :])
+                    y_inl[r0:r0 + cnt] = (ve * x[ce]).sum(axis=(0, 2))[:cnt]
     er_col = plan.array("er_col")
     er_val = plan.array("er_val")
     assert np.all(seg_done == 1), "every residual segment belongs to exactly one work item"
+    if inline:
+        # inline form (tiny residual): the pairs behind the slabs hold the same entries as the CSR segments
+        y_seg = np.zeros(n)
+        np.add.at(y_seg, seg_row & 0x7FFFFFFF, np.add.reduceat(er_val * x[er_col], seg_ptr[:-1]))
+        assert np.allclose(y_inl, y_seg, rtol=0, atol=1e-12 * (np.abs(y_seg).max() + 1e-300))
     if len(seg_row):
         prod = er_val * x[er_col]
         sums = np.add.reduceat(prod, seg_ptr[:-1]) if len(prod) else np.zeros(0)

@@ -24,7 +24,17 @@ def _properties(E, O, c, plan, y_perm):
     dx, dy = E.DeviceBuffer(n).upload(c.xp), E.DeviceBuffer(n)
     plan.spmv(dx.ptr, dy.ptr, phase=1)
     plan.spmv(dx.ptr, dy.ptr, phase=2)
-    assert np.array_equal(dy.download(), y_perm)
+    y_split = dy.download()
+    if plan.stats["er_inline"] == 0:
+        assert np.array_equal(y_split, y_perm)
+    else:
+        # a tiny residual rides inside the ELL launch (summed with the ELL entries before y is rounded
+        # and stored), so the two-phase result may differ from the one-call result in the last bits
+        # of the rows that have residual entries, and only there
+        assert c.check(y_split)[0] == 0
+        differs = np.flatnonzero(y_split != y_perm)
+        er_rows = np.unique(plan.array("er_seg_row") & 0x7FFFFFFF)
+        assert np.all(np.isin(differs, er_rows))
 
 
 def test_config2_audikw_like_full(E, O, gpu):

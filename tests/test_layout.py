@@ -25,6 +25,34 @@ def test_walk_equals_oracle(E, O, name, kind, args, mode):
     _walk_ok(E, O, c, plan)
 
 
+@pytest.mark.parametrize("fuse", [0, 1, 2], ids=["auto", "inline", "own-launch"])
+def test_inline_residual_form(E, O, fuse):
+    """A residual the ELL launch carries itself: its entries sit behind the slabs' ELL pairs with
+    global columns (walk_plan checks them against the CSR segments, which stay for the two-phase
+    call).  fuse_er=1 forces the form, 2 forbids it, 0 takes it for residuals under 0.2 %."""
+    cfg = E.make_config(lds_doubles=1024, fuse_er=fuse, cap_split=2)
+    c = Case(E, O, "fem3d", (6000, 3, 12, 12, 20000, 1, 5), cfg)
+    plan = E.Plan(c.m, cfg, upload=False)
+    st = plan.stats
+    assert st["nnz_er"] > 0, "the case must leave a residual"
+    meta = plan.array("slab_meta").astype(np.int64).reshape(-1, 4)
+    ner = (meta[:, 3] >> 8) & 0xFF
+    small = st["nnz_er"] * 500 < st["nnz"]
+    if fuse == 1 or (fuse == 0 and small):
+        assert st["er_inline"] == ner.sum() * 128 > 0
+        # a slab's inline pairs hold its longest residual row
+        er_len = np.zeros(c.n, dtype=np.int64)
+        np.add.at(er_len, plan.array("er_seg_row") & 0x7FFFFFFF, np.diff(plan.array("er_seg_ptr")))
+        srow = plan.array("slab_row")
+        for s in np.flatnonzero(ner):
+            assert ner[s] == (er_len[srow[s]:srow[s] + 64].max() + 1) // 2
+    else:
+        assert st["er_inline"] == 0 and not ner.any()
+    assert st["size_block_ell"] == st["nnz_ell"] + st["ell_padding"]
+    assert len(plan.array("ell_val")) == st["size_block_ell"] + st["er_inline"]
+    _walk_ok(E, O, c, plan)
+
+
 @pytest.mark.parametrize("mode", [1, 2])
 def test_structural_invariants(E, O, mode):
     """The reference's exit()-style self-checks (convert.c:122-125,226-263,287-303) as assertions:
@@ -57,8 +85,9 @@ def test_structural_invariants(E, O, mode):
         wsize = (ps & 1) + wl[p] + (hp[p + 1] - hp[p])
         assert wsize <= cfg.lds_doubles
         npairs = spp[s + 1] - spp[s]
-        G = int(meta[s, 3] & 0xFF) + 1
-        assert scp[s + 1] - scp[s] == npairs * G and meta[s, 3] >> 8 == npairs
+        G = int(meta[s, 3] & 0x3F) + 1
+        # record word 3 = pairs << 16 | inline residual pairs << 8 | groups - 1 (this residual is not inline)
+        assert scp[s + 1] - scp[s] == npairs * G and meta[s, 3] >> 16 == npairs and (meta[s, 3] >> 8) & 0xFF == 0
         assert lg[s].max() < G and lg[s][0] == 0 and np.all(np.diff(lg[s]) >= 0) and np.all(np.diff(lg[s]) <= 1)
         words = ew[scp[s]:scp[s + 1]].reshape(npairs, G)[:, lg[s]] if npairs else np.zeros((0, 64), dtype=np.int64)
         cols = np.stack([words & 0xFFFF, words >> 16], axis=2)   # [pair][lane][2] as the kernel decodes it
@@ -134,9 +163,9 @@ def test_shared_column_lists(E, O):
     assert 0.93 * s_off["size_block_ell"] <= s_off["col_words"] * 2 <= s_off["size_block_ell"]
     assert s_on["col_words"] < 0.36 * s_off["col_words"]              # groups of 3 (+ partial groups at slab edges)
     assert s_on["size_block_ell"] == s_off["size_block_ell"] and s_on["nnz_er"] == s_off["nnz_er"]
-    g = (on.array("slab_meta").reshape(-1, 4)[:, 3] & 0xFF) + 1
+    g = (on.array("slab_meta").reshape(-1, 4)[:, 3] & 0x3F) + 1
     assert g.max() <= 26 and np.median(g) == 22                        # 64 lanes = 21 nodes x 3 rows + 1
-    assert ((off.array("slab_meta").reshape(-1, 4)[:, 3] & 0xFF) + 1).min() >= 1
+    assert ((off.array("slab_meta").reshape(-1, 4)[:, 3] & 0x3F) + 1).min() >= 1
     y_on, _ = O.walk_plan(on, c.xp)
     y_off, _ = O.walk_plan(off, c.xp)
     assert np.array_equal(y_on, y_off)

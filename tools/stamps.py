@@ -20,7 +20,7 @@ def main():
     ap.add_argument("--part-rows", type=int, default=0)
     ap.add_argument("--threads", type=int, default=1024)
     ap.add_argument("--items", type=int, default=2)
-    ap.add_argument("--variant", type=int, default=0, help="0/5 dynamic slab hand-out, 3 static round-robin")
+    ap.add_argument("--variant", type=int, default=0, help="0/1 LDS slab counter, 3 static round-robin")
     args = ap.parse_args()
     import numpy as np
 

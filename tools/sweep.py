@@ -22,13 +22,13 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="audikw_1-like")
     ap.add_argument("--lds", default="10240")
-    ap.add_argument("--rows-frac", default="625", help="part_rows as per-mille of lds (comma list)")
-    ap.add_argument("--threads", default="512")
-    ap.add_argument("--variants", default="1,2")
-    ap.add_argument("--items", default="4")
+    ap.add_argument("--rows-frac", default="550", help="part_rows as per-mille of lds (comma list)")
+    ap.add_argument("--threads", default="1024")
+    ap.add_argument("--variants", default="1", help="ell_variant values: 1 LDS slab counter (default), 3 static round-robin")
+    ap.add_argument("--items", default="2")
     ap.add_argument("--mode", default="2")
     ap.add_argument("--sharing", default="1", help="col_sharing values: 1 on, 2 off")
-    ap.add_argument("--fuse", default="1", help="fuse_er values: 1 residual in the ELL launch, 2 two launches ('sh' column prints sharing*10+fuse)")
+    ap.add_argument("--fuse", default="0", help="fuse_er values: 0 automatic, 1 residual inline in the ELL launch, 2 own launch ('sh' column prints sharing*10+fuse)")
     ap.add_argument("--capsplit", type=int, default=1, help="cap_split of the reorder step: 1 on, 2 off")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--rounds", type=int, default=2)
