@@ -4,10 +4,14 @@
     python bench.py --gpus N --steps K --warmup W
 
 A "step" is one SpMV of the whole matrix: y = A x through libehyb.so's HIP kernels (N = 1),
-or, for N > 1, one exchange of the x segments over RCCL followed by each rank's local
-multiply (rows are sharded by top-level partition blocks; strong scaling: the matrix is fixed).
+or, for N > 1, one exchange of x entries over RCCL plus each rank's local multiply:
+  --scaling weak (default)  the N = 1 matrix once per GPU: N such grids stacked along z, rank r
+                            generates, partitions and uploads block r only; per step a halo exchange
+                            (all_to_all of the x entries next to the block boundaries) overlapped
+                            with the ELL phase, then the residual phase on the received entries;
+  --scaling strong          the N = 1 matrix sharded by rows (two-level partition), all-gatherv of x.
 
-Workload at N = 1 (and by default at every N): BASELINE.json configs[1], audikw_1 -- as a
+Workload at N = 1 (per GPU at N > 1): BASELINE.json configs[1], audikw_1 -- as a
 statistically matched synthetic, because no .mtx file exists offline: 943,695 rows, 3 unknowns
 per node of a 68x68x69 grid truncated to 314,565 nodes, 27-point node coupling plus hashed
 second-shell couplings tuned to audikw_1's 77.65 M entries (82.3 per row), node labels
@@ -41,6 +45,91 @@ WORKLOADS = {
 }
 
 
+def timed_steps(step, args, torch, dist, world, dev):
+    """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks."""
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def run_weak(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
+    """N > 1, weak scaling: the N = 1 matrix once per GPU -- N audikw_1-like grids stacked along z,
+    rank r owning (and generating) block r only -- and a halo exchange of the x entries of the two
+    grid layers next to each block boundary.  Per-GPU work is the N = 1 workload plus ~1 % coupling."""
+    import numpy as np
+
+    from ehyb_spmv_gpu_amd import dist as D
+    from oracle import oracle as O
+
+    gen, gargs, desc = WORKLOADS[args.workload]
+    n_loc = gargs[0]
+    t0 = time.time()
+    mr = E.Matrix.generate("fem3d_block", *gargs, rank, world, cfg=cfg)
+    I, J, V = mr.I.copy(), mr.J.copy(), mr.V.copy()
+    mr.free()
+    n_glob = n_loc * world
+    cuts = [n_loc * r for r in range(world + 1)]
+    r0, r1 = cuts[rank], cuts[rank + 1]
+    log(f"[bench] rank 0 generated its block: {n_loc} rows, {len(V)} entries in {time.time() - t0:.1f}s")
+    # checker (not timed): the oracle on this rank's rows; x is a function of the global index
+    x = E.x_glibc(n_glob)
+    y_cpu = O.spmv_coo(n_glob, I, J, V, x)[r0:r1]
+    scale = O.abs_rowsum(n_glob, I, J, V, x)[r0:r1]
+    t0 = time.time()
+    L = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, symmetric=True)  # partition + permute the diagonal block, ghost slots
+    del I, J
+    sh = D.HaloSpmv(L, dev, overlap=not args.no_overlap, stage_on_cpu=stage_on_cpu)
+    sh.set_x_local(x[r0:r1])
+    st = sh.plan.stats
+    log(f"[bench] rank 0: reorder + plan in {time.time() - t0:.1f}s: ell {st['nnz_ell']} residual {st['nnz_er']} "
+        f"ghost slots {L.n_ghost} (receives from {int((L.recv_counts > 0).sum())} ranks)")
+    elapsed = timed_steps(sh.step, args, torch, dist, world, dev)
+    # parity of what was just timed, every rank on its own rows
+    bad, worst = O.check_tolerance(sh.y_local(), y_cpu, scale)
+    tot = torch.tensor([float(bad), float(len(V)), float(L.n_ghost)], dtype=torch.float64, device=dev)
+    mx = torch.tensor([float(worst), float(L.n_ghost)], dtype=torch.float64, device=dev)
+    dist.all_reduce(tot)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    bad, nnz, worst = int(tot[0].item()), int(tot[1].item()), float(mx[0].item())
+    log(f"[bench] parity vs CPU oracle (all ranks, own rows): {bad} rows over 1e-12, worst {worst:.3e}")
+    if bad:
+        raise SystemExit("bench.py: GPU result differs from the CPU oracle; refusing to report a number")
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        out = {
+            "metric": "fp64 SpMV GFLOP/s (2*nnz/t_iter), EHYB on MI355X",
+            "value": round(2.0 * nnz * args.steps / elapsed / 1e9, 2), "unit": "GFLOP/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+            "data": f"synthetic: {world} x ({desc}), stacked along z, one block per GPU",
+            "config": {"workload": args.workload, "rows": n_glob, "nnz": nnz, "rows_per_gpu": n_loc,
+                       "lds_doubles": int(cfg.lds_doubles), "part_rows": int(cfg.part_rows), "threads": int(cfg.threads),
+                       "window_mode": "halo" if cfg.window_mode != 1 else "reference",
+                       "ghost_slots_per_gpu_max": int(mx[1].item()), "ghost_slots_total": int(tot[2].item()),
+                       "exchange": "halo: gather of the requested x entries + RCCL all_to_all_single into the ghost slots, "
+                                   "overlapped with the ELL phase" if not stage_on_cpu else "halo via gloo point-to-point (functional mode)"},
+            "alg_GBps": round((12 * nnz + 4 * (n_glob + 1) + 16 * n_glob) / (elapsed / args.steps) / 1e9, 1),
+            "roofline": None, "cpu_baseline": None, "parity": {"rows_over_1e-12": bad, "worst_rel": worst},
+        }
+        print(json.dumps(out), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -54,6 +143,9 @@ def main():
     ap.add_argument("--window-mode", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange first, then multiply (no stream overlap)")
+    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
+                    help="N>1: weak = the N=1 matrix once per GPU, rank-local build, halo exchange (fem3d workloads); "
+                         "strong = the N=1 matrix sharded by rows, all-gatherv of x")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
 
@@ -98,6 +190,11 @@ def main():
     cfg = E.make_config(n_top=world, verbose=1 if (args.verbose and rank == 0) else 0, **kw)
 
     gen, gargs, desc = WORKLOADS[args.workload]
+    if world > 1 and args.scaling == "weak" and gen == "fem3d":
+        cfg.n_top = 1  # every rank partitions its own block
+        run_weak(args, E, torch, dist, rank, world, torch.device("cuda", local_rank), cfg, log, stage_on_cpu=backend != "nccl")
+        dist.destroy_process_group()
+        return
     t0 = time.time()
     m = E.Matrix.generate(gen, *gargs, cfg=cfg)
     n, nnz = m.n, m.nnz
@@ -149,24 +246,7 @@ def main():
     stream = torch.cuda.current_stream().cuda_stream
     step = sh.step  # N = 1: one SpMV; N > 1: all-gatherv of the x segments over xGMI + local multiply
 
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    t_start = time.perf_counter()
-    for _ in range(args.steps):
-        step()
-    torch.cuda.synchronize()
-    if world > 1:
-        dist.barrier()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t_start
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+    elapsed = timed_steps(step, args, torch, dist, world, dev)
 
     # ---- parity of what was just timed (rank-local rows) against the CPU oracle
     parity = None
@@ -210,7 +290,8 @@ def main():
         out = {
             "metric": "fp64 SpMV GFLOP/s (2*nnz/t_iter), EHYB on MI355X",
             "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+            "scaling": "strong" if world > 1 else args.scaling, "vs_baseline": None,
             "dtype": "f64", "data": "synthetic: " + desc,
             "config": {"workload": args.workload, "rows": n, "nnz": nnz, "parts": int(m.c.nParts),
                        "lds_doubles": int(cfg.lds_doubles), "part_rows": int(cfg.part_rows), "threads": int(cfg.threads),

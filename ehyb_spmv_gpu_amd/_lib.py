@@ -121,6 +121,9 @@ SIGNATURES = {
     "ehyb_x_glibc": (None, [C.c_int, _dp]),
     "ehyb_gen_banded": (C.c_int, [C.c_int, C.c_int, C.c_int, _cfgp, _mp]),
     "ehyb_gen_fem3d": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _cfgp, _mp]),
+    "ehyb_gen_fem3d_block": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
+                                       _cfgp, _mp]),
+    "ehyb_matrix_append_ghosts": (C.c_int, [_mp, C.c_int, C.c_int64, _ip, _ip, _dp]),
     "ehyb_gen_rmat": (C.c_int, [C.c_int, C.c_int64, C.c_uint64, _cfgp, _mp]),
     "ehyb_gen_stencil2d": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _cfgp, _mp]),
     "ehyb_gen_kkt3d": (C.c_int, [C.c_int, _cfgp, _mp]),

@@ -73,7 +73,10 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         std::vector<int> src;
         // A matrix that never went through the reorder step has nParts from the sizing rule but
         // an all-zero partBoundary: treated as "no partition information".
-        const bool have_parts = m->partBoundary && m->nParts > 0 && m->partBoundary[m->nParts] == n;
+        // The partitions may end below n: the rows behind them are the empty ghost rows of a
+        // rank-local matrix (ehyb_matrix_append_ghosts).
+        const bool have_parts = m->partBoundary && m->nParts > 0 && m->partBoundary[m->nParts] > 0 &&
+                                m->partBoundary[m->nParts] <= n && m->partBoundary[m->nParts] >= row_end;
         if (have_parts) {
             bool okb = false, oke = false;
             for (int p = 0; p <= m->nParts; ++p) {

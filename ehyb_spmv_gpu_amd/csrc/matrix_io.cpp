@@ -261,65 +261,94 @@ int ehyb_gen_banded(int n, int band, int block, const ehyb_config* cfg, matrixCO
 int ehyb_gen_fem3d(int n, int dof, int nx, int ny, int extra_ppm, int scramble, uint64_t seed,
                    const ehyb_config* cfg, matrixCOO* out)
 {
+    return ehyb_gen_fem3d_block(n, dof, nx, ny, extra_ppm, scramble, seed, 0, 1, cfg, out);
+}
+
+// Rows of block `block` of n_blocks fem3d grids stacked along z: a matrix of dimension
+// n * n_blocks whose rows outside [block*n, (block+1)*n) are empty.  Nodes are labelled
+// block by block (each block scrambled on its own), so a block's rows reference its own
+// columns plus those of the two layers next to it in the neighbouring blocks.  Every process of
+// a weak-scaling run generates its own rows only; (0, 1) is ehyb_gen_fem3d itself.
+int ehyb_gen_fem3d_block(int n, int dof, int nx, int ny, int extra_ppm, int scramble, uint64_t seed,
+                         int block, int n_blocks, const ehyb_config* cfg, matrixCOO* out)
+{
     clear_error();
     if (!out || n <= 0 || dof <= 0 || nx <= 0 || ny <= 0 || n % dof != 0 || extra_ppm < 0)
         EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_fem3d: need n %% dof == 0 and positive grid sizes");
+    if (n_blocks < 1 || block < 0 || block >= n_blocks || (int64_t)n * n_blocks > 0x7FFFFFFFll)
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_fem3d_block: block %d of %d, %d rows each", block, n_blocks, n);
     const int N = n / dof;
     const int64_t layer = (int64_t)nx * ny;
     const int nz = (int)((N + layer - 1) / layer);
-    std::vector<int> perm(N);
-    std::iota(perm.begin(), perm.end(), 0);
-    if (scramble) {
-        uint64_t s = seed ^ 0xABCDEF12345ull;
-        for (int i = N - 1; i > 0; --i) std::swap(perm[i], perm[(int)(splitmix64(s) % (uint64_t)(i + 1))]);
+    const int nzf = (int)(N / layer);  // full layers
+    if (n_blocks > 1 && nzf < 3) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_fem3d_block: a block needs at least three full grid layers");
+    // node labels of this block and of its two neighbours
+    std::vector<int> perms[3];
+    for (int o = -1; o <= 1; ++o) {
+        const int b = block + o;
+        if (b < 0 || b >= n_blocks) continue;
+        std::vector<int>& pm = perms[o + 1];
+        pm.resize(N);
+        std::iota(pm.begin(), pm.end(), 0);
+        if (scramble) {
+            uint64_t s = (seed + 0x9E3779B97F4A7C15ull * (uint64_t)b) ^ 0xABCDEF12345ull;
+            for (int i = N - 1; i > 0; --i) std::swap(pm[i], pm[(int)(splitmix64(s) % (uint64_t)(i + 1))]);
+        }
     }
+    const std::vector<int>& perm = perms[1];
     const uint64_t thr = (uint64_t)extra_ppm;
-    // neighbours of grid node g (grid numbering), including g itself
+    const int64_t grid_block = n_blocks > 1 ? (int64_t)nz * layer : 0;  // grid ids per block (last layer may be partial)
+    // neighbours of grid node g of this block, including g itself, as global node labels
     auto neighbours = [&](int g, int* nb) {
         int ix = (int)(g % nx), iy = (int)((g / nx) % ny), iz = (int)(g / layer);
         int c = 0;
         for (int dz = -2; dz <= 2; ++dz)
             for (int dy = -2; dy <= 2; ++dy)
-                for (int dx = -2; dx <= 2; ++dx) {
-                    int x = ix + dx, y = iy + dy, z = iz + dz;
-                    if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) continue;
-                    int64_t h = (int64_t)z * layer + (int64_t)y * nx + x;
-                    if (h >= N) continue;
-                    bool near = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
-                    if (!near) {
-                        if (thr == 0) continue;
-                        uint64_t lo = std::min<int64_t>(g, h), hi = std::max<int64_t>(g, h);
-                        if (mix64(lo * 0x100000001B3ull + hi + seed) % 1000000ull >= thr) continue;
+                for (int dx = -2; dx <= 2; ++dx)
+                    // Block b+1 sits on the last FULL layer of block b (height b*nzf), so that the
+                    // interface is a whole grid layer even when a block ends in a partial one; a
+                    // position may then hold a node of each block, both are neighbours.
+                    for (int o = (block > 0 ? -1 : 0); o <= (block + 1 < n_blocks ? 1 : 0); ++o) {
+                        const int x = ix + dx, y = iy + dy, z = iz + dz - o * nzf;
+                        if (x < 0 || y < 0 || z < 0 || x >= nx || y >= ny || z >= nz) continue;
+                        int64_t h = (int64_t)z * layer + (int64_t)y * nx + x;
+                        if (h >= N) continue;
+                        bool near = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
+                        if (!near) {
+                            if (thr == 0) continue;
+                            const int64_t gg = block * grid_block + g, hh = (block + o) * grid_block + h;
+                            uint64_t lo = std::min<int64_t>(gg, hh), hi = std::max<int64_t>(gg, hh);
+                            if (mix64(lo * 0x100000001B3ull + hi + seed) % 1000000ull >= thr) continue;
+                        }
+                        nb[c++] = (block + o) * N + perms[o + 1][(size_t)h];
                     }
-                    nb[c++] = (int)h;
-                }
         return c;
     };
     // pass 1: row counts
     std::vector<int> cnt(N);
 #pragma omp parallel for schedule(static, 1024)
     for (int g = 0; g < N; ++g) {
-        int nb[125];
+        int nb[256];  // 125 positions, at the block interface up to two nodes each
         cnt[perm[g]] = neighbours(g, nb);
     }
     int64_t pairs = 0;
     for (int a = 0; a < N; ++a) pairs += cnt[a];
-    int rc = alloc_matrix(n, pairs * dof * dof, out);
+    int rc = alloc_matrix(n * n_blocks, pairs * dof * dof, out);
     if (rc != EHYB_OK) return rc;
+    const int row0 = block * n;
     for (int a = 0; a < N; ++a)
-        for (int d = 0; d < dof; ++d) out->numInRow[a * dof + d] = cnt[a] * dof;
+        for (int d = 0; d < dof; ++d) out->numInRow[row0 + a * dof + d] = cnt[a] * dof;
     rc = finish_matrix(out, cfg);
     if (rc != EHYB_OK) return rc;
     // pass 2: fill, columns ascending within a row
 #pragma omp parallel for schedule(static, 1024)
     for (int g = 0; g < N; ++g) {
-        int nb[125];
+        int nb[256];  // 125 positions, at the block interface up to two nodes each
         int c = neighbours(g, nb);
-        for (int k = 0; k < c; ++k) nb[k] = perm[nb[k]];
         std::sort(nb, nb + c);
         const int a = perm[g];
         for (int d = 0; d < dof; ++d) {
-            const int i = a * dof + d;
+            const int i = row0 + a * dof + d;
             int64_t at = out->rowIdx[i];
             for (int k = 0; k < c; ++k)
                 for (int e = 0; e < dof; ++e) {
@@ -509,6 +538,82 @@ int ehyb_gen_kkt3d(int nx, const ehyb_config* cfg, matrixCOO* out)
             if (i == j) out->diag[i] = v;
         }
     }
+    return EHYB_OK;
+}
+
+// A rank's square diagonal block (already reordered: partBoundary covers [0, n_loc)) grows n_ghost
+// columns for the x entries it receives from other ranks: dimension n_loc + n_ghost, the new rows
+// empty, the coupling entries (gi = row in the block's current numbering, gj = ghost slot) merged
+// into their rows behind the local columns.  Partition data stays as it is; a plan over rows
+// [0, n_loc) with cfg.n_top > 1 sends every ghost column to the residual (phase 2), whose x is
+// [local x | receive buffer] in one allocation.
+int ehyb_matrix_append_ghosts(matrixCOO* m, int n_ghost, int64_t nnz_g, const int* gi, const int* gj, const double* gv)
+{
+    clear_error();
+    if (!m || !m->rowIdx || n_ghost < 0 || nnz_g < 0 || (nnz_g > 0 && (!gi || !gj || !gv)))
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_append_ghosts: bad arguments");
+    const int n0 = m->dimension;
+    const int64_t n1 = (int64_t)n0 + n_ghost, nnz1 = (int64_t)m->totalNum + nnz_g;
+    if (n1 > 0x7FFFFFFFll || nnz1 > 0x7FFFFFFFll) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_append_ghosts: result does not fit int counts");
+    std::vector<int> add(n0, 0);
+    for (int64_t k = 0; k < nnz_g; ++k) {
+        if ((unsigned)gi[k] >= (unsigned)n0 || (unsigned)gj[k] >= (unsigned)n_ghost)
+            EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_append_ghosts: entry %lld (%d,%d) out of range", (long long)k, gi[k], gj[k]);
+        ++add[gi[k]];
+    }
+    const size_t e = (size_t)std::max<int64_t>(nnz1, 1);
+    int* I = (int*)malloc(e * sizeof(int));
+    int* J = (int*)malloc(e * sizeof(int));
+    double* V = (double*)malloc(e * sizeof(double));
+    int* rowIdx = (int*)calloc((size_t)n1 + 1, sizeof(int));
+    auto grow = [&](auto*& p) {
+        using T = std::remove_reference_t<decltype(*p)>;
+        T* q = (T*)realloc(p, ((size_t)n1 + 1) * sizeof(T));
+        if (!q) return false;
+        memset(q + n0 + 1, 0, ((size_t)n1 - n0) * sizeof(T));  // the arrays hold n0 + 1 entries so far
+        p = q;
+        return true;
+    };
+    if (!I || !J || !V || !rowIdx || !grow(m->numInRow) || !grow(m->numInRow2) || !grow(m->partBoundary) ||
+        !grow(m->reorderList) || !grow(m->diag)) {
+        free(I), free(J), free(V), free(rowIdx);
+        EHYB_FAIL(EHYB_ERR_ALLOC, "ehyb_matrix_append_ghosts: out of memory");
+    }
+    std::vector<int> fill(n0);
+    for (int r = 0; r < n0; ++r) {
+        const int len = m->rowIdx[r + 1] - m->rowIdx[r];
+        rowIdx[r + 1] = rowIdx[r] + len + add[r];
+        std::copy(m->I + m->rowIdx[r], m->I + m->rowIdx[r + 1], I + rowIdx[r]);
+        std::copy(m->J + m->rowIdx[r], m->J + m->rowIdx[r + 1], J + rowIdx[r]);
+        std::copy(m->V + m->rowIdx[r], m->V + m->rowIdx[r + 1], V + rowIdx[r]);
+        fill[r] = rowIdx[r] + len;
+        m->numInRow[r] = len + add[r];
+        m->maxCol = std::max(m->maxCol, len + add[r]);
+    }
+    for (int64_t r = n0; r < n1; ++r) {
+        rowIdx[r + 1] = rowIdx[n0];
+        m->reorderList[r] = (int)r;
+    }
+    for (int64_t k = 0; k < nnz_g; ++k) {
+        const int at = fill[gi[k]]++;
+        I[at] = gi[k];
+        J[at] = n0 + gj[k];
+        V[at] = gv[k];
+    }
+    // ghost columns ascending within a row
+    std::vector<std::pair<int, double>> tmp;
+    for (int r = 0; r < n0; ++r) {
+        if (add[r] < 2) continue;
+        const int b = rowIdx[r + 1] - add[r];
+        tmp.resize(add[r]);
+        for (int k = 0; k < add[r]; ++k) tmp[k] = {J[b + k], V[b + k]};
+        std::sort(tmp.begin(), tmp.end(), [](const std::pair<int, double>& a, const std::pair<int, double>& c) { return a.first < c.first; });
+        for (int k = 0; k < add[r]; ++k) J[b + k] = tmp[k].first, V[b + k] = tmp[k].second;
+    }
+    free(m->I), free(m->J), free(m->V), free(m->rowIdx);
+    m->I = I, m->J = J, m->V = V, m->rowIdx = rowIdx;
+    m->dimension = (int)n1;
+    m->totalNum = (int)nnz1;
     return EHYB_OK;
 }
 

@@ -90,3 +90,185 @@ class ShardedSpmv:
 
     def local_y(self):
         return self.y[self.r0:self.r1]
+
+
+# ======================================================================================
+# Rank-local build with a halo exchange.
+#
+# ShardedSpmv above needs the whole matrix on every rank and moves the whole of x every
+# iteration.  At scale neither is acceptable: a rank should hold its own rows only and receive
+# only the x entries its rows reference.  The classes below do that:
+#
+#   RankLocalMatrix   rows [r0, r1) of the global matrix (global column labels) ->
+#                       * the square diagonal block, partitioned and permuted by
+#                         ehyb_matrix_reorder on this rank alone,
+#                       * "ghost" columns: one slot per distinct remote column, ordered by owner
+#                         rank and then by global label, appended behind the local columns
+#                         (ehyb_matrix_append_ghosts),
+#                       * the send lists: which of its own (permuted) x entries every peer wants.
+#   HaloExchange      per iteration: gather the send entries into one buffer, one all_to_all
+#                     (RCCL over xGMI; point-to-point pairs on gloo) straight into the ghost part
+#                     of x = [local x | ghosts].
+#   HaloSpmv          the rank's multiply: phase 1 (ELL, local columns) runs while the exchange is
+#                     in flight on a side stream, phase 2 (residual = all ghost columns) after it.
+#
+# Exchange volume per rank = number of ghost slots, not the length of x: for a mesh-like matrix
+# cut into slabs that is the two interface layers, a few per cent of the rank's rows.
+def _copy_cfg(cfg, **kw):
+    c = type(cfg).from_buffer_copy(cfg) if cfg is not None else H.make_config()
+    for k, v in kw.items():
+        setattr(c, k, v)
+    return c
+
+
+class RankLocalMatrix:
+    def __init__(self, I, J, V, cuts, rank, cfg=None, symmetric=False, group=None):
+        """I, J, V: this rank's rows in global labels, row-grouped (I ascending).  cuts: first row of
+        every rank, world+1 entries.  Collective: every rank of `group` must call it."""
+        world = len(cuts) - 1
+        self.rank, self.world, self.cuts, self.group = rank, world, [int(c) for c in cuts], group
+        r0, r1 = self.cuts[rank], self.cuts[rank + 1]
+        self.r0, self.r1, self.n_loc = r0, r1, r1 - r0
+        I = np.asarray(I)
+        J = np.asarray(J)
+        V = np.asarray(V, dtype=np.float64)
+        if len(I) and (I.min() < r0 or I.max() >= r1 or np.any(np.diff(I) < 0)):
+            raise ValueError("RankLocalMatrix: rows must lie in [r0, r1) and be grouped in ascending order")
+        own = (J >= r0) & (J < r1)
+        # diagonal block: a masked row-grouped sequence is still row-grouped
+        indptr = np.zeros(self.n_loc + 1, dtype=np.int64)
+        np.cumsum(np.bincount(I[own] - r0, minlength=self.n_loc), out=indptr[1:])
+        cfg1 = _copy_cfg(cfg, n_top=1)
+        self.m = H.Matrix.from_csr(indptr, J[own] - r0, V[own], cfg1, symmetric=symmetric)
+        self.m.reorder(cfg1)
+        self.perm = self.m.reorder_list[:self.n_loc].copy()  # local row i (unpermuted) -> its place in the plan
+        # ghost slots: distinct remote columns, ascending = grouped by owner
+        off = ~own
+        Jg = J[off]
+        gcols = np.unique(Jg)
+        owner = np.searchsorted(np.asarray(self.cuts), gcols, side="right") - 1
+        self.n_ghost = len(gcols)
+        self.ghost_cols = gcols
+        self.recv_counts = np.bincount(owner, minlength=world).astype(np.int64)
+        assert self.recv_counts[rank] == 0
+        wants = [gcols[owner == p] for p in range(world)]
+        # what the peers want from me, in their slot order
+        if world > 1:
+            import torch.distributed as dist
+
+            everyone = [None] * world
+            dist.all_gather_object(everyone, wants, group=group)
+        else:
+            everyone = [wants]
+        asked = [np.asarray(everyone[q][rank], dtype=np.int64) for q in range(world)]
+        for a in asked:
+            if len(a) and (a.min() < r0 or a.max() >= r1):
+                raise ValueError("RankLocalMatrix: a peer asked for a column this rank does not own")
+        self.send_counts = np.array([len(a) for a in asked], dtype=np.int64)
+        self.send_idx = np.concatenate([self.perm[a - r0] for a in asked]).astype(np.int64) if world > 1 else np.zeros(0, np.int64)
+        # the coupling entries, rows in plan numbering, columns = ghost slots
+        self.m.append_ghosts(self.n_ghost, self.perm[I[off] - r0], np.searchsorted(gcols, Jg), V[off])
+        self.nnz = len(V)
+        self.cfg_plan = _copy_cfg(cfg, n_top=2 if world > 1 else 1)
+
+    def plan(self, upload=True):
+        return H.Plan(self.m, self.cfg_plan, rows=(0, self.n_loc), upload=upload)
+
+    def x_to_plan(self, x_local):
+        """Local x segment (global label order) -> plan order."""
+        return H.vector_reorder(x_local, self.perm)
+
+    def y_from_plan(self, y_plan):
+        return H.vector_recover(y_plan, self.perm)
+
+
+class HaloExchange:
+    """x_ext = [local x (plan order) | ghost slots]; run() refreshes the ghost slots from the peers."""
+
+    def __init__(self, local, x_ext, group=None, stage_on_cpu=False):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.L, self.group, self.x_ext = local, group, x_ext
+        dev = x_ext.device
+        self.send_idx = torch.from_numpy(local.send_idx).to(dev)
+        self.send_buf = torch.empty(len(local.send_idx), dtype=torch.float64, device=dev)
+        self.ghosts = x_ext[local.n_loc:]
+        self.send_counts = [int(c) for c in local.send_counts]
+        self.recv_counts = [int(c) for c in local.recv_counts]
+        self.a2a = local.world > 1 and dist.get_backend(group) == "nccl"
+        self.stage = stage_on_cpu and dev.type != "cpu"  # gloo cannot move GPU tensors point to point
+
+    def pack(self):
+        if len(self.send_idx):
+            self.torch.index_select(self.x_ext[:self.L.n_loc], 0, self.send_idx, out=self.send_buf)
+
+    def transfer(self):
+        L, dist, torch = self.L, self.dist, self.torch
+        if L.world == 1:
+            return
+        if self.a2a:
+            dist.all_to_all_single(self.ghosts, self.send_buf, self.recv_counts, self.send_counts, group=self.group)
+            return
+        send, recv = (self.send_buf.cpu(), torch.empty(L.n_ghost, dtype=torch.float64)) if self.stage else (self.send_buf, self.ghosts)
+        ops, so, ro = [], 0, 0
+        for q in range(L.world):
+            peer = dist.get_global_rank(self.group, q) if self.group else q
+            if self.send_counts[q]:
+                ops.append(dist.P2POp(dist.isend, send[so:so + self.send_counts[q]], peer, group=self.group))
+            if self.recv_counts[q]:
+                ops.append(dist.P2POp(dist.irecv, recv[ro:ro + self.recv_counts[q]], peer, group=self.group))
+            so += self.send_counts[q]
+            ro += self.recv_counts[q]
+        for r in (dist.batch_isend_irecv(ops) if ops else []):
+            r.wait()
+        if self.stage:
+            self.ghosts.copy_(recv)
+
+    def run(self):
+        self.pack()
+        self.transfer()
+
+
+class HaloSpmv:
+    """One rank's multiply of a RankLocalMatrix on its GPU: y_loc = A[r0:r1, :] x."""
+
+    def __init__(self, local, device, overlap=True, stage_on_cpu=False):
+        import torch
+
+        self.torch = torch
+        self.L = local
+        self.plan = local.plan()
+        self.x = torch.zeros(local.n_loc + local.n_ghost, dtype=torch.float64, device=device)
+        self.y = torch.zeros(local.n_loc, dtype=torch.float64, device=device)
+        self.halo = HaloExchange(local, self.x, local.group, stage_on_cpu=stage_on_cpu)
+        self.overlap = overlap and local.world > 1
+        self.comm_stream = torch.cuda.Stream(device=device) if self.overlap else None
+
+    def set_x_local(self, x_local):
+        """x_local: this rank's x segment in global label order."""
+        self.x[:self.L.n_loc].copy_(self.torch.from_numpy(self.L.x_to_plan(x_local)))
+
+    def step(self):
+        torch = self.torch
+        cur = torch.cuda.current_stream()
+        xp, yp = self.x.data_ptr(), self.y.data_ptr()
+        if self.L.world == 1:
+            self.plan.spmv(xp, yp, cur.cuda_stream)
+            return
+        self.halo.pack()
+        if not self.overlap:
+            self.halo.transfer()
+            self.plan.spmv(xp, yp, cur.cuda_stream)
+            return
+        self.comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self.comm_stream):
+            self.halo.transfer()
+        self.plan.spmv(xp, yp, cur.cuda_stream, phase=1)  # local columns only
+        cur.wait_stream(self.comm_stream)
+        self.plan.spmv(xp, yp, cur.cuda_stream, phase=2)  # ghost columns
+
+    def y_local(self):
+        """This rank's y segment in global label order (host array)."""
+        return self.L.y_from_plan(self.y.cpu().numpy())

@@ -124,6 +124,10 @@ class Matrix:
             n, dof, nx, ny, ppm, scramble, seed = args
             rc = m.lib.ehyb_gen_fem3d(n, dof, nx, ny, ppm, scramble, seed, cp, C.byref(m.c))
             m.symmetric = True
+        elif kind == "fem3d_block":
+            n, dof, nx, ny, ppm, scramble, seed, block, n_blocks = args
+            rc = m.lib.ehyb_gen_fem3d_block(n, dof, nx, ny, ppm, scramble, seed, block, n_blocks, cp, C.byref(m.c))
+            m.symmetric = n_blocks == 1
         elif kind == "rmat":
             scale, edges, seed = args
             rc = m.lib.ehyb_gen_rmat(scale, edges, seed, cp, C.byref(m.c))
@@ -196,6 +200,17 @@ class Matrix:
         sym = self.symmetric if symmetric is None else symmetric
         _check(self.lib.ehyb_matrix_reorder(C.byref(self.c), 1 if sym else 0, C.byref(cfg) if cfg else None),
                "ehyb_matrix_reorder")
+        return self
+
+    def append_ghosts(self, n_ghost, gi, gj, gv):
+        """Rank-local multi-GPU build: add n_ghost receive-buffer columns and the entries coupling
+        to them (ehyb_matrix_append_ghosts)."""
+        gi = np.ascontiguousarray(gi, dtype=np.int32)
+        gj = np.ascontiguousarray(gj, dtype=np.int32)
+        gv = np.ascontiguousarray(gv, dtype=np.float64)
+        _check(self.lib.ehyb_matrix_append_ghosts(C.byref(self.c), int(n_ghost), len(gi), _ptr(gi, C.c_int), _ptr(gj, C.c_int),
+                                                  _ptr(gv, C.c_double)), "ehyb_matrix_append_ghosts")
+        self.symmetric = False
         return self
 
     def write_mtx(self, path, symmetric_lower_only=False):

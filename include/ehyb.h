@@ -294,6 +294,16 @@ int ehyb_mm_write(const char* path, const matrixCOO* m, int symmetric_lower_only
 int ehyb_matrix_from_csr(int n, const int64_t* rowptr, const int* cols, const double* vals,
                          const ehyb_config* cfg, matrixCOO* out);
 void ehyb_matrix_free(matrixCOO* m);
+/*
+ * Multi-GPU, rank-local build (no reference counterpart -- the reference is single-GPU).
+ * m is a rank's square diagonal block after ehyb_matrix_reorder.  It grows n_ghost columns, one
+ * per x entry the rank receives from other ranks, and the nnz_g coupling entries (gi[k] = row in
+ * m's current numbering, gj[k] in [0, n_ghost), gv[k]); the n_ghost new rows stay empty and the
+ * partition data is kept.  A plan over rows [0, old dimension) with cfg.n_top > 1 then multiplies
+ * the ghost columns in phase 2 from x = [local x | receive buffer].
+ */
+int ehyb_matrix_append_ghosts(matrixCOO* m, int n_ghost, int64_t nnz_g,
+                              const int* gi, const int* gj, const double* gv);
 
 /* x[i]: srand(i); (rand()%200-100)/1000.0  -- solver_test.c:89-92, 228-231 (glibc rand). */
 void ehyb_x_glibc(int n, double* x);
@@ -310,6 +320,12 @@ int ehyb_gen_banded(int n, int band, int block, const ehyb_config* cfg, matrixCO
  * symmetric values; scramble != 0 applies a random relabelling of the nodes.            */
 int ehyb_gen_fem3d(int n, int dof, int nx, int ny, int extra_ppm, int scramble, uint64_t seed,
                    const ehyb_config* cfg, matrixCOO* out);
+/* The rows of block `block` of n_blocks such grids stacked along z (weak scaling: one block per
+ * GPU, each rank generates only its own rows): dimension n*n_blocks, rows outside
+ * [block*n, (block+1)*n) empty, every block labelled (scrambled) on its own, couplings reach two
+ * grid layers into the neighbouring blocks.  (block, n_blocks) = (0, 1) is ehyb_gen_fem3d. */
+int ehyb_gen_fem3d_block(int n, int dof, int nx, int ny, int extra_ppm, int scramble, uint64_t seed,
+                         int block, int n_blocks, const ehyb_config* cfg, matrixCOO* out);
 /* R-MAT (a,b,c,d)=(.57,.19,.19,.05), 2^scale rows, `edges` samples, duplicates merged */
 int ehyb_gen_rmat(int scale, int64_t edges, uint64_t seed, const ehyb_config* cfg, matrixCOO* out);
 /* 2-D 5/9-point stencil plus `extra` random symmetric couplings (small test inputs) */

@@ -1,0 +1,82 @@
+"""Worker for tests/test_distributed_cpu.py::test_halo_path_gloo: the rank-local build and the
+halo exchange (ehyb_spmv_gpu_amd.dist: RankLocalMatrix, HaloExchange) under gloo on CPU.  The
+multiply itself is the oracle's CPU walk of the rank's plan over x = [local x | ghost slots]."""
+import os
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+import ehyb_spmv_gpu_amd as E  # noqa: E402
+from ehyb_spmv_gpu_amd import dist as D  # noqa: E402
+from oracle import oracle as O  # noqa: E402
+
+
+def check_rank(tag, I, J, V, cuts, rank, world, cfg, symmetric):
+    n_glob = cuts[-1]
+    r0, r1 = cuts[rank], cuts[rank + 1]
+    x = O.x_glibc(n_glob)                       # every rank can compute any x entry: x is a function of the index
+    y_ref = O.spmv_coo(n_glob, I, J, V, x)[r0:r1]
+    scale = O.abs_rowsum(n_glob, I, J, V, x)[r0:r1]
+    L = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, symmetric=symmetric)
+    assert L.m.n == L.n_loc + L.n_ghost and L.m.nnz == len(V)
+    assert int(L.recv_counts.sum()) == L.n_ghost and L.recv_counts[rank] == 0 and L.send_counts[rank] == 0
+    plan = L.plan(upload=False)
+    st = plan.stats
+    # phase 1 must not touch a ghost slot: window columns are local
+    hc = plan.array("halo_cols")
+    assert len(hc) == 0 or hc.max() < L.n_loc
+    assert st["er_inline"] == 0 or world == 1
+    # every entry that references a remote column is in the residual
+    remote = int(((J < r0) | (J >= r1)).sum())
+    assert st["nnz_er"] >= remote and (world > 1 or remote == 0)
+    x_ext = torch.zeros(L.n_loc + L.n_ghost, dtype=torch.float64)
+    x_ext[:L.n_loc] = torch.from_numpy(L.x_to_plan(x[r0:r1]))
+    D.HaloExchange(L, x_ext).run()
+    assert np.array_equal(x_ext[L.n_loc:].numpy(), x[L.ghost_cols]), "ghost slots do not hold the owners' x entries"
+    y_plan, written = O.walk_plan(plan, x_ext.numpy())
+    assert written[:L.n_loc].min() == 1 and written.sum() == L.n_loc
+    y = L.y_from_plan(y_plan[:L.n_loc])
+    bad, worst = O.check_tolerance(y, y_ref, scale)
+    tot = torch.tensor([float(L.n_ghost), float(len(V)), float(bad)], dtype=torch.float64)
+    dist.all_reduce(tot)
+    if rank == 0:
+        print(f"HALO_CASE {tag} world={world} ghosts_total={int(tot[0])} nnz_total={int(tot[1])} bad={int(tot[2])} worst0={worst:.2e}", flush=True)
+    return int(tot[2])
+
+
+def main():
+    dist.init_process_group("gloo")
+    rank, world = dist.get_rank(), dist.get_world_size()
+    bad = 0
+    # 1. weak scaling: one fem3d block per rank, each rank generates its own rows only
+    n = 9000
+    cfg = E.make_config(lds_doubles=512)
+    m = E.Matrix.generate("fem3d_block", n, 3, 12, 12, 20000, 1, 7, rank, world, cfg=cfg)
+    cuts = [n * r for r in range(world + 1)]
+    bad += check_rank("fem3d_block", m.I.copy(), m.J.copy(), m.V.copy(), cuts, rank, world, cfg, symmetric=False)
+    # 2. a matrix with no locality cut into ragged row ranges: nearly every column is a ghost somewhere
+    cfg = E.make_config(lds_doubles=256)
+    g = E.Matrix.generate("rmat", 12, 1 << 15, 2, cfg=cfg)
+    base = [0, 1500, 2600, 4096][:world] + [g.n] if world <= 3 else [g.n * r // world for r in range(world + 1)]
+    rp = g.row_idx
+    a, b = int(rp[base[rank]]), int(rp[base[rank + 1]])
+    bad += check_rank("rmat-rows", g.I[a:b].copy(), g.J[a:b].copy(), g.V[a:b].copy(), base, rank, world, cfg, symmetric=False)
+    # 3. block diagonal: no ghosts at all, the exchange is empty
+    cfg = E.make_config(lds_doubles=1024, window_mode=1, partitioner=1)
+    g = E.Matrix.generate("banded", 2048, 16, 1024, cfg=cfg)
+    cuts = [2048 * r for r in range(world + 1)]
+    bad += check_rank("block-diagonal", g.I + 2048 * rank, g.J + 2048 * rank, g.V.copy(), cuts, rank, world, cfg, symmetric=False)
+    dist.barrier()
+    if rank == 0:
+        print("HALO_OK" if bad == 0 else f"HALO_FAIL {bad}", flush=True)
+    dist.destroy_process_group()
+    sys.exit(0 if bad == 0 else 1)
+
+
+if __name__ == "__main__":
+    main()

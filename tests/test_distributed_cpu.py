@@ -24,3 +24,16 @@ def test_sharded_path_gloo(world):
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "DIST_OK" in p.stdout, p.stdout[-3000:]
     assert p.stdout.count("DIST_CASE") == 3
+
+
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_halo_path_gloo(world):
+    """Rank-local build + halo exchange: each rank holds only its own rows and receives only the x
+    entries they reference (ghost slots), checked against the oracle on the rank's rows."""
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(HERE, "halo_worker.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
+    assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
+    assert "HALO_OK" in p.stdout, p.stdout[-3000:]
+    assert p.stdout.count("HALO_CASE") == 3
