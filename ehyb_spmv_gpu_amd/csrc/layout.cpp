@@ -270,7 +270,9 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     // The CSR segments are built as well, so the two-phase call of the same plan still works.
     L->inline_er = cfg.n_top <= 1 && nnz_er > 0 && (cfg.fuse_er == 1 || (cfg.fuse_er != 2 && nnz_er * 500 < nnz));
     if (L->inline_er) {
-        const int max_ner = cfg.fuse_er == 1 ? 255 : 8;
+        // every lane of a slab gets as many residual pairs as the slab's longest residual row: fine
+        // for a handful of rows (hub rows moved out of the ELL part whole), not for many long ones
+        int64_t padded = 0;
         for (int p = 0; p < np && L->inline_er; ++p) {
             PartScratch& S = ps[p];
             S.slab_ner.assign(S.slab_w2.size(), 0);
@@ -278,9 +280,11 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 const int64_t c = er_rp[r - row_begin + 1] - er_rp[r - row_begin];
                 uint32_t& ner = S.slab_ner[(r - pb[p]) / kSlabRows];
                 ner = std::max<uint32_t>(ner, (uint32_t)std::min<int64_t>((c + 1) / 2, 1 << 20));
-                if ((int)ner > max_ner) L->inline_er = false;  // a long residual row: the CSR kernel is the better tool
+                if (ner > 255) L->inline_er = false;  // a long residual row: the CSR kernel is the better tool
             }
+            for (uint32_t ner : S.slab_ner) padded += (int64_t)ner * 2 * kSlabRows;
         }
+        if (cfg.fuse_er != 1 && padded * 100 > nnz) L->inline_er = false;  // the slices would add > 1 % (x 2: 24 B each) traffic
     }
 
     // ---- pass 2: prefix sums
