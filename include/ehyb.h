@@ -226,8 +226,9 @@ int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int
  * y = A*x on `stream` (a hipStream_t passed as void*; NULL = the null stream).
  * x and y are DEVICE pointers to full-length vectors in the permuted numbering
  * (x: n_cols doubles; y: rows [row_begin,row_end) of it are written).  Asynchronous.
- * Two launches: ehyb_ell_kernel then ehyb_er_kernel (skipped when the residual is
- * empty).  Replaces matrixVectorEHYB / matrixVectorEHYB_small (kernel.cu:490-552).
+ * One launch (ehyb_ell_kernel) when the residual is empty or tiny enough to ride inside
+ * it (stats.er_inline > 0), else two: ehyb_ell_kernel then ehyb_er_kernel.
+ * Replaces matrixVectorEHYB / matrixVectorEHYB_small (kernel.cu:490-552).
  */
 int ehyb_spmv(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream);
 
