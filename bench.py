@@ -187,6 +187,10 @@ def main():
                  ("items_per_cu", args.items_per_cu), ("window_mode", args.window_mode)):
         if v:
             kw[k] = v
+    if world > 1 and os.environ.get("OMP_NUM_THREADS") == "1":
+        # torch.distributed.run pins every rank to one OpenMP thread; the host pre-step (partitioner,
+        # layout builder) of each rank gets its share of the node's cores instead
+        kw["host_threads"] = max(1, (os.cpu_count() or world) // world)
     cfg = E.make_config(n_top=world, verbose=1 if (args.verbose and rank == 0) else 0, **kw)
 
     gen, gargs, desc = WORKLOADS[args.workload]

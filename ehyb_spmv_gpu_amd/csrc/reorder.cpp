@@ -14,6 +14,7 @@
 #include "ehyb_internal.h"
 
 #include <dlfcn.h>
+#include <omp.h>
 
 #include <algorithm>
 #include <numeric>
@@ -114,6 +115,7 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
         !m->numInRow || !m->numInRow2 || !m->partBoundary || !m->reorderList)
         EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_reorder: incomplete matrixCOO");
     Config c = resolve_config(cfg);
+    if (c.host_threads > 0) omp_set_num_threads(c.host_threads);
     const int n = m->dimension;
     const int64_t nnz = m->totalNum;
     int nparts = m->nParts;

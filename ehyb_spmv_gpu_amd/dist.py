@@ -13,6 +13,7 @@ phase 1 on the compute stream while the exchange is in flight on a side stream.
 torch is plumbing here: device buffers, streams and the collective.  The kernels are libehyb.so's.
 """
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -197,7 +198,8 @@ class HaloExchange:
         self.ghosts = x_ext[local.n_loc:]
         self.send_counts = [int(c) for c in local.send_counts]
         self.recv_counts = [int(c) for c in local.recv_counts]
-        self.a2a = local.world > 1 and dist.get_backend(group) == "nccl"
+        # RCCL: one all_to_all_single with uneven splits; EHYB_HALO_P2P=1 forces grouped send/recv pairs
+        self.a2a = local.world > 1 and dist.get_backend(group) == "nccl" and os.environ.get("EHYB_HALO_P2P") != "1"
         self.stage = stage_on_cpu and dev.type != "cpu"  # gloo cannot move GPU tensors point to point
 
     def pack(self):
