@@ -98,6 +98,9 @@ SIGNATURES = {
     "ehyb_plan_upload": (C.c_int, [_vp]),
     "ehyb_plan_create": (C.c_int, [_mp, _cfgp, _P(_vp)]),
     "ehyb_plan_destroy": (None, [_vp]),
+    "ehyb_matrix_key": (C.c_uint64, [_mp]),
+    "ehyb_plan_save": (C.c_int, [_vp, _ip, C.c_uint64, C.c_char_p]),
+    "ehyb_plan_load": (C.c_int, [C.c_char_p, C.c_uint64, _P(_vp), _ip]),
     "ehyb_plan_stats": (C.c_int, [_vp, _P(Stats)]),
     "ehyb_plan_host_array": (C.c_int, [_vp, C.c_int, _P(_vp), _i64p]),
     "ehyb_spmv": (C.c_int, [_vp, _vp, _vp, _vp]),

@@ -134,6 +134,7 @@ struct ehyb_plan {
     ehyb::HostLayout host;
     bool uploaded = false;
     int device = -1;
+    std::vector<int32_t> perm;  // reorderList a cached plan was saved with (ehyb_plan_load), else empty
     // device arrays (same names as HostLayout; what the kernels do not read stays on the host)
     int32_t* d_halo_cols = nullptr;
     int32_t* d_segs = nullptr;

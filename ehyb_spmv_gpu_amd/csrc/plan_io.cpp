@@ -1,0 +1,176 @@
+// On-disk cache of a plan: the permutation and the finished EHYB layout in one file, so that the
+// partitioner and the layout builder run once per matrix.  The reference redoes
+// mt-metis + COO2EHYB on every run (solver_test.c:369-382, spmv.cu:74); on the bench matrix that
+// is seconds of host work in front of a 0.14 ms multiply.
+//
+// File: "EHYBPLN2", key, resolved Config, layout scalars, stats, then every array as
+// {u64 count, bytes}, then "EHYBEND2".  Native byte order, same-machine cache -- not an
+// interchange format.  A file whose magic, version, key or sizes do not fit is rejected.
+#include "ehyb_internal.h"
+
+#include <cstdio>
+#include <memory>
+#include <new>
+#include <type_traits>
+
+using namespace ehyb;
+
+namespace {
+
+const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '2'};
+const char kEnd[8] = {'E', 'H', 'Y', 'B', 'E', 'N', 'D', '2'};
+
+struct FileCloser {
+    void operator()(FILE* f) const
+    {
+        if (f) fclose(f);
+    }
+};
+using File = std::unique_ptr<FILE, FileCloser>;
+
+template <class T>
+bool put(FILE* f, const T& v)
+{
+    static_assert(std::is_trivially_copyable<T>::value, "raw write");
+    return fwrite(&v, sizeof(T), 1, f) == 1;
+}
+template <class T>
+bool get(FILE* f, T& v)
+{
+    return fread(&v, sizeof(T), 1, f) == 1;
+}
+template <class T>
+bool put_vec(FILE* f, const std::vector<T>& v)
+{
+    const uint64_t n = v.size();
+    return put(f, n) && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
+}
+template <class T>
+bool get_vec(FILE* f, std::vector<T>& v, uint64_t limit)
+{
+    uint64_t n = 0;
+    if (!get(f, n) || n > limit) return false;
+    v.resize(n);
+    return n == 0 || fread(v.data(), sizeof(T), n, f) == n;
+}
+
+// Every array of the layout, in file order.
+template <class F>
+bool each_array(HostLayout& H, F&& io)
+{
+    return io(H.part_boundary) && io(H.win_len) && io(H.halo_ptr) && io(H.halo_cols) && io(H.slab_pair_ptr) &&
+           io(H.slab_row) && io(H.slab_part) && io(H.ell_val) && io(H.ell_col) && io(H.slab_col_ptr) && io(H.lane_group) &&
+           io(H.slab_meta) && io(H.items) && io(H.segs) && io(H.er_seg_ptr) && io(H.er_seg_row) && io(H.er_col) &&
+           io(H.er_val) && io(H.er_blocks);
+}
+
+struct Scalars {
+    int32_t n_cols, row_begin, row_end, n_parts, lds_doubles, inline_er;
+    int32_t er_bins[8];
+};
+
+}  // namespace
+
+extern "C" {
+
+// Order-sensitive 64-bit digest of the matrix a plan was built from (dimension, entry count,
+// coordinates and values as stored).  0 is never returned: it means "do not check" to ehyb_plan_load.
+uint64_t ehyb_matrix_key(const matrixCOO* m)
+{
+    if (!m) return 1;
+    uint64_t h = mix64(0x45485942ull ^ (uint64_t)(uint32_t)m->dimension) ^ mix64((uint64_t)(uint32_t)m->totalNum + 0x9E37ull);
+    const int64_t nnz = m->totalNum;
+    if (m->I && m->J && m->V) {
+        // four independent lanes, so the loop is not one long multiply chain
+        uint64_t a[4] = {h, h ^ 0x1111, h ^ 0x2222, h ^ 0x3333};
+        for (int64_t k = 0; k < nnz; ++k) {
+            uint64_t bits;
+            memcpy(&bits, &m->V[k], 8);
+            const uint64_t w = ((uint64_t)(uint32_t)m->I[k] << 32 | (uint32_t)m->J[k]) ^ (bits * 0x9E3779B97F4A7C15ull);
+            uint64_t& s = a[k & 3];
+            s = (s ^ w) * 0xBF58476D1CE4E5B9ull;
+            s ^= s >> 29;
+        }
+        h = mix64(a[0]) ^ mix64(a[1] + 1) ^ mix64(a[2] + 2) ^ mix64(a[3] + 3);
+    }
+    return h ? h : 1;
+}
+
+int ehyb_plan_save(const ehyb_plan* plan, const int* reorder_list, uint64_t matrix_key, const char* path)
+{
+    clear_error();
+    if (!plan || !path) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_save: null argument");
+    HostLayout& H = const_cast<HostLayout&>(plan->host);  // each_array takes non-const; nothing is modified
+    File f(fopen(path, "wb"));
+    if (!f) EHYB_FAIL(EHYB_ERR_IO, "ehyb_plan_save: cannot create %s", path);
+    Scalars s{H.n_cols, H.row_begin, H.row_end, H.n_parts, H.lds_doubles, H.inline_er ? 1 : 0, {0}};
+    memcpy(s.er_bins, H.er_bins, sizeof s.er_bins);
+    std::vector<int32_t> perm;
+    if (reorder_list) perm.assign(reorder_list, reorder_list + H.n_cols);
+    bool ok = fwrite(kMagic, 8, 1, f.get()) == 1 && put(f.get(), matrix_key) && put(f.get(), plan->cfg) && put(f.get(), s) &&
+              put(f.get(), H.stats) && put_vec(f.get(), perm) &&
+              each_array(H, [&](auto& v) { return put_vec(f.get(), v); }) && fwrite(kEnd, 8, 1, f.get()) == 1;
+    FILE* raw = f.release();
+    ok = (fclose(raw) == 0) && ok;
+    if (!ok) {
+        remove(path);
+        EHYB_FAIL(EHYB_ERR_IO, "ehyb_plan_save: write to %s failed", path);
+    }
+    return EHYB_OK;
+}
+
+int ehyb_plan_load(const char* path, uint64_t expect_key, ehyb_plan** plan, int* reorder_list)
+{
+    clear_error();
+    if (!path || !plan) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_load: null argument");
+    *plan = nullptr;
+    File f(fopen(path, "rb"));
+    if (!f) EHYB_FAIL(EHYB_ERR_IO, "ehyb_plan_load: cannot open %s", path);
+    char magic[8];
+    uint64_t key = 0;
+    if (fread(magic, 8, 1, f.get()) != 1 || memcmp(magic, kMagic, 8) != 0 || !get(f.get(), key))
+        EHYB_FAIL(EHYB_ERR_FORMAT, "ehyb_plan_load: %s is not a plan file of this version", path);
+    if (expect_key != 0 && key != expect_key)
+        EHYB_FAIL(EHYB_ERR_FORMAT, "ehyb_plan_load: %s was built from another matrix (key %016llx, expected %016llx)", path,
+                  (unsigned long long)key, (unsigned long long)expect_key);
+    std::unique_ptr<ehyb_plan> P(new (std::nothrow) ehyb_plan());
+    if (!P) EHYB_FAIL(EHYB_ERR_ALLOC, "ehyb_plan_load: out of memory");
+    Scalars s;
+    HostLayout& H = P->host;
+    std::vector<int32_t> perm;
+    const uint64_t limit = 1ull << 36;  // sanity bound for any array count
+    try {
+        bool ok = get(f.get(), P->cfg) && get(f.get(), s) && get(f.get(), H.stats) && get_vec(f.get(), perm, limit) &&
+                  each_array(H, [&](auto& v) { return get_vec(f.get(), v, limit); });
+        char end[8];
+        ok = ok && fread(end, 8, 1, f.get()) == 1 && memcmp(end, kEnd, 8) == 0;
+        if (!ok) EHYB_FAIL(EHYB_ERR_FORMAT, "ehyb_plan_load: %s is truncated or damaged", path);
+    } catch (const std::bad_alloc&) {
+        EHYB_FAIL(EHYB_ERR_ALLOC, "ehyb_plan_load: out of memory reading %s", path);
+    }
+    H.n_cols = s.n_cols, H.row_begin = s.row_begin, H.row_end = s.row_end, H.n_parts = s.n_parts;
+    H.lds_doubles = s.lds_doubles, H.inline_er = s.inline_er != 0;
+    memcpy(H.er_bins, s.er_bins, sizeof s.er_bins);
+    // the sizes the kernels rely on must fit together -- a damaged file must not reach the GPU
+    const size_t nslab = H.slab_row.size(), nseg = H.er_seg_row.size();
+    const bool consistent =
+        H.n_cols > 0 && H.row_begin >= 0 && H.row_end <= H.n_cols && H.row_begin < H.row_end && H.n_parts >= 1 &&
+        H.part_boundary.size() == (size_t)H.n_parts + 1 && H.win_len.size() == (size_t)H.n_parts &&
+        H.halo_ptr.size() == (size_t)H.n_parts + 1 && H.halo_cols.size() == (size_t)H.halo_ptr.back() &&
+        H.slab_pair_ptr.size() == nslab + 1 && H.slab_col_ptr.size() == nslab + 1 && H.slab_part.size() == nslab &&
+        H.slab_meta.size() == nslab * 4 && H.lane_group.size() == nslab * kSlabRows &&
+        H.ell_val.size() == (size_t)H.slab_pair_ptr.back() * 2 * kSlabRows && H.ell_col.size() == (size_t)H.slab_col_ptr.back() &&
+        H.items.size() % 8 == 0 && H.segs.size() % 8 == 0 && H.er_seg_ptr.size() == nseg + 1 &&
+        H.er_col.size() == (size_t)H.er_seg_ptr.back() && H.er_val.size() == H.er_col.size() && H.er_blocks.size() % 4 == 0 &&
+        H.lds_doubles > 0 && H.lds_doubles <= EHYB_LDS_MAX_DOUBLES && (perm.empty() || perm.size() == (size_t)H.n_cols);
+    if (!consistent) EHYB_FAIL(EHYB_ERR_FORMAT, "ehyb_plan_load: %s holds inconsistent array sizes", path);
+    if (reorder_list) {
+        if (perm.empty()) EHYB_FAIL(EHYB_ERR_FORMAT, "ehyb_plan_load: %s holds no permutation", path);
+        std::copy(perm.begin(), perm.end(), reorder_list);
+    }
+    P->perm.swap(perm);  // also readable through ehyb_plan_host_array(EHYB_ARR_PERM)
+    *plan = P.release();
+    return EHYB_OK;
+}
+
+}  // extern "C"

@@ -60,7 +60,9 @@ static std::vector<long long> split_numbers(const char* s)
 
 static void usage()
 {
-    printf("usage: solver_test -i <iters> (-m <name> | -g <spec>) [-w 1|2] [-l lds_doubles] [-T threads] [-v]\n"
+    printf("usage: solver_test -i <iters> (-m <name> | -g <spec>) [-w 1|2] [-l lds_doubles] [-T threads] [-c plan.cache] [-v]\n"
+           "  -c file   plan cache: reuse the permutation + layout saved by an earlier run on the same matrix,\n"
+           "            or write it (the reference repeats mt-metis + COO2EHYB on every run)\n"
            "  -m name   ./read/name.mtx (Matrix Market, general or symmetric)\n"
            "  -g spec   banded:n:band:block | fem3d:n:dof:nx:ny:ppm:scramble | rmat:scale:edges |\n"
            "            stencil2d:nx:ny:points:extra | kkt3d:nx\n"
@@ -79,8 +81,10 @@ int main(int argc, char* argv[])
     ehyb_config_default(&cfg);
 
     int oc;
-    while ((oc = getopt(argc, argv, "m:i:r:t:f:p:g:w:l:T:vh")) != -1) {
+    std::string cache;
+    while ((oc = getopt(argc, argv, "m:i:r:t:f:p:g:w:l:T:c:vh")) != -1) {
         switch (oc) {
+            case 'c': cache = optarg; break;
             case 'm':
                 snprintf(fileName, sizeof fileName, "./read/%s.mtx", optarg);
                 printf("filename is %s\n", fileName);
@@ -176,30 +180,79 @@ int main(int argc, char* argv[])
     double* xReorder = (double*)calloc(n, sizeof(double));
     double* yReorder = (double*)calloc(n, sizeof(double));
 
-    // --------------------------------- reorder (solver_test.c:369-376)
-    gettimeofday(&t0, NULL);
-    rc = ehyb_matrix_reorder(&A, symmetric, &cfg);
-    gettimeofday(&t1, NULL);
-    if (rc != EHYB_OK) {
-        printf("reorder failed: %s\n", ehyb_last_error());
-        return 1;
+    // --------------------------------- plan cache (-c): permutation + finished layout from an
+    // earlier run of the same matrix; the partitioner and the conversion are skipped on a hit
+    ehyb_plan* plan = nullptr;
+    std::vector<int> cachedList;
+    uint64_t key = 0;
+    if (!cache.empty()) {
+        key = ehyb_matrix_key(&A);  // of the matrix as read, before it is permuted
+        cachedList.resize(n);
+        if (ehyb_plan_load(cache.c_str(), key, &plan, cachedList.data()) == EHYB_OK) {
+            printf("plan cache hit: %s (reorder and conversion skipped)\n", cache.c_str());
+        } else {
+            printf("plan cache miss: %s\n", ehyb_last_error());
+            plan = nullptr;
+        }
     }
-    printf("reorder time is %f ms\n", (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_usec - t0.tv_usec) * 1e-3);
-    vectorReorder(n, xCompare, xReorder, A.reorderList);
+
+    // --------------------------------- reorder (solver_test.c:369-376)
+    if (!plan) {
+        gettimeofday(&t0, NULL);
+        rc = ehyb_matrix_reorder(&A, symmetric, &cfg);
+        gettimeofday(&t1, NULL);
+        if (rc != EHYB_OK) {
+            printf("reorder failed: %s\n", ehyb_last_error());
+            return 1;
+        }
+        printf("reorder time is %f ms\n", (t1.tv_sec - t0.tv_sec) * 1e3 + (t1.tv_usec - t0.tv_usec) * 1e-3);
+    }
+    const int* reorderList = plan ? cachedList.data() : A.reorderList;
+    vectorReorder(n, xCompare, xReorder, reorderList);
 
     // --------------------------------- the hot path (solver_test.c:382-383)
     int realIter = 0;
-    if (cfg.verbose) setenv("EHYB_VERBOSE", "1", 1);
-    char buf[32];
-    snprintf(buf, sizeof buf, "%d", cfg.lds_doubles), setenv("EHYB_LDS_DOUBLES", buf, 1);
-    snprintf(buf, sizeof buf, "%d", cfg.threads), setenv("EHYB_THREADS", buf, 1);
-    snprintf(buf, sizeof buf, "%d", cfg.window_mode), setenv("EHYB_WINDOW_MODE", buf, 1);
-    rc = spmvGPuEHYB_status(&A, xReorder, yReorder, MAXIter, &realIter);
-    if (rc != EHYB_OK) {
-        printf("spmvGPuEHYB failed (%d): %s\n", rc, ehyb_last_error());
-        return 1;
+    if (cache.empty()) {
+        if (cfg.verbose) setenv("EHYB_VERBOSE", "1", 1);
+        char buf[32];
+        snprintf(buf, sizeof buf, "%d", cfg.lds_doubles), setenv("EHYB_LDS_DOUBLES", buf, 1);
+        snprintf(buf, sizeof buf, "%d", cfg.threads), setenv("EHYB_THREADS", buf, 1);
+        snprintf(buf, sizeof buf, "%d", cfg.window_mode), setenv("EHYB_WINDOW_MODE", buf, 1);
+        rc = spmvGPuEHYB_status(&A, xReorder, yReorder, MAXIter, &realIter);
+        if (rc != EHYB_OK) {
+            printf("spmvGPuEHYB failed (%d): %s\n", rc, ehyb_last_error());
+            return 1;
+        }
+    } else {
+        // the same sequence through the plan API (what spmvGPuEHYB does inside), so that the
+        // layout can come from / go to the cache file
+        if (!plan) {
+            rc = ehyb_plan_create_host(&A, 0, n, &cfg, &plan);
+            if (rc == EHYB_OK && (rc = ehyb_plan_save(plan, A.reorderList, key, cache.c_str())) == EHYB_OK)
+                printf("plan cache written: %s\n", cache.c_str());
+        }
+        ehyb_stats st;
+        void *dx = nullptr, *dy = nullptr;
+        double ms = 0;
+        if (rc == EHYB_OK) rc = ehyb_plan_upload(plan);
+        if (rc == EHYB_OK) rc = ehyb_plan_stats(plan, &st);
+        if (rc == EHYB_OK) printf("sizeER is %lld\n", (long long)st.size_er);  // spmv.cu:82
+        if (rc == EHYB_OK) rc = ehyb_dev_alloc(sizeof(double) * n, &dx);
+        if (rc == EHYB_OK) rc = ehyb_dev_alloc(sizeof(double) * n, &dy);
+        if (rc == EHYB_OK) rc = ehyb_h2d(dx, xReorder, sizeof(double) * n);
+        if (rc == EHYB_OK) rc = ehyb_spmv_bench(plan, (const double*)dx, (double*)dy, nullptr, 10, MAXIter, &ms, nullptr, nullptr);
+        if (rc == EHYB_OK) rc = ehyb_d2h(yReorder, dy, sizeof(double) * n);
+        if (rc != EHYB_OK) {
+            printf("plan path failed (%d): %s\n", rc, ehyb_last_error());
+            return 1;
+        }
+        printf("iter is %d, time is %f ms, GPU Gflops is %f\n ", MAXIter, ms, 2.0 * st.nnz * MAXIter / (ms * 1e6));  // spmv.cu:121
+        realIter = MAXIter;
+        ehyb_dev_free(dx);
+        ehyb_dev_free(dy);
+        ehyb_plan_destroy(plan);
     }
-    vectorRecover(n, yReorder, yResult, A.reorderList);
+    vectorRecover(n, yReorder, yResult, reorderList);
 
     // --------------------------------- compare (solver_test.c:389) + strict tolerance
     int loose = compare(yResult, y, 0.01, n);
@@ -215,7 +268,12 @@ int main(int argc, char* argv[])
 
     ehyb_matrix_free(&A);
     free(yResult), free(xReorder), free(yReorder), free(y), free(yAbs), free(xCompare);
-    if (strict || loose) {
+    // The verdict is the stated tolerance.  compare() above is the reference's own report
+    // (solver_test.c:389 prints it and carries on): its 1 % test is relative to |y_i| alone, so a row
+    // whose terms cancel to rounding level is flagged under any change of summation order.
+    if (loose && !strict)
+        printf("compare(): %d rows flagged, all within 1e-12 of sum|a*x| (cancellation rows)\n", loose);
+    if (strict) {
         printf("FAILED\n");
         return 1;
     }

@@ -23,7 +23,7 @@ ARRAYS = {
     "items": (9, np.int32), "er_seg_ptr": (10, np.int64), "er_seg_row": (11, np.int32),
     "er_col": (12, np.int32), "er_val": (13, np.float64), "er_bins": (14, np.int32),
     "slab_col_ptr": (15, np.uint32), "lane_group": (16, np.uint8), "slab_meta": (17, np.uint32),
-    "segs": (18, np.int32),
+    "segs": (18, np.int32), "perm": (19, np.int32),
 }
 
 
@@ -202,6 +202,10 @@ class Matrix:
                "ehyb_matrix_reorder")
         return self
 
+    def key(self):
+        """ehyb_matrix_key: digest of the matrix as stored (take it BEFORE reorder() to key a plan cache)."""
+        return int(self.lib.ehyb_matrix_key(C.byref(self.c)))
+
     def append_ghosts(self, n_ghost, gi, gj, gv):
         """Rank-local multi-GPU build: add n_ghost receive-buffer columns and the entries coupling
         to them (ehyb_matrix_append_ghosts)."""
@@ -277,6 +281,31 @@ class Plan:
     def upload(self):
         _check(self.lib.ehyb_plan_upload(self.h), "ehyb_plan_upload")
         return self
+
+    def save(self, path, reorder_list=None, key=0):
+        """ehyb_plan_save: the host layout (+ the permutation, + a matrix key) to a cache file."""
+        lst = None if reorder_list is None else np.ascontiguousarray(reorder_list, dtype=np.int32)
+        assert lst is None or lst.shape == (self.n,)
+        _check(self.lib.ehyb_plan_save(self.h, _ptr(lst, C.c_int) if lst is not None else None, key, str(path).encode()),
+               "ehyb_plan_save")
+
+    @classmethod
+    def load(cls, path, key=0, want_perm=True, upload=True):
+        """ehyb_plan_load -> (plan, reorder_list or None); key != 0 must match the file's."""
+        self = cls.__new__(cls)
+        self.lib = _lib.load()
+        self.h = C.c_void_p()
+        _check(self.lib.ehyb_plan_load(str(path).encode(), key, C.byref(self.h), None), "ehyb_plan_load")
+        st = self.stats
+        self.n = st["n_cols"]
+        seg = self.array("part_boundary")
+        self.rows = (int(seg[0]), int(seg[-1]))
+        perm = self.array("perm") if want_perm else None
+        if perm is not None and len(perm) == 0:
+            perm = None
+        if upload:
+            self.upload()
+        return self, perm
 
     @property
     def stats(self):

@@ -158,6 +158,19 @@ int ehyb_plan_upload(ehyb_plan* plan);
 int ehyb_plan_create(const matrixCOO* m, const ehyb_config* cfg, ehyb_plan** plan);
 void ehyb_plan_destroy(ehyb_plan* plan);
 
+/*
+ * On-disk cache of the pre-step: the reference repeats mt-metis and COO2EHYB on
+ * every run (solver_test.c:369-382, spmv.cu:74).  ehyb_plan_save writes the host layout of a plan
+ * together with the permutation that produced its matrix (reorder_list: n_cols ints, may be NULL)
+ * and a key of the caller's choice -- ehyb_matrix_key(m) of the UNPERMUTED matrix is the intended
+ * one.  ehyb_plan_load rebuilds a host plan (then ehyb_plan_upload); it fails with
+ * EHYB_ERR_FORMAT when the file is damaged, from another version, or expect_key (non-zero) differs.
+ * Same-machine cache, native byte order.
+ */
+uint64_t ehyb_matrix_key(const matrixCOO* m);
+int ehyb_plan_save(const ehyb_plan* plan, const int* reorder_list, uint64_t matrix_key, const char* path);
+int ehyb_plan_load(const char* path, uint64_t expect_key, ehyb_plan** plan, int* reorder_list);
+
 /* Format metrics; the first five are the ones the reference prints
  * (convert.c:140,310; spmv.cu:82). */
 typedef struct ehyb_stats {
@@ -215,8 +228,10 @@ enum {
                                    (stats.er_inline): behind the slab's `pairs` ELL pairs the value stream
                                    holds er_pairs more pairs [pair][lane][2], and behind its pairs*G column
                                    words the column stream holds [er pair][2][lane] GLOBAL 32-bit columns */
-    EHYB_ARR_SEGS          = 18 /* int32  [n_segs*8]   {partition, slab_begin, slab_end, halo_count, first row,
+    EHYB_ARR_SEGS          = 18,/* int32  [n_segs*8]   {partition, slab_begin, slab_end, halo_count, first row,
                                    end row, win_len, halo_begin}: one LDS window staging each       */
+    EHYB_ARR_PERM          = 19 /* int32  [n_cols]     reorderList stored with a plan that came from
+                                   ehyb_plan_load (empty for plans built in this process)          */
 };
 int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int64_t* count);
 
@@ -240,9 +255,9 @@ int ehyb_spmv_phase(ehyb_plan* plan, const double* x_dev, double* y_dev, void* s
  * Timed loop on device-resident vectors: `warmup` untimed multiplies, then `iters`
  * multiplies bracketed by HIP events on `stream` (no copies inside, residual recomputed
  * every time: SURVEY 8d "Timing protocol").  ms_total = whole loop.  If ms_ell / ms_er
- * are non-NULL a second pass of `iters` multiplies brackets every launch with its own
- * event pair and returns the SUM of the kernel durations (divide by iters for the
- * average launch).
+ * are non-NULL a second pass of min(iters, 200) multiplies brackets every launch with its
+ * own event pair and returns the AVERAGE duration of the ELL launch and of the residual
+ * launch (0-length interval when the residual is inline or empty).
  */
 int ehyb_spmv_bench(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream,
                     int warmup, int iters, double* ms_total, double* ms_ell, double* ms_er);

@@ -46,3 +46,19 @@ def test_cli_usage_errors(gpu, tmp_path):
     assert p.returncode != 0 and "file read error" in p.stdout    # solver_test.c:328-331
     p = _run(["-i", "5", "-g", "stencil2d:40:30:5:100"], tmp_path)
     assert p.returncode == 0 and "PASSED" in p.stdout
+
+
+def test_cli_plan_cache_miss_then_hit(E, gpu, tmp_path):
+    """-c file: the first run partitions, converts and writes the cache; the second reads the
+    permutation and the layout back and skips both steps; a different matrix is a miss."""
+    cache = str(tmp_path / "plan.cache")
+    a = ["-i", "20", "-g", "fem3d:30000:3:22:22:13500:1", "-c", cache]
+    p1 = _run(a, tmp_path)
+    assert p1.returncode == 0, p1.stdout[-2000:] + p1.stderr[-2000:]
+    assert "plan cache miss" in p1.stdout and "reorder time is" in p1.stdout and "plan cache written" in p1.stdout
+    assert "PASSED" in p1.stdout and "iter is 20, time is" in p1.stdout
+    p2 = _run(a, tmp_path)
+    assert p2.returncode == 0, p2.stdout[-2000:] + p2.stderr[-2000:]
+    assert "plan cache hit" in p2.stdout and "reorder time is" not in p2.stdout and "PASSED" in p2.stdout
+    p3 = _run(["-i", "5", "-g", "fem3d:30000:3:22:22:13400:1", "-c", cache], tmp_path)   # other matrix, same file
+    assert p3.returncode == 0 and "plan cache miss" in p3.stdout and "another matrix" in p3.stdout and "PASSED" in p3.stdout
