@@ -5,6 +5,7 @@
 #include "ehyb_internal.h"
 
 #include <omp.h>
+#include <zlib.h>
 
 #include <algorithm>
 #include <cctype>
@@ -83,71 +84,141 @@ int ehyb_mm_read(const char* path, const ehyb_config* cfg, matrixCOO* out, int* 
 {
     clear_error();
     if (!path || !out) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_mm_read: null argument");
-    FILE* f = fopen(path, "r");
-    if (!f) EHYB_FAIL(EHYB_ERR_IO, "file read error: %s", path);
+    // The whole file in memory, plain or gzip (zlib reads both; "<path>.gz" is tried when <path>
+    // does not exist, so `-m audikw_1` also finds ./read/audikw_1.mtx.gz).  The reference parses
+    // with fscanf one entry at a time (solver_test.c:96-103,196-206); here the body is cut into
+    // line-aligned pieces parsed in parallel -- tens of millions of lines are the common case.
+    std::vector<char> text;
+    {
+        gzFile g = gzopen(path, "rb");
+        if (!g) g = gzopen((std::string(path) + ".gz").c_str(), "rb");
+        if (!g) EHYB_FAIL(EHYB_ERR_IO, "file read error: %s", path);
+        gzbuffer(g, 1u << 20);
+        size_t used = 0;
+        try {
+            text.resize(size_t(1) << 24);
+            for (;;) {
+                if (text.size() - used < (size_t(1) << 22)) text.resize(text.size() * 2);
+                const int got = gzread(g, text.data() + used, (unsigned)std::min<size_t>(text.size() - used - 1, size_t(1) << 30));
+                if (got < 0) {
+                    gzclose(g);
+                    EHYB_FAIL(EHYB_ERR_IO, "file read error: %s (damaged gzip stream?)", path);
+                }
+                if (got == 0) break;
+                used += (size_t)got;
+            }
+        } catch (const std::bad_alloc&) {
+            gzclose(g);
+            EHYB_FAIL(EHYB_ERR_ALLOC, "out of memory reading %s", path);
+        }
+        gzclose(g);
+        text.resize(used + 1);
+        text[used] = '\0';  // strtod never runs off the end
+    }
+    const char* const end = text.data() + text.size() - 1;
+    const char* cur = text.data();
+    auto next_line = [&](const char* p) {
+        const char* q = (const char*)memchr(p, '\n', (size_t)(end - p));
+        return q ? q + 1 : end;
+    };
     char line[1100];
-    if (!fgets(line, sizeof line, f)) {
-        fclose(f);
-        EHYB_FAIL(EHYB_ERR_FORMAT, "Could not process Matrix Market banner.");
-    }
+    auto copy_line = [&](const char* p) {
+        const char* q = next_line(p);
+        const size_t len = std::min<size_t>((size_t)(q - p), sizeof line - 1);
+        memcpy(line, p, len);
+        line[len] = '\0';
+        return q;
+    };
+    if (cur >= end) EHYB_FAIL(EHYB_ERR_FORMAT, "Could not process Matrix Market banner.");
+    cur = copy_line(cur);
     char banner[64], object[64], format[64], field[64], symm[64];
-    if (sscanf(line, "%63s %63s %63s %63s %63s", banner, object, format, field, symm) != 5) {
-        fclose(f);
+    if (sscanf(line, "%63s %63s %63s %63s %63s", banner, object, format, field, symm) != 5)
         EHYB_FAIL(EHYB_ERR_FORMAT, "Could not process Matrix Market banner.");
-    }
     auto lower = [](char* s) {
         for (; *s; ++s) *s = (char)tolower((unsigned char)*s);
     };
     lower(object), lower(format), lower(field), lower(symm);
-    if (strcmp(banner, "%%MatrixMarket") != 0 || strcmp(object, "matrix") != 0) {
-        fclose(f);
+    if (strcmp(banner, "%%MatrixMarket") != 0 || strcmp(object, "matrix") != 0)
         EHYB_FAIL(EHYB_ERR_FORMAT, "Could not process Matrix Market banner.");
-    }
-    if (strcmp(format, "coordinate") != 0) {
-        fclose(f);
+    if (strcmp(format, "coordinate") != 0)
         EHYB_FAIL(EHYB_ERR_FORMAT, "only coordinate (sparse) Matrix Market files are supported, got '%s'", format);
-    }
     const bool pattern = strcmp(field, "pattern") == 0;
-    if (!pattern && strcmp(field, "real") != 0 && strcmp(field, "integer") != 0 && strcmp(field, "double") != 0) {
-        fclose(f);  // solver_test.c:339-345 rejects complex
+    if (!pattern && strcmp(field, "real") != 0 && strcmp(field, "integer") != 0 && strcmp(field, "double") != 0)
+        // solver_test.c:339-345 rejects complex
         EHYB_FAIL(EHYB_ERR_FORMAT, "Sorry, this application does not support Market Market type: [%s %s %s %s]", object, format, field, symm);
-    }
     const bool sym = strcmp(symm, "symmetric") == 0;
     const bool skew = strcmp(symm, "skew-symmetric") == 0;
-    if (!sym && !skew && strcmp(symm, "general") != 0) {
-        fclose(f);
-        EHYB_FAIL(EHYB_ERR_FORMAT, "unsupported Matrix Market symmetry '%s'", symm);
-    }
+    if (!sym && !skew && strcmp(symm, "general") != 0) EHYB_FAIL(EHYB_ERR_FORMAT, "unsupported Matrix Market symmetry '%s'", symm);
     // size line: first non-comment, non-blank line (mmio.c:189-217)
     long M = 0, N = 0, stored = 0;
     for (;;) {
-        if (!fgets(line, sizeof line, f)) {
-            fclose(f);
-            EHYB_FAIL(EHYB_ERR_FORMAT, "premature end of file before the size line");
-        }
+        if (cur >= end) EHYB_FAIL(EHYB_ERR_FORMAT, "premature end of file before the size line");
+        cur = copy_line(cur);
         if (line[0] == '%') continue;
         if (sscanf(line, "%ld %ld %ld", &M, &N, &stored) == 3) break;
     }
-    if (M <= 0 || M != N || stored < 0 || M > 0x7FFFFFF0l) {
-        fclose(f);
+    if (M <= 0 || M != N || stored < 0 || M > 0x7FFFFFF0l)
         EHYB_FAIL(EHYB_ERR_FORMAT, "size line %ld x %ld with %ld entries: a square matrix is required", M, N, stored);
-    }
     const int n = (int)M;
     std::vector<int> fi((size_t)stored), fj((size_t)stored);
     std::vector<double> fv((size_t)stored);
-    for (long k = 0; k < stored; ++k) {
-        int a = 0, b = 0;
-        double v = 1.0;
-        int got = pattern ? fscanf(f, "%d %d", &a, &b) : fscanf(f, "%d %d %lg", &a, &b, &v);
-        if (got != (pattern ? 2 : 3) || a < 1 || b < 1 || a > n || b > n) {
-            fclose(f);
-            EHYB_FAIL(EHYB_ERR_FORMAT, "bad entry %ld of %ld in %s", k + 1, stored, path);
+    {
+        // pieces of the body that start at line starts; entry lines per piece; then parse
+        const int pieces = (int)std::max<int64_t>(1, std::min<int64_t>(omp_get_max_threads(), (end - cur) / (1 << 16)));
+        std::vector<const char*> start(pieces + 1);
+        for (int t = 0; t <= pieces; ++t) {
+            const char* p = cur + (int64_t)(end - cur) * t / pieces;
+            start[t] = (t == 0) ? cur : (t == pieces ? end : next_line(p - 1));  // p-1: p itself may be a line start
         }
-        fi[k] = a - 1;  // 1-based -> 0-based (solver_test.c:98-99, 198-199)
-        fj[k] = b - 1;
-        fv[k] = v;
+        auto is_entry = [](const char* p, const char* q) {  // a line with something other than blanks, not a comment
+            for (; p < q; ++p)
+                if (*p != ' ' && *p != '\t' && *p != '\r' && *p != '\n') return *p != '%';
+            return false;
+        };
+        std::vector<int64_t> first(pieces + 1, 0);
+#pragma omp parallel for schedule(static, 1)
+        for (int t = 0; t < pieces; ++t) {
+            int64_t c = 0;
+            for (const char* p = start[t]; p < start[t + 1];) {
+                const char* q = next_line(p);
+                c += is_entry(p, q);
+                p = q;
+            }
+            first[t + 1] = c;
+        }
+        for (int t = 0; t < pieces; ++t) first[t + 1] += first[t];
+        if (first[pieces] < stored)
+            EHYB_FAIL(EHYB_ERR_FORMAT, "bad entry %lld of %ld in %s", (long long)first[pieces] + 1, stored, path);
+        int64_t bad = -1;
+#pragma omp parallel for schedule(static, 1)
+        for (int t = 0; t < pieces; ++t) {
+            int64_t k = first[t];
+            for (const char* p = start[t]; p < start[t + 1] && k < stored;) {
+                const char* q = next_line(p);
+                if (is_entry(p, q)) {
+                    char* e1 = nullptr;
+                    const long a = strtol(p, &e1, 10);
+                    char* e2 = nullptr;
+                    const long b = strtol(e1, &e2, 10);
+                    double v = 1.0;
+                    char* e3 = e2;
+                    if (!pattern) v = strtod(e2, &e3);
+                    if (e1 == p || e2 == e1 || (!pattern && e3 == e2) || e3 > q || a < 1 || b < 1 || a > n || b > n) {
+#pragma omp critical
+                        if (bad < 0 || k < bad) bad = k;
+                    } else {
+                        fi[k] = (int)a - 1;  // 1-based -> 0-based (solver_test.c:98-99, 198-199)
+                        fj[k] = (int)b - 1;
+                        fv[k] = v;
+                    }
+                    ++k;
+                }
+                p = q;
+            }
+        }
+        if (bad >= 0) EHYB_FAIL(EHYB_ERR_FORMAT, "bad entry %lld of %ld in %s", (long long)bad + 1, stored, path);
     }
-    fclose(f);
+    std::vector<char>().swap(text);
 
     const bool mirror = sym || skew;
     int64_t total = stored;

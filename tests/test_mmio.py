@@ -130,3 +130,39 @@ def test_generators_are_deterministic_and_shaped(E):
     K = k.to_scipy()
     assert abs(K - K.T).max() == 0 and k.n == 2 * 6 ** 3
     assert k.nnz - K.count_nonzero() == 6 ** 3, "explicit zeros on the diagonal of the (2,2) block are stored entries"
+
+
+def test_gzip_input_and_parallel_parse(E, tmp_path):
+    """The reader takes gzip files (also by finding <name>.mtx.gz for <name>.mtx) and parses the body in
+    line-aligned pieces in parallel: same matrix as the plain file, comment and blank lines in the
+    body tolerated, a bad line reported by its entry number."""
+    import gzip
+
+    m = E.Matrix.generate("fem3d", 30000, 3, 22, 22, 13500, 1, 3)      # ~2.3 M entries: several pieces
+    plain = tmp_path / "a.mtx"
+    m.write_mtx(plain, symmetric_lower_only=True)
+    text = plain.read_bytes()
+    lines = text.split(b"\n")
+    lines.insert(5000, b"% a comment in the body")
+    lines.insert(9000, b"   ")
+    text2 = b"\n".join(lines)
+    (tmp_path / "b.mtx.gz").write_bytes(gzip.compress(text2, compresslevel=1))
+    a = E.Matrix.read_mtx(plain)
+    b = E.Matrix.read_mtx(tmp_path / "b.mtx.gz")
+    c = E.Matrix.read_mtx(tmp_path / "b.mtx")                           # found as b.mtx.gz
+    for other in (b, c):
+        assert other.n == a.n and other.nnz == a.nnz and other.symmetric
+        assert np.array_equal(a.I, other.I) and np.array_equal(a.J, other.J) and np.array_equal(a.V, other.V)
+    assert a.nnz == m.nnz and np.array_equal(np.sort(a.J + a.I.astype(np.int64) * a.n), np.sort(m.J + m.I.astype(np.int64) * m.n))
+    # entry 777777 damaged
+    data = [ln for ln in text.split(b"\n")]
+    data[2 + 777776] = b"12 x 3.0"
+    (tmp_path / "bad.mtx").write_bytes(b"\n".join(data))
+    with pytest.raises(E.EhybError) as e:
+        E.Matrix.read_mtx(tmp_path / "bad.mtx")
+    assert e.value.code == 6 and "bad entry 777777 " in str(e.value)
+    # fewer entries than the size line promises
+    (tmp_path / "short.mtx").write_bytes(b"\n".join(text.split(b"\n")[:1000]) + b"\n")
+    with pytest.raises(E.EhybError) as e:
+        E.Matrix.read_mtx(tmp_path / "short.mtx")
+    assert e.value.code == 6 and "bad entry 999 " in str(e.value)
