@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libehyb.so")
+# EHYB_LIB: another build of the same library (A/B timing of kernel changes on one GPU box)
+LIB_PATH = os.environ.get("EHYB_LIB") or os.path.join(_HERE, "libehyb.so")
 
 
 class MatrixCOO(C.Structure):
