@@ -12,6 +12,8 @@
 // Deterministic for a given seed.  Complexity O(|E|) per level.
 #include "ehyb_internal.h"
 
+#include <omp.h>
+
 #include <algorithm>
 #include <numeric>
 #include <queue>
@@ -90,36 +92,67 @@ void coarsen_once(const GView& g, int max_vw, uint64_t& rng, Graph* out, std::ve
         first.push_back(v);
         ++nc;
     }
+    // Contraction: the adjacency of coarse vertex c is the merged adjacency of its members.  Coarse
+    // vertices are independent: a first parallel pass counts their distinct coarse neighbours, a
+    // prefix sum places them, a second pass fills the arrays in place (neighbour order inside a
+    // vertex = member order, edge order: the same graph for any thread count; no per-thread
+    // buffers to grow and copy).
     out->n = nc;
     out->xadj.assign(nc + 1, 0);
     out->vw.assign(nc, 0);
-    out->adj.clear();
-    out->ew.clear();
-    out->adj.reserve((size_t)g.xadj[n] / 2 + 16);
-    out->ew.reserve((size_t)g.xadj[n] / 2 + 16);
-    std::vector<int64_t> pos(nc, -1);
-    for (int c = 0; c < nc; ++c) {
-        const int64_t start = (int64_t)out->adj.size();
-        int members[2] = {first[c], match[first[c]]};
-        int nm = members[0] == members[1] ? 1 : 2;
-        int w = 0;
-        for (int k = 0; k < nm; ++k) {
-            int v = members[k];
-            w += g.wv(v);
-            for (int64_t e = g.xadj[v]; e < g.xadj[v + 1]; ++e) {
-                int cu = (*cmap)[g.adj[e]];
-                if (cu == c) continue;
-                if (pos[cu] >= start) {
-                    out->ew[pos[cu]] += g.we(e);
-                } else {
-                    pos[cu] = (int64_t)out->adj.size();
-                    out->adj.push_back(cu);
-                    out->ew.push_back(g.we(e));
+#pragma omp parallel
+    {
+        std::vector<int> seen(nc, -1);  // last coarse vertex that counted cu
+#pragma omp for schedule(dynamic, 2048)
+        for (int c = 0; c < nc; ++c) {
+            const int members[2] = {first[c], match[first[c]]};
+            const int nm = members[0] == members[1] ? 1 : 2;
+            int w = 0;
+            int64_t deg = 0;
+            for (int k = 0; k < nm; ++k) {
+                const int v = members[k];
+                w += g.wv(v);
+                for (int64_t e = g.xadj[v]; e < g.xadj[v + 1]; ++e) {
+                    const int cu = (*cmap)[g.adj[e]];
+                    if (cu != c && seen[cu] != c) {
+                        seen[cu] = c;
+                        ++deg;
+                    }
+                }
+            }
+            out->vw[c] = w;
+            out->xadj[c + 1] = deg;
+        }
+    }
+    for (int c = 0; c < nc; ++c) out->xadj[c + 1] += out->xadj[c];
+    out->adj.resize((size_t)out->xadj[nc]);
+    out->ew.resize((size_t)out->xadj[nc]);
+#pragma omp parallel
+    {
+        std::vector<int64_t> pos(nc, -1);  // where coarse neighbour cu sits, if at or behind the vertex's start
+#pragma omp for schedule(dynamic, 2048)
+        for (int c = 0; c < nc; ++c) {
+            const int64_t start = out->xadj[c];
+            int64_t at = start;
+            const int members[2] = {first[c], match[first[c]]};
+            const int nm = members[0] == members[1] ? 1 : 2;
+            for (int k = 0; k < nm; ++k) {
+                const int v = members[k];
+                for (int64_t e = g.xadj[v]; e < g.xadj[v + 1]; ++e) {
+                    const int cu = (*cmap)[g.adj[e]];
+                    if (cu == c) continue;
+                    // entries of earlier vertices sit below `start`, so a stale pos never passes
+                    if (pos[cu] >= start && pos[cu] < at && out->adj[pos[cu]] == cu) {
+                        out->ew[pos[cu]] += g.we(e);
+                    } else {
+                        pos[cu] = at;
+                        out->adj[at] = cu;
+                        out->ew[at] = g.we(e);
+                        ++at;
+                    }
                 }
             }
         }
-        out->vw[c] = w;
-        out->xadj[c + 1] = (int64_t)out->adj.size();
     }
 }
 
@@ -307,14 +340,31 @@ int refine_kway(const GView& g, int k, int64_t cap, int passes, std::vector<int>
     std::vector<int> touched;
     touched.reserve(64);
     int total_moves = 0;
-    std::vector<int> order(n);
-    std::iota(order.begin(), order.end(), 0);
-    for (int pass = 0; pass < passes; ++pass) {
-        // cheap shuffle: rotate by a random offset and stride through blocks
-        int off = n ? (int)(splitmix64(rng) % (uint64_t)n) : 0;
-        int moves = 0;
+    // Only a vertex with a neighbour in another part can move.  The first pass visits the boundary
+    // vertices (found in parallel; most vertices are interior and were scanned for nothing before),
+    // later passes the vertices whose neighbourhood changed in the pass before.
+    std::vector<char> flag(n, 0);
+#pragma omp parallel for schedule(static, 4096)
+    for (int v = 0; v < n; ++v) {
+        const int pv = part[v];
+        char b = 0;
+        for (int64_t e = g.xadj[v]; e < g.xadj[v + 1] && !b; ++e) b = part[g.adj[e]] != pv;
+        flag[v] = b;
+    }
+    std::vector<int> work, next;
+    {
+        // cheap shuffle: start at a random offset
+        const int off = n ? (int)(splitmix64(rng) % (uint64_t)n) : 0;
         for (int idx = 0; idx < n; ++idx) {
-            int v = order[(idx + off) % n];
+            const int v = idx + off < n ? idx + off : idx + off - n;
+            if (flag[v]) work.push_back(v);
+        }
+    }
+    std::fill(flag.begin(), flag.end(), 0);  // from here on: "queued for the next pass"
+    for (int pass = 0; pass < passes && !work.empty(); ++pass) {
+        int moves = 0;
+        next.clear();
+        for (int v : work) {
             int pv = part[v];
             touched.clear();
             int id = 0;
@@ -346,12 +396,21 @@ int refine_kway(const GView& g, int k, int64_t cap, int passes, std::vector<int>
                     pw[pv] -= wv;
                     pw[best] += wv;
                     ++moves;
+                    for (int64_t e = g.xadj[v]; e < g.xadj[v + 1]; ++e) {
+                        const int u = g.adj[e];
+                        if (!flag[u]) {
+                            flag[u] = 1;
+                            next.push_back(u);
+                        }
+                    }
                 }
             }
             for (int p : touched) conn[p] = 0;
         }
         total_moves += moves;
         if (moves == 0) break;
+        for (int u : next) flag[u] = 0;
+        work.swap(next);
     }
     return total_moves;
 }
@@ -552,7 +611,9 @@ int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vw
         if (finer.vw)
             for (int v = 0; v < finer.n; ++v) lvl_max = std::max(lvl_max, finer.vw[v]);
         int64_t lcap = l == 0 ? cap : std::max(cap, avg + lvl_max);
-        refine_kway(finer, nparts, lcap, l == 0 ? 4 : 6, cpart, pw, rng);
+        const double tl = wall_seconds();
+        const int mv = refine_kway(finer, nparts, lcap, l == 0 ? 4 : 6, cpart, pw, rng);
+        if (cfg.verbose > 1) printf("  refine level %d: n=%d moves %d %.3fs\n", l, finer.n, mv, wall_seconds() - tl);
     }
     if (levels.empty()) refine_kway(fine, nparts, cap, 4, cpart, pw, rng);
     enforce_cap(fine, nparts, cap, cpart, pw);

@@ -120,10 +120,20 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
     const int64_t nnz = m->totalNum;
     int nparts = m->nParts;
     if (nparts < 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_reorder: nParts = %d (call ehyb_sizing first)", nparts);
-    for (int64_t k = 0; k < nnz; ++k)
-        if ((unsigned)m->I[k] >= (unsigned)n || (unsigned)m->J[k] >= (unsigned)n)
-            EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_reorder: entry %lld (%d,%d) outside a %d x %d matrix",
-                      (long long)k, m->I[k], m->J[k], n, n);
+    // The input is row-grouped: rowIdx delimits the rows (solver_test.c:105-124).  Everything below
+    // works row by row on that.
+    if (m->rowIdx[0] != 0 || m->rowIdx[n] != nnz) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_reorder: rowIdx does not span the %lld entries", (long long)nnz);
+    int64_t bad_entry = -1;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i)
+        for (int k = m->rowIdx[i]; k < m->rowIdx[i + 1]; ++k)
+            if (m->I[k] != i || (unsigned)m->J[k] >= (unsigned)n) {
+#pragma omp critical
+                if (bad_entry < 0 || k < bad_entry) bad_entry = k;
+            }
+    if (bad_entry >= 0)
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_reorder: entry %lld (%d,%d) is outside the %d x %d matrix or not in the row rowIdx places it in",
+                  (long long)bad_entry, m->I[bad_entry], m->J[bad_entry], n, n);
     if (c.verbose) printf("nParts is %d\n", nparts);
 
     int cache = m->vectorCacheSize > 0 ? (int)m->vectorCacheSize : c.part_rows;
@@ -134,8 +144,10 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
     {
         std::vector<int64_t> xadj;
         std::vector<int> adj;
+        const double ta = wall_seconds();
         build_adjacency(m, symmetric_pattern != 0, &xadj, &adj);
         const double t0 = wall_seconds();
+        if (c.verbose) printf("adjacency time is %ld us\n", (long)((t0 - ta) * 1e6));
         int64_t cut = 0;
         int rc;
         if (c.partitioner == EHYB_PART_MTMETIS) {
@@ -192,6 +204,7 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
             m->nParts = nparts;
         } else {
             rc = partition_graph(n, xadj.data(), adj.data(), nullptr, nparts, cap, c, part.data(), &cut);
+            if (c.verbose) printf("k-way partition time is %ld us\n", (long)((wall_seconds() - t0) * 1e6));
             // Capacity-aware refinement (halo window only): a partition whose own rows plus the
             // distinct outside columns it references do not fit the LDS window would spill
             // entries into the residual.  Such partitions -- and only those -- are bisected, which
@@ -199,58 +212,71 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
             // (and its kernel launch) disappears.  Partitions that overflow by more than 1.5x
             // (power-law graphs) are left alone: splitting cannot make them fit.
             if (rc == EHYB_OK && c.window_mode == EHYB_WINDOW_HALO && c.cap_split != 2) {
+                const int* rp0 = m->rowIdx;  // the input is row-grouped: row i = entries [rp0[i], rp0[i+1])
                 for (int round = 0; round < 3; ++round) {
-                    std::vector<int> own(nparts, 0), demand(nparts, 0);
-                    for (int i = 0; i < n; ++i) own[part[i]]++;
+                    std::vector<int> demand(nparts, 0), local(n, -1);
+                    std::vector<std::vector<int>> members(nparts);
+                    for (int i = 0; i < n; ++i) {
+                        local[i] = (int)members[part[i]].size();
+                        members[part[i]].push_back(i);
+                    }
+                    // distinct outside columns per partition
+#pragma omp parallel
                     {
-                        // distinct outside columns per partition: sort (part, col) pairs
-                        std::vector<std::vector<int>> outside(nparts);
-                        for (int64_t k = 0; k < nnz; ++k) {
-                            int pi = part[m->I[k]];
-                            if (part[m->J[k]] != pi) outside[pi].push_back(m->J[k]);
-                        }
-#pragma omp parallel for schedule(dynamic, 4)
+                        std::vector<int> o;
+#pragma omp for schedule(dynamic, 2)
                         for (int p = 0; p < nparts; ++p) {
-                            std::vector<int>& o = outside[p];
+                            o.clear();
+                            for (int i : members[p])
+                                for (int k = rp0[i]; k < rp0[i + 1]; ++k)
+                                    if (part[m->J[k]] != p) o.push_back(m->J[k]);
                             std::sort(o.begin(), o.end());
-                            demand[p] = own[p] + 1 + (int)(std::unique(o.begin(), o.end()) - o.begin());
+                            demand[p] = (int)members[p].size() + 1 + (int)(std::unique(o.begin(), o.end()) - o.begin());
                         }
                     }
                     std::vector<int> offenders;
                     for (int p = 0; p < nparts; ++p)
-                        if (demand[p] > c.lds_doubles - 2 && demand[p] <= c.lds_doubles * 3 / 2 && own[p] >= 4 * kSlabRows)
+                        if (demand[p] > c.lds_doubles - 2 && demand[p] <= c.lds_doubles * 3 / 2 && (int)members[p].size() >= 4 * kSlabRows)
                             offenders.push_back(p);
                     if (offenders.empty()) break;
                     if (c.verbose) printf("capacity split round %d: %zu of %d partitions overflow the window\n", round, offenders.size(), nparts);
-                    std::vector<int> local(n, -1), spart;
-                    std::vector<int64_t> sx;
-                    std::vector<int> sa;
-                    std::vector<char> is_off(nparts, 0);
-                    for (int p : offenders) is_off[p] = 1;
-                    std::vector<std::vector<int>> members(nparts);
-                    for (int i = 0; i < n; ++i)
-                        if (is_off[part[i]]) {
-                            local[i] = (int)members[part[i]].size();
-                            members[part[i]].push_back(i);
+                    // bisect the offenders side by side (each on its own induced subgraph), then renumber
+                    std::vector<std::vector<int>> halves(offenders.size());
+                    int rc_any = EHYB_OK;
+                    Config quiet = c;
+                    quiet.verbose = 0;
+#pragma omp parallel
+                    {
+                        std::vector<int64_t> sx;
+                        std::vector<int> sa;
+#pragma omp for schedule(dynamic, 1)
+                        for (int oi = 0; oi < (int)offenders.size(); ++oi) {
+                            const int p = offenders[oi];
+                            const std::vector<int>& verts = members[p];
+                            const int nb = (int)verts.size();
+                            sx.assign((size_t)nb + 1, 0);
+                            sa.clear();
+                            for (int q = 0; q < nb; ++q) {
+                                int v = verts[q];
+                                for (int64_t e = xadj[v]; e < xadj[v + 1]; ++e)
+                                    if (part[adj[e]] == p) sa.push_back(local[adj[e]]);
+                                sx[q + 1] = (int64_t)sa.size();
+                            }
+                            halves[oi].assign(nb, 0);
+                            int64_t bcut = 0;
+                            int r2 = partition_graph(nb, sx.data(), sa.data(), nullptr, 2, (nb + 1) / 2 + std::max(8, nb / 40), quiet,
+                                                     halves[oi].data(), &bcut);
+                            if (r2 != EHYB_OK) {
+#pragma omp critical
+                                rc_any = r2;
+                            }
                         }
-                    for (int p : offenders) {
-                        const std::vector<int>& verts = members[p];
-                        const int nb = (int)verts.size();
-                        sx.assign((size_t)nb + 1, 0);
-                        sa.clear();
-                        for (int q = 0; q < nb; ++q) {
-                            int v = verts[q];
-                            for (int64_t e = xadj[v]; e < xadj[v + 1]; ++e)
-                                if (part[adj[e]] == p) sa.push_back(local[adj[e]]);
-                            sx[q + 1] = (int64_t)sa.size();
-                        }
-                        spart.assign(nb, 0);
-                        int64_t bcut = 0;
-                        rc = partition_graph(nb, sx.data(), sa.data(), nullptr, 2, (nb + 1) / 2 + std::max(8, nb / 40), c,
-                                             spart.data(), &bcut);
-                        if (rc != EHYB_OK) return rc;
-                        for (int q = 0; q < nb; ++q)
-                            if (spart[q] == 1) part[verts[q]] = nparts;
+                    }
+                    if (rc_any != EHYB_OK) return rc_any;
+                    for (size_t oi = 0; oi < offenders.size(); ++oi) {
+                        const std::vector<int>& verts = members[offenders[oi]];
+                        for (size_t q = 0; q < verts.size(); ++q)
+                            if (halves[oi][q] == 1) part[verts[q]] = nparts;
                         ++nparts;
                     }
                     m->nParts = nparts;
@@ -263,6 +289,7 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
     }
 
     // ---- partition-contiguous numbering in old order (reordering.c:301-321)
+    const double t_sort = wall_seconds();
     std::vector<int> part_size(nparts, 0);
     for (int i = 0; i < n; ++i) {
         if ((unsigned)part[i] >= (unsigned)nparts) EHYB_FAIL(EHYB_ERR_INTERNAL, "partitioner returned part %d", part[i]);
@@ -274,8 +301,12 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
 
     // in-partition entry count per old row (reordering.c:327-331)
     std::vector<int> inpart(n, 0);
-    for (int64_t k = 0; k < nnz; ++k)
-        if (part[m->I[k]] == part[m->J[k]]) inpart[m->I[k]]++;
+#pragma omp parallel for schedule(static)
+    for (int i = 0; i < n; ++i) {
+        int cnt = 0;
+        for (int k = m->rowIdx[i]; k < m->rowIdx[i + 1]; ++k) cnt += part[m->J[k]] == part[i];
+        inpart[i] = cnt;
+    }
 
     // rows of each partition, old order, then stable sort by inpart descending (reordering.c:334)
     std::vector<int> rows_of(n);
@@ -338,17 +369,21 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
     for (int pos = 0; pos < n; ++pos) list[rows_of[pos]] = pos;
 
     // ---- permuted CSR (reordering.c:335-362)
+    const double t_perm = wall_seconds();
+    if (c.verbose) printf("row order time is %ld us\n", (long)((t_perm - t_sort) * 1e6));
     int* num = m->numInRow;
     int* num2 = m->numInRow2;
     int* rp = m->rowIdx;
-    std::fill(num, num + n, 0);
+    // the input is row-grouped (rowIdx delimits the rows, solver_test.c:105-124), so the new row
+    // `pos` is the old row rows_of[pos] copied in its stored order: rows are independent
+    const std::vector<int> old_rp(rp, rp + n + 1);
     std::fill(num2, num2 + n, 0);
-    for (int64_t k = 0; k < nnz; ++k) num[list[m->I[k]]]++;
     rp[0] = 0;
     int maxcol = 0;
-    for (int i = 0; i < n; ++i) {
-        rp[i + 1] = rp[i] + num[i];
-        maxcol = std::max(maxcol, num[i]);
+    for (int pos = 0; pos < n; ++pos) {
+        num[pos] = old_rp[rows_of[pos] + 1] - old_rp[rows_of[pos]];
+        rp[pos + 1] = rp[pos] + num[pos];
+        maxcol = std::max(maxcol, num[pos]);
     }
     int* nI = (int*)malloc(sizeof(int) * (size_t)std::max<int64_t>(nnz, 1));
     int* nJ = (int*)malloc(sizeof(int) * (size_t)std::max<int64_t>(nnz, 1));
@@ -359,16 +394,20 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
         free(nV);
         EHYB_FAIL(EHYB_ERR_ALLOC, "ehyb_matrix_reorder: out of memory for %lld entries", (long long)nnz);
     }
-    std::vector<int> fill(n, 0);
-    for (int64_t k = 0; k < nnz; ++k) {
-        int oi = m->I[k];
-        int ti = list[oi], tj = list[m->J[k]];
-        int64_t dst = (int64_t)rp[ti] + fill[ti]++;
-        nI[dst] = ti;
-        nJ[dst] = tj;
-        nV[dst] = m->V[k];
-        int ps = pb[part[oi]];
-        if (tj >= ps && tj < ps + cache) num2[ti]++;
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int ti = 0; ti < n; ++ti) {
+        const int oi = rows_of[ti];
+        const int ps = pb[part[oi]];
+        int64_t dst = rp[ti];
+        int in_window = 0;
+        for (int k = old_rp[oi]; k < old_rp[oi + 1]; ++k, ++dst) {
+            const int tj = list[m->J[k]];
+            nI[dst] = ti;
+            nJ[dst] = tj;
+            nV[dst] = m->V[k];
+            in_window += tj >= ps && tj < ps + cache;
+        }
+        num2[ti] = in_window;
     }
     free(m->I);
     free(m->J);
@@ -377,6 +416,7 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
     m->J = nJ;
     m->V = nV;
     m->maxCol = maxcol;
+    if (c.verbose) printf("permute time is %ld us\n", (long)((wall_seconds() - t_perm) * 1e6));
     return EHYB_OK;
 }
 
