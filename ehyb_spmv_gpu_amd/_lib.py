@@ -54,7 +54,8 @@ class Config(C.Structure):
         ("fuse_er", C.c_int32),
         ("cap_split", C.c_int32),
         ("hub_rule", C.c_int32),
-        ("reserved", C.c_int32 * 7),
+        ("sym_pairs", C.c_int32),
+        ("reserved", C.c_int32 * 6),
     ]
 
 
@@ -62,12 +63,12 @@ _STAT_NAMES = [
     "nnz", "nnz_ell", "nnz_er", "ell_padding", "size_block_ell", "size_er", "rows_er",
     "er_segments", "n_rows", "n_cols", "n_parts", "n_slabs", "n_items", "halo_cols",
     "window_loads", "bytes_format", "bytes_alg", "max_row", "lds_bytes", "col_words",
-    "er_inline",
+    "er_inline", "sym_pairs",
 ]
 
 
 class Stats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in _STAT_NAMES] + [("reserved", C.c_int64 * 3)]
+    _fields_ = [(n, C.c_int64) for n in _STAT_NAMES] + [("reserved", C.c_int64 * 2)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n in _STAT_NAMES}

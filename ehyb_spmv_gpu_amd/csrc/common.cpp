@@ -59,6 +59,14 @@ Config resolve_config(const ehyb_config* in)
     c.fuse_er = (z.fuse_er == 1 || z.fuse_er == 2) ? z.fuse_er : 0;  // 0 = automatic (ehyb_hip.hip: fuse_residual)
     c.cap_split = z.cap_split == 2 ? 2 : 1;
     c.hub_rule = z.hub_rule == 2 ? 2 : 1;
+    // Symmetric pair storage: the window also holds one accumulator per own row, so a partition gets
+    // at most 30 % of the budget as rows (x: own + halo, y: own); whole rows may not leave the ELL
+    // part (a residual row cannot scatter), so the hub rule is off.
+    c.sym_pairs = (z.sym_pairs == 1 && c.window_mode == EHYB_WINDOW_HALO && c.n_top <= 1) ? 1 : 2;
+    if (c.sym_pairs == 1) {
+        c.part_rows = std::max(kSlabRows, std::min(c.part_rows, round_down(c.lds_doubles * 3 / 10, kSlabRows)));
+        c.hub_rule = 2;
+    }
     return c;
 }
 
@@ -104,6 +112,12 @@ int ehyb_sizing(int dimension, const ehyb_config* cfg, int* nParts, int* vectorC
     int64_t parts = (dimension + usable - 1) / usable;
     if (c.n_top > 1) parts = (parts + c.n_top - 1) / c.n_top * c.n_top;
     if (parts < 1) parts = 1;
+    if (c.sym_pairs == 1 && parts > kNumCU / 2) {
+        // one workgroup per partition, all of equal size: whole rounds of 256 workgroups, and a cap
+        // just above the mean so that the partitioner keeps them equal
+        parts = (parts + kNumCU - 1) / kNumCU * kNumCU;
+        cache = (int)std::min<int64_t>(cache, (int64_t)((double)dimension / parts * 1.03) + 2);
+    }
     int64_t items = (int64_t)c.items_per_cu * kNumCU;
     int kpp = (int)std::max<int64_t>(1, (items + parts - 1) / parts);
     if (nParts) *nParts = (int)parts;

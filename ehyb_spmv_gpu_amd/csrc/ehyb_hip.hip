@@ -112,8 +112,24 @@ struct EllArgs {
     unsigned long long* __restrict__ stamps;
 };
 
-template <bool INLINE_ER>
-__device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restrict__ win, int s, int pe, int lane)
+// One entry of a slab: gather x from the window; SYM: bit 15 of the column says "this entry also
+// stands for its mirror image": value * x[own row] goes to row `column`'s accumulator in LDS.
+template <bool SYM>
+__device__ __forceinline__ void ell_entry(double v, uint32_t col16, const double* __restrict__ win, double* yacc, double xi,
+                                          double& acc)
+{
+    if (SYM) {
+        const uint32_t idx = col16 & 0x7fffu;
+        acc = fma(v, win[idx], acc);
+        if (col16 & 0x8000u) unsafeAtomicAdd(&yacc[idx], v * xi);  // ds_add_f64
+    } else {
+        acc = fma(v, win[col16], acc);
+    }
+}
+
+template <bool INLINE_ER, bool SYM>
+__device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restrict__ win, double* yacc, int s, int base,
+                                         int pe, int lane)
 {
     // slab record {first value pair, first column word, first row, pairs << 16 | residual pairs << 8 | groups - 1}
     const uint4 sm = A.slab_meta[s];
@@ -137,31 +153,41 @@ __device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restr
             acc1 = fma(vv.y, A.x[cb], acc1);
         }
     }
+    const int row = (int)sm.z + lane;
+    const int lrow = row - base;  // the row's place in the LDS image (x) and among the accumulators (y)
+    const double xi = (SYM && row < pe) ? win[lrow] : 0.0;
     int k = 0;
     for (; k + 4 <= np; k += 4) {
         const double2 v0 = v[(k + 0) * 64], v1 = v[(k + 1) * 64], v2 = v[(k + 2) * 64], v3 = v[(k + 3) * 64];
         const uint32_t c0 = c[(k + 0) * G], c1 = c[(k + 1) * G], c2 = c[(k + 2) * G], c3 = c[(k + 3) * G];
-        acc0 = fma(v0.x, win[c0 & 0xffffu], acc0);
-        acc1 = fma(v0.y, win[c0 >> 16], acc1);
-        acc0 = fma(v1.x, win[c1 & 0xffffu], acc0);
-        acc1 = fma(v1.y, win[c1 >> 16], acc1);
-        acc0 = fma(v2.x, win[c2 & 0xffffu], acc0);
-        acc1 = fma(v2.y, win[c2 >> 16], acc1);
-        acc0 = fma(v3.x, win[c3 & 0xffffu], acc0);
-        acc1 = fma(v3.y, win[c3 >> 16], acc1);
+        ell_entry<SYM>(v0.x, c0 & 0xffffu, win, yacc, xi, acc0);
+        ell_entry<SYM>(v0.y, c0 >> 16, win, yacc, xi, acc1);
+        ell_entry<SYM>(v1.x, c1 & 0xffffu, win, yacc, xi, acc0);
+        ell_entry<SYM>(v1.y, c1 >> 16, win, yacc, xi, acc1);
+        ell_entry<SYM>(v2.x, c2 & 0xffffu, win, yacc, xi, acc0);
+        ell_entry<SYM>(v2.y, c2 >> 16, win, yacc, xi, acc1);
+        ell_entry<SYM>(v3.x, c3 & 0xffffu, win, yacc, xi, acc0);
+        ell_entry<SYM>(v3.y, c3 >> 16, win, yacc, xi, acc1);
     }
     for (; k < np; ++k) {
         const double2 v0 = v[k * 64];
         const uint32_t c0 = c[k * G];
-        acc0 = fma(v0.x, win[c0 & 0xffffu], acc0);
-        acc1 = fma(v0.y, win[c0 >> 16], acc1);
+        ell_entry<SYM>(v0.x, c0 & 0xffffu, win, yacc, xi, acc0);
+        ell_entry<SYM>(v0.y, c0 >> 16, win, yacc, xi, acc1);
     }
-    const int row = (int)sm.z + lane;
-    if (row < pe) A.y[row] = acc0 + acc1;
+    if (row < pe) {
+        if (SYM)
+            unsafeAtomicAdd(&yacc[lrow], acc0 + acc1);  // other lanes scatter into the same accumulator
+        else
+            A.y[row] = acc0 + acc1;
+    }
 }
 
 // Stage the window of segment g and multiply its slabs.
-template <int THREADS, bool DYN, bool INLINE_ER>
+// SYM (symmetric pair storage): the segment is a whole partition; its rows' accumulators sit in LDS
+// right behind the x image, take the lanes' own sums and the scattered mirror products, and are
+// written to y in one coalesced sweep at the end.
+template <int THREADS, bool DYN, bool INLINE_ER, bool SYM>
 __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict__ win, int* __restrict__ next_slab,
                                             int g, int lane, int wave)
 {
@@ -173,13 +199,16 @@ __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict
     // The LDS image starts at the even row at or below the partition start (the layout builder
     // numbers window-local columns from there); win[0] may hold x[ps-1], unused.
     const int base = ps & ~1, cnt = wl + (ps & 1);
+    double* yacc = win + cnt + hn;
     for (int i = threadIdx.x; i < cnt; i += THREADS) win[i] = A.x[base + i];
     for (int i = threadIdx.x; i < hn; i += THREADS) win[cnt + i] = A.x[A.halo_cols[hb + i]];
+    if (SYM)
+        for (int i = threadIdx.x; i < cnt; i += THREADS) yacc[i] = 0.0;
     if (DYN && threadIdx.x == 0) *next_slab = sb + WAVES;  // slabs sb..sb+WAVES-1 are pre-assigned
     __syncthreads();
     int s = sb + wave;
     while (s < se) {
-        ell_slab<INLINE_ER>(A, win, s, pe, lane);
+        ell_slab<INLINE_ER, SYM>(A, win, yacc, s, base, pe, lane);
         if (DYN) {
             int nx = 0;
             if (lane == 0) nx = atomicAdd(next_slab, 1);
@@ -188,9 +217,13 @@ __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict
             s += WAVES;
         }
     }
+    if (SYM) {
+        __syncthreads();  // all sums and scatters of the partition are in
+        for (int i = threadIdx.x + (ps & 1); i < cnt; i += THREADS) A.y[base + i] = yacc[i];
+    }
 }
 
-template <int THREADS, bool DYN, bool STAMP, bool INLINE_ER>
+template <int THREADS, bool DYN, bool STAMP, bool INLINE_ER, bool SYM>
 // 8 waves per SIMD (<= 64 VGPRs): two 1024-thread workgroups per CU, the occupancy the 80 KiB window is sized for
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void ehyb_ell_kernel(const EllArgs A)
 {
@@ -201,7 +234,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8)))
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int sg = it.x; sg < it.y; ++sg) {
-        ell_segment<THREADS, DYN, INLINE_ER>(A, win, next_slab, sg, lane, wave);
+        ell_segment<THREADS, DYN, INLINE_ER, SYM>(A, win, next_slab, sg, lane, wave);
         if (STAMP && sg == it.x && threadIdx.x == 0) A.stamps[4 * blockIdx.x + 1] = wall_clock64();
     }
     if (STAMP) {
@@ -279,18 +312,22 @@ static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t
     const size_t lds = ell_lds_bytes(H);
     const bool dyn = P->cfg.ell_variant != 3;
     const EllArgs A = ell_args(P, x, y, stamps);
-#define ELL_GO(T, M, I)                                                                                      \
+    const bool sym = H.sym;
+#define ELL_GO(T, M, I, S)                                                                                   \
     {                                                                                                        \
-        if (STAMP) HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<T, M, STAMP, I>,                 \
+        if (STAMP) HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<T, M, STAMP, I, S>,              \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \
-        hipLaunchKernelGGL((ehyb_ell_kernel<T, M, STAMP, I>), dim3(n_items), dim3(T), lds, st, A);           \
+        hipLaunchKernelGGL((ehyb_ell_kernel<T, M, STAMP, I, S>), dim3(n_items), dim3(T), lds, st, A);        \
     }
-#define ELL_MODE(T, I)           \
-    if (dyn) ELL_GO(T, true, I)  \
-    else ELL_GO(T, false, I)
-#define ELL_LAUNCH(T)            \
-    if (inl) { ELL_MODE(T, true) } \
-    else { ELL_MODE(T, false) }
+#define ELL_MODE(T, I, S)           \
+    if (dyn) ELL_GO(T, true, I, S)  \
+    else ELL_GO(T, false, I, S)
+#define ELL_INL(T, S)                 \
+    if (inl) { ELL_MODE(T, true, S) } \
+    else { ELL_MODE(T, false, S) }
+#define ELL_LAUNCH(T)           \
+    if (sym) { ELL_INL(T, true) } \
+    else { ELL_INL(T, false) }
     switch (P->cfg.threads) {
         case 256: ELL_LAUNCH(256) break;
         case 512: ELL_LAUNCH(512) break;
@@ -298,6 +335,7 @@ static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t
         default: EHYB_FAIL(EHYB_ERR_ARG, "ELL workgroup size %d not built (256/512/1024)", P->cfg.threads);
     }
 #undef ELL_LAUNCH
+#undef ELL_INL
 #undef ELL_MODE
 #undef ELL_GO
     HIP_TRY(hipGetLastError());
@@ -487,11 +525,14 @@ int ehyb_plan_upload(ehyb_plan* P)
     // opt in to the full 160 KiB of LDS (the role of cudaFuncSetAttribute at kernel.cu:351,411)
     const int lds = (int)ell_lds_bytes(H);
 #define LDS_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
-#define LDS_ATTR_T(T)                                   \
-    LDS_ATTR((ehyb_ell_kernel<T, false, false, false>)) \
-    LDS_ATTR((ehyb_ell_kernel<T, false, false, true>))  \
-    LDS_ATTR((ehyb_ell_kernel<T, true, false, false>))  \
-    LDS_ATTR((ehyb_ell_kernel<T, true, false, true>))
+#define LDS_ATTR_S(T, S)                                   \
+    LDS_ATTR((ehyb_ell_kernel<T, false, false, false, S>)) \
+    LDS_ATTR((ehyb_ell_kernel<T, false, false, true, S>))  \
+    LDS_ATTR((ehyb_ell_kernel<T, true, false, false, S>))  \
+    LDS_ATTR((ehyb_ell_kernel<T, true, false, true, S>))
+#define LDS_ATTR_T(T)      \
+    LDS_ATTR_S(T, false)   \
+    LDS_ATTR_S(T, true)
     LDS_ATTR_T(256)
     LDS_ATTR_T(512)
     LDS_ATTR_T(1024)

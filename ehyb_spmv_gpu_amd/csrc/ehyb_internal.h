@@ -42,6 +42,7 @@ struct Config {
     int fuse_er;
     int cap_split;
     int hub_rule;
+    int sym_pairs;
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -94,6 +95,10 @@ struct HostLayout {
     // inline form: the residual is also stored as extra pairs behind each slab's ELL pairs
     // (slab_meta word 3, bits 8..15) and the ELL launch multiplies it
     bool inline_er = false;
+    // symmetric pair storage: bit 15 of a 16-bit column = "also add value * x[row] to row `column`";
+    // the accumulators of a partition's rows live in LDS behind the window (yacc_doubles of them)
+    bool sym = false;
+    int yacc_doubles = 0;
 
     ehyb_stats stats{};
 };

@@ -44,6 +44,108 @@ inline int halo_lookup(const std::vector<int32_t>& halo, int col)
     return -1;
 }
 
+// Symmetric pair storage for the rows [s, e) of one partition.  For every pair of in-partition
+// entries (i,j), (j,i) with bitwise equal values one of the two is kept with the "scatter" mark
+// (state 1: the lane of row i also adds a_ij * x_i to row j) and the other is dropped (state 2);
+// every other entry stays as it is (state 0), so nothing depends on the matrix being symmetric.
+//   * Which side keeps a pair is decided per pair of row GROUPS (consecutive rows with identical
+//     column lists -- the d unknowns of a finite-element node): all rows of a group make the same
+//     choice, so their stored column lists stay identical and can still be shared.
+//   * The choice is an Euler-trail orientation of the group graph: every group keeps half of its
+//     pairs, give or take one, so rows that were equally long stay equally long (a slab is as wide
+//     as its longest row).
+//   * Entries inside a group (the diagonal blocks) stay as they are.
+// state is indexed by entry number minus k0.
+void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64_t k0, uint8_t* state)
+{
+    const int own = e - s;
+    const int* J = m->J;
+    const double* V = m->V;
+    std::vector<int> grp(own), gfirst;
+    for (int r = s; r < e; ++r) {
+        const int len = rp[r + 1] - rp[r];
+        const bool same = r > s && len == rp[r] - rp[r - 1] && (len == 0 || memcmp(J + rp[r], J + rp[r - 1], sizeof(int) * (size_t)len) == 0);
+        if (!same) gfirst.push_back(r);
+        grp[r - s] = (int)gfirst.size() - 1;
+    }
+    const int G = (int)gfirst.size();
+    // neighbour groups of every group (from its first row), sorted
+    std::vector<std::vector<int>> nb(G);
+    for (int g = 0; g < G; ++g) {
+        const int r = gfirst[g];
+        for (int k = rp[r]; k < rp[r + 1]; ++k)
+            if (J[k] >= s && J[k] < e && grp[J[k] - s] != g) nb[g].push_back(grp[J[k] - s]);
+        std::sort(nb[g].begin(), nb[g].end());
+        nb[g].erase(std::unique(nb[g].begin(), nb[g].end()), nb[g].end());
+    }
+    // edges = pairs that see each other; incidence lists (other end, edge)
+    std::vector<std::vector<std::pair<int, int>>> inc(G);
+    int n_edges = 0;
+    for (int g = 0; g < G; ++g)
+        for (int h : nb[g])
+            if (h > g && std::binary_search(nb[h].begin(), nb[h].end(), g)) {
+                inc[g].push_back({h, n_edges});
+                inc[h].push_back({g, n_edges});
+                ++n_edges;
+            }
+    std::vector<int> owner(n_edges, -1), left(G);
+    std::vector<size_t> at(G, 0);
+    for (int g = 0; g < G; ++g) left[g] = (int)inc[g].size();
+    auto walk = [&](int v) {
+        for (;;) {
+            while (at[v] < inc[v].size() && owner[inc[v][at[v]].second] >= 0) ++at[v];
+            if (at[v] == inc[v].size()) return;
+            const int u = inc[v][at[v]].first, id = inc[v][at[v]].second;
+            owner[id] = v;
+            --left[v];
+            --left[u];
+            v = u;
+        }
+    };
+    for (int g = 0; g < G; ++g)
+        if (left[g] & 1) walk(g);  // open trails first: they start and end at odd vertices
+    for (int g = 0; g < G; ++g)
+        while (left[g] > 0) walk(g);  // what is left is Eulerian: closed trails
+    std::vector<std::vector<int>> keeps(G);  // groups whose pairs group g keeps, sorted
+    for (int g = 0; g < G; ++g) {
+        for (const auto& oe : inc[g])
+            if (owner[oe.second] == g) keeps[g].push_back(oe.first);
+        std::sort(keeps[g].begin(), keeps[g].end());
+    }
+    // in-partition entries of every row sorted by column, to find partners
+    std::vector<int> ip_ptr(own + 1, 0);
+    for (int r = s; r < e; ++r) {
+        int c = 0;
+        for (int k = rp[r]; k < rp[r + 1]; ++k) c += J[k] >= s && J[k] < e;
+        ip_ptr[r - s + 1] = ip_ptr[r - s] + c;
+    }
+    std::vector<std::pair<int, int>> ip(ip_ptr[own]);  // (column, entry)
+    for (int r = s; r < e; ++r) {
+        int q = ip_ptr[r - s];
+        for (int k = rp[r]; k < rp[r + 1]; ++k)
+            if (J[k] >= s && J[k] < e) ip[q++] = {J[k], k};
+        std::sort(ip.begin() + ip_ptr[r - s], ip.begin() + ip_ptr[r - s + 1]);
+    }
+    for (int i = s; i < e; ++i) {
+        const int g = grp[i - s];
+        if (keeps[g].empty()) continue;
+        for (int k = rp[i]; k < rp[i + 1]; ++k) {
+            const int j = J[k];
+            if (j < s || j >= e || state[k - k0] != 0) continue;
+            const int h = grp[j - s];
+            if (h == g || !std::binary_search(keeps[g].begin(), keeps[g].end(), h)) continue;
+            // the partner (j, i): first unclaimed entry of row j in column i with the same value
+            auto lo = std::lower_bound(ip.begin() + ip_ptr[j - s], ip.begin() + ip_ptr[j - s + 1], std::make_pair(i, -1));
+            for (; lo != ip.begin() + ip_ptr[j - s + 1] && lo->first == i; ++lo)
+                if (state[lo->second - k0] == 0 && V[lo->second] == V[k]) {
+                    state[k - k0] = 1;
+                    state[lo->second - k0] = 2;
+                    break;
+                }
+        }
+    }
+}
+
 }  // namespace
 
 int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* L)
@@ -65,6 +167,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     // 10,240-double budget is exactly 80 KiB and two workgroups still fit one CU's 160 KiB.
     const int lds = std::max(kSlabRows, cfg.lds_doubles - 2);
     const bool halo_mode = cfg.window_mode == EHYB_WINDOW_HALO;
+    const bool sym = cfg.sym_pairs == 1 && halo_mode && cfg.n_top <= 1;  // symmetric pair storage
 
     // ---- partitions: the caller's, cut down to the window capacity where needed
     std::vector<int32_t>& pb = L->part_boundary;
@@ -91,7 +194,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         } else {
             src = {row_begin, row_end};
         }
-        const int cap0 = have_parts ? lds : std::min(lds, cfg.part_rows);
+        const int cap0 = have_parts ? lds / (sym ? 2 : 1) : std::min(lds / (sym ? 2 : 1), cfg.part_rows);
         for (size_t k = 0; k + 1 < src.size(); ++k) {
             int b = src[k], e = src[k + 1];
             if (e == b) continue;  // empty partition
@@ -102,7 +205,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 bool fits = true;
                 for (int q = 0; q < pieces && fits; ++q) {
                     int s0 = b + (int)((int64_t)(e - b) * q / pieces), s1 = b + (int)((int64_t)(e - b) * (q + 1) / pieces);
-                    fits = (s0 & 1) + (s1 - s0) <= lds;
+                    fits = ((s0 & 1) + (s1 - s0)) * (sym ? 2 : 1) <= lds;  // symmetric pairs: x image + y accumulators
                 }
                 if (fits || cap <= 2) {
                     for (int q = 0; q < pieces; ++q) pb.push_back(b + (int)((int64_t)(e - b) * q / pieces));
@@ -118,6 +221,26 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     L->row_begin = row_begin;
     L->row_end = row_end;
     const int nrows = row_end - row_begin;
+
+    // ---- symmetric pair storage (cfg.sym_pairs): which entries carry their partner, which are dropped
+    const int64_t k0 = rp[row_begin];
+    std::vector<uint8_t> state;       // per entry: 0 as it is, 1 kept + scatter, 2 dropped
+    std::vector<int32_t> dropped;     // per row
+    if (sym) {
+        state.assign((size_t)(rp[row_end] - k0), 0);
+        dropped.assign(nrows, 0);
+#pragma omp parallel for schedule(dynamic, 2)
+        for (int p = 0; p < np; ++p) {
+            sym_orient_partition(m, rp, pb[p], pb[p + 1], k0, state.data());
+            for (int r = pb[p]; r < pb[p + 1]; ++r) {
+                int d = 0;
+                for (int k = rp[r]; k < rp[r + 1]; ++k) d += state[k - k0] == 2;
+                dropped[r - row_begin] = d;
+            }
+        }
+    }
+    L->sym = sym;
+    L->yacc_doubles = 0;
 
     // ---- pass 1: window contents, per-row ELL counts, slab widths
     std::vector<PartScratch> ps(np);
@@ -141,7 +264,9 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 wlen = std::min(lds - (s & 1), std::min(n, cfg.n_top > 1 ? row_end : n) - s);
             } else {
                 wlen = own;
-                int hcap = lds - own - (s & 1);  // the LDS image starts at the even row below s
+                // the LDS image starts at the even row below s; with symmetric pairs it is followed
+                // by one accumulator per image row
+                int hcap = lds - (own + (s & 1)) * (sym ? 2 : 1);
                 cand.clear();
                 for (int r = s; r < e; ++r)
                     for (int k = rp[r]; k < rp[r + 1]; ++k) {
@@ -188,6 +313,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                         continue;
                     }
                     if (m->I && m->I[k] != r) bad_row = 1;  // convert.c:243-246 "row val check"
+                    if (sym && state[k - k0] == 2) continue;  // its partner carries it
                     if (j >= s && j < s + wlen)
                         ++c;
                     else if (halo_mode && !S.halo.empty() && halo_lookup(S.halo, j) >= 0)
@@ -242,6 +368,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                     const int len = rp[r + 1] - rp[r];
                     lead = len != rp[r] - rp[r - 1] ||
                            (len > 0 && memcmp(m->J + rp[r], m->J + rp[r - 1], sizeof(int) * (size_t)len) != 0);
+                    // symmetric pairs: the kept / scatter / dropped pattern must be the same as well
+                    if (!lead && sym && len > 0 && memcmp(&state[rp[r] - k0], &state[rp[r - 1] - k0], (size_t)len) != 0) lead = true;
                 }
                 lead_row[r - row_begin] = lead ? 1 : 0;
                 S.slab_g[(r - s) / kSlabRows] += lead ? 1 : 0;
@@ -254,12 +382,16 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     // residual row pointer (row order)
     std::vector<int64_t> er_rp(nrows + 1, 0);
     for (int r = 0; r < nrows; ++r) {
-        int len = rp[row_begin + r + 1] - rp[row_begin + r];
+        int len = rp[row_begin + r + 1] - rp[row_begin + r] - (sym ? dropped[r] : 0);
         er_rp[r + 1] = er_rp[r] + (len - cnt_ell[r]);
     }
     const int64_t nnz_er = er_rp[nrows];
     const int64_t nnz = (int64_t)rp[row_end] - rp[row_begin];
-    const int64_t nnz_ell = nnz - nnz_er;
+    const int64_t nnz_ell = nnz - nnz_er;  // entries the ELL part stands for (a kept pair entry counts twice)
+    int64_t stored_ell = 0, sym_kept = 0;
+    for (int r = 0; r < nrows; ++r) stored_ell += cnt_ell[r];
+    if (sym)
+        for (uint8_t st8 : state) sym_kept += st8 == 1;
 
     // ---- inline form of a tiny residual.  The residual entries of a slab's rows are stored as
     // extra pairs behind the slab's ELL pairs -- values in the same stream, columns as two global
@@ -294,7 +426,11 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     for (int p = 0; p < np; ++p) {
         L->halo_ptr[p + 1] = L->halo_ptr[p] + (int32_t)ps[p].halo.size();
         slab_base[p + 1] = slab_base[p] + (int64_t)ps[p].slab_w2.size();
-        max_win = std::max(max_win, (pb[p] & 1) + L->win_len[p] + (int)ps[p].halo.size());
+        // the partition's x image (own rows from the even row below the start, then the halo) and,
+        // with symmetric pairs, one y accumulator per image row right behind it
+        const int image = (pb[p] & 1) + L->win_len[p];
+        max_win = std::max(max_win, image + (int)ps[p].halo.size() + (sym ? image : 0));
+        if (sym) L->yacc_doubles = std::max(L->yacc_doubles, image);
     }
     if (max_win > lds) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: window of %d doubles exceeds %d", max_win, lds);
     L->lds_doubles = max_win;
@@ -374,6 +510,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             for (int k = rp[r]; k < rp[r + 1]; ++k) {
                 int j = m->J[k];
                 int local = -1;
+                const uint8_t st8 = sym ? state[k - k0] : 0;
+                if (st8 == 2) continue;  // symmetric pair: stored with its partner
                 // window-local index: the LDS image starts at the even row at or below s, so the
                 // staging loads of the kernel are 16-byte aligned (x is hipMalloc-aligned)
                 if (row_to_er[r - row_begin])
@@ -391,6 +529,13 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                     }
                     size_t at = (size_t)(((pp + k_ell / 2) * kSlabRows + lane) * 2 + (k_ell & 1));
                     L->ell_val[at] = m->V[k];
+                    if (st8 == 1) {
+                        if (local >= 0x8000 || j < s || j >= e) {  // only own rows have an accumulator
+                            overflow = 1;
+                            continue;
+                        }
+                        local |= 0x8000;  // bit 15: also add value * x[row] to row `local`
+                    }
                     if (lead)  // two 16-bit window-local columns per word, one word per pair and group
                         L->ell_col[(size_t)(cp + (uint64_t)(k_ell / 2) * G + gid)] |= (uint32_t)local << (16 * (k_ell & 1));
                     ++k_ell;
@@ -456,6 +601,13 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             if (c > cuts.back() && c < nslabs) cuts.push_back(c);
         }
         if (nslabs > 0) cuts.push_back(nslabs);
+        if (sym) {
+            // symmetric pairs: the accumulators of a partition's rows live in one workgroup's LDS, so
+            // an item is a whole partition (the reorder step makes them equal: nParts = k x 256)
+            cuts.clear();
+            for (int p = 0; p <= np; ++p)
+                if (cuts.empty() || slab_base[p] > cuts.back()) cuts.push_back(slab_base[p]);
+        }
         L->items.clear();
         L->segs.clear();
         int64_t window_loads = 0;
@@ -559,7 +711,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     st.nnz_ell = nnz_ell;
     st.nnz_er = nnz_er;
     st.size_block_ell = size_ell;
-    st.ell_padding = size_ell - nnz_ell;
+    st.ell_padding = size_ell - stored_ell;
+    st.sym_pairs = sym_kept;
     st.size_er = nnz_er;
     st.rows_er = rows_er;
     st.er_segments = nseg;
@@ -584,6 +737,13 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                       4 * halo_item_loads + 8 * (int64_t)nrows +
                       (L->inline_er ? 8 * st.er_inline + 8 * nnz_er : 12 * nnz_er + 12 * nseg + 16 * nseg);
     if (nnz_ell + nnz_er != nnz) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: %lld + %lld != %lld", (long long)nnz_ell, (long long)nnz_er, (long long)nnz);
+    if (sym) {
+        int64_t gone = 0;
+        for (int r = 0; r < nrows; ++r) gone += dropped[r];
+        // every dropped entry has exactly one kept partner, and the ELL part stands for both
+        if (gone != sym_kept || stored_ell + gone != nnz_ell)
+            EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: symmetric pairs do not add up (%lld kept, %lld dropped)", (long long)sym_kept, (long long)gone);
+    }
     if (cfg.verbose) {
         printf("toER is %lld, kernel calculation is %lld\n", (long long)nnz_er, (long long)nnz_ell);
         printf("wasteElement is %lld\n", (long long)st.ell_padding);

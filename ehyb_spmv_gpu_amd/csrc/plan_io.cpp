@@ -3,8 +3,8 @@
 // mt-metis + COO2EHYB on every run (solver_test.c:369-382, spmv.cu:74); on the bench matrix that
 // is seconds of host work in front of a 0.14 ms multiply.
 //
-// File: "EHYBPLN2", key, resolved Config, layout scalars, stats, then every array as
-// {u64 count, bytes}, then "EHYBEND2".  Native byte order, same-machine cache -- not an
+// File: "EHYBPLN3", key, resolved Config, layout scalars, stats, then every array as
+// {u64 count, bytes}, then "EHYBEND3".  Native byte order, same-machine cache -- not an
 // interchange format.  A file whose magic, version, key or sizes do not fit is rejected.
 #include "ehyb_internal.h"
 
@@ -17,8 +17,8 @@ using namespace ehyb;
 
 namespace {
 
-const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '2'};
-const char kEnd[8] = {'E', 'H', 'Y', 'B', 'E', 'N', 'D', '2'};
+const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '3'};
+const char kEnd[8] = {'E', 'H', 'Y', 'B', 'E', 'N', 'D', '3'};
 
 struct FileCloser {
     void operator()(FILE* f) const
@@ -67,6 +67,7 @@ bool each_array(HostLayout& H, F&& io)
 struct Scalars {
     int32_t n_cols, row_begin, row_end, n_parts, lds_doubles, inline_er;
     int32_t er_bins[8];
+    int32_t sym, yacc_doubles;
 };
 
 }  // namespace
@@ -103,7 +104,7 @@ int ehyb_plan_save(const ehyb_plan* plan, const int* reorder_list, uint64_t matr
     HostLayout& H = const_cast<HostLayout&>(plan->host);  // each_array takes non-const; nothing is modified
     File f(fopen(path, "wb"));
     if (!f) EHYB_FAIL(EHYB_ERR_IO, "ehyb_plan_save: cannot create %s", path);
-    Scalars s{H.n_cols, H.row_begin, H.row_end, H.n_parts, H.lds_doubles, H.inline_er ? 1 : 0, {0}};
+    Scalars s{H.n_cols, H.row_begin, H.row_end, H.n_parts, H.lds_doubles, H.inline_er ? 1 : 0, {0}, H.sym ? 1 : 0, H.yacc_doubles};
     memcpy(s.er_bins, H.er_bins, sizeof s.er_bins);
     std::vector<int32_t> perm;
     if (reorder_list) perm.assign(reorder_list, reorder_list + H.n_cols);
@@ -150,6 +151,7 @@ int ehyb_plan_load(const char* path, uint64_t expect_key, ehyb_plan** plan, int*
     }
     H.n_cols = s.n_cols, H.row_begin = s.row_begin, H.row_end = s.row_end, H.n_parts = s.n_parts;
     H.lds_doubles = s.lds_doubles, H.inline_er = s.inline_er != 0;
+    H.sym = s.sym != 0, H.yacc_doubles = s.yacc_doubles;
     memcpy(H.er_bins, s.er_bins, sizeof s.er_bins);
     // the sizes the kernels rely on must fit together -- a damaged file must not reach the GPU
     const size_t nslab = H.slab_row.size(), nseg = H.er_seg_row.size();

@@ -231,7 +231,8 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
                                 for (int k = rp0[i]; k < rp0[i + 1]; ++k)
                                     if (part[m->J[k]] != p) o.push_back(m->J[k]);
                             std::sort(o.begin(), o.end());
-                            demand[p] = (int)members[p].size() + 1 + (int)(std::unique(o.begin(), o.end()) - o.begin());
+                            // own rows (twice with symmetric pair storage: x and the y accumulators) + halo
+                            demand[p] = (int)members[p].size() * (c.sym_pairs == 1 ? 2 : 1) + 2 + (int)(std::unique(o.begin(), o.end()) - o.begin());
                         }
                     }
                     std::vector<int> offenders;
@@ -305,7 +306,9 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
     for (int i = 0; i < n; ++i) {
         int cnt = 0;
         for (int k = m->rowIdx[i]; k < m->rowIdx[i + 1]; ++k) cnt += part[m->J[k]] == part[i];
-        inpart[i] = cnt;
+        // symmetric pair storage keeps about half of a row's in-partition entries (and all of its
+        // halo entries, added below): the sort key is the number of entries the row will STORE
+        inpart[i] = c.sym_pairs == 1 ? (cnt + 3) / 2 : cnt;
     }
 
     // rows of each partition, old order, then stable sort by inpart descending (reordering.c:334)
@@ -325,7 +328,8 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
 #pragma omp for schedule(dynamic, 4)
             for (int p = 0; p < nparts; ++p) {
                 const int own = pb[p + 1] - pb[p];
-                const int hcap = c.lds_doubles - 2 - own - (pb[p] & 1);  // 2 doubles hold the kernel's slab counter
+                // 2 doubles hold the kernel's slab counter; symmetric pair storage keeps y accumulators too
+                const int hcap = c.lds_doubles - 2 - (own + (pb[p] & 1)) * (c.sym_pairs == 1 ? 2 : 1);
                 if (hcap <= 0) continue;
                 cand.clear();
                 for (int q = pb[p]; q < pb[p + 1]; ++q) {

@@ -91,7 +91,14 @@ typedef struct ehyb_config {
     int32_t cap_split;     /* 0/1 = bisect partitions whose halo overflows the window (reorder step), 2 = off */
     int32_t hub_rule;      /* 0/1 = rows that would pad their slab by > 25 % go to the residual whole
                               (the reference's long-row intent, convert.c:92-101), 2 = off          */
-    int32_t reserved[7];
+    int32_t sym_pairs;     /* symmetric pair storage (single GPU, halo window): an in-partition pair a_ij == a_ji is
+                              stored once; the owning lane adds a_ij*x_j to its own row and a_ij*x_i to row
+                              j's accumulator in LDS (ds_add_f64), so the value stream is read once for two
+                              entries.  One workgroup per partition, nParts a multiple of 256.  Results do
+                              not depend on the matrix being symmetric (unmatched entries stay as they are)
+                              but the order of the LDS adds varies from run to run (last-bit differences).
+                              0 = default (on for the single-GPU halo window), 1 = on, 2 = off            */
+    int32_t reserved[6];
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);
@@ -196,7 +203,9 @@ typedef struct ehyb_stats {
     int64_t col_words;      /* stored 4-byte column words (2 x 16 bit) after sharing  */
     int64_t er_inline;      /* stored inline-residual elements incl. padding; > 0: the residual rides in
                                the ELL launch (ehyb_spmv is one launch), see EHYB_ARR_SLAB_META */
-    int64_t reserved[3];
+    int64_t sym_pairs;      /* stored entries that stand for a symmetric pair (cfg.sym_pairs): nnz_ell counts
+                               both entries of such a pair, size_block_ell one                          */
+    int64_t reserved[2];
 } ehyb_stats;
 int ehyb_plan_stats(const ehyb_plan* plan, ehyb_stats* out);
 

@@ -169,6 +169,8 @@ def walk_plan(plan, x):
     seg_done = np.zeros(len(seg_row), dtype=np.int32)
     inline = plan.stats["er_inline"] > 0
     y_inl = np.zeros(n)
+    sym = plan.stats["sym_pairs"] > 0
+    y_mirror = np.zeros(n)
     next_seg, next_slab = 0, 0
     for g0, g1, is0, is1, e0, e64, e16, e1 in items:
         # an item = consecutive segments covering the consecutive slabs [is0, is1)
@@ -207,6 +209,19 @@ def walk_plan(plan, x):
                     v = ell_val[p0 * 128:p1 * 128].reshape(npairs, 64, 2)
                     words = ell_col[scp[s]:scp[s] + npairs * G].reshape(npairs, G)[:, lane_group[s]]  # [pair][lane]
                     c = np.stack([words & 0xFFFF, words >> 16], axis=2)
+                    if sym:
+                        # symmetric pair storage: bit 15 = "this entry also stands for its mirror image":
+                        # value * x[row of the lane] goes to row `column` of the same partition
+                        mirror = (c >> 15).astype(bool)
+                        c = c & 0x7FFF
+                        assert not mirror.any() or (c[mirror].max() < (ps & 1) + wl and c[mirror].min() >= (ps & 1)), "mirror target outside the partition's rows"
+                        r0s = int(slab_row[s])
+                        xrow = np.zeros(64)
+                        xrow[:min(64, pe - r0s)] = x[r0s:min(r0s + 64, pe)]
+                        contrib = v * xrow[None, :, None]
+                        # lanes past the partition end read the last group's words: their values are zero
+                        assert not contrib[mirror & (np.arange(64)[None, :, None] >= pe - r0s)].any(), "a padding lane scatters a value"
+                        np.add.at(y_mirror, base + c[mirror], contrib[mirror])
                     assert c.max() < len(win), "window-local column outside the window"
                     acc = (v * win[c]).sum(axis=(0, 2))
                 r0 = int(slab_row[s])
@@ -228,6 +243,11 @@ def walk_plan(plan, x):
         y_seg = np.zeros(n)
         np.add.at(y_seg, seg_row & 0x7FFFFFFF, np.add.reduceat(er_val * x[er_col], seg_ptr[:-1]))
         assert np.allclose(y_inl, y_seg, rtol=0, atol=1e-12 * (np.abs(y_seg).max() + 1e-300))
+    y += y_mirror
+    if sym:
+        # one workgroup holds a partition's accumulators: every item is exactly one partition
+        assert np.all(items[:, 1] - items[:, 0] == 1)
+        assert np.all(segs[:, 1] == np.searchsorted(slab_part, segs[:, 0])) and np.all(segs[:, 2] == np.searchsorted(slab_part, segs[:, 0], side="right"))
     if len(seg_row):
         prod = er_val * x[er_col]
         sums = np.add.reduceat(prod, seg_ptr[:-1]) if len(prod) else np.zeros(0)

@@ -1,0 +1,57 @@
+"""GPU parity of symmetric pair storage (cfg.sym_pairs = 1): an in-partition pair a_ij == a_ji is
+stored once; the owning lane adds a_ij * x_j to its own row and a_ij * x_i to row j's accumulator in
+LDS (ds_add_f64).  Same tolerance as every other path; the order of the LDS adds is not fixed, so
+two runs may differ in the last bits -- by far less than the tolerance."""
+import numpy as np
+import pytest
+
+from util import Case
+
+pytestmark = pytest.mark.gpu
+
+CASES = [
+    ("fem3d-3dof", "fem3d", (30000, 3, 22, 22, 13500, 1, 1)),      # symmetric, shared column lists
+    ("fem3d-1dof", "fem3d", (20000, 1, 30, 30, 50000, 1, 2)),
+    ("stencil", "stencil2d", (150, 150, 9, 3000, 1)),               # symmetric, short rows
+    ("kkt", "kkt3d", (18,)),                                        # symmetric saddle point, zero diagonal block
+    ("rmat", "rmat", (13, 1 << 16, 9)),                             # unsymmetric: almost nothing pairs up
+]
+
+
+@pytest.mark.parametrize("name,kind,args", CASES, ids=[c[0] for c in CASES])
+@pytest.mark.parametrize("lds,threads", [(2048, 256), (6144, 1024), (20480, 512)])
+def test_sym_matches_oracle(E, O, gpu, name, kind, args, lds, threads):
+    cfg = E.make_config(lds_doubles=lds, threads=threads, sym_pairs=1)
+    c = Case(E, O, kind, args, cfg)
+    plan = E.Plan(c.m, cfg)
+    st = plan.stats
+    assert st["nnz_ell"] + st["nnz_er"] == c.nnz
+    if name != "rmat":
+        assert st["sym_pairs"] > 0.2 * c.nnz
+    y1 = plan.spmv_host(c.xp, iters=2)
+    bad, worst = c.check(y1)
+    assert bad == 0, f"{name} lds={lds}: {bad} rows over tolerance, worst {worst:.3e}"
+    y2 = plan.spmv_host(c.xp)
+    assert np.max(np.abs(y1 - y2)) <= 1e-13 * c.scale.max()      # run-to-run: last bits only
+    # two-phase call (what a multi-GPU caller would use) agrees as well
+    dx, dy = E.DeviceBuffer(c.n).upload(c.xp), E.DeviceBuffer(c.n)
+    plan.spmv(dx.ptr, dy.ptr, phase=1)
+    plan.spmv(dx.ptr, dy.ptr, phase=2)
+    assert c.check(dy.download())[0] == 0
+
+
+def test_sym_full_size_audikw_like(E, O, gpu):
+    """BASELINE config 2 in full with symmetric pair storage: 512 equal partitions, one workgroup each."""
+    cfg = E.make_config(sym_pairs=1)
+    c = Case(E, O, "fem3d", (943695, 3, 68, 68, 13500, 1, 1), cfg)
+    plan = E.Plan(c.m, cfg)
+    st = plan.stats
+    assert st["n_parts"] == st["n_items"] == 512
+    assert st["sym_pairs"] > 0.35 * c.nnz and st["size_block_ell"] < 0.68 * c.nnz
+    y = plan.spmv_host(c.xp)
+    bad, worst = c.check(y)
+    assert bad == 0, f"worst {worst:.3e}"
+    # checksum of checksums: sum_i y_i == sum_j (column sum_j) x_j
+    colsum = np.zeros(c.n)
+    np.add.at(colsum, c.m.J, c.m.V)
+    assert abs(y.sum() - float(colsum @ c.xp)) <= 1e-11 * float(np.abs(c.m.V).sum())

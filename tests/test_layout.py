@@ -297,3 +297,42 @@ def test_bad_inputs_are_rejected(E, O):
     m.row_idx[2] = m.row_idx[3] + 5
     with pytest.raises(E.EhybError):
         E.Plan(m, cfg, upload=False)
+
+
+@pytest.mark.parametrize("case", ["fem3d", "stencil", "rmat", "pattern-symmetric-only"])
+def test_symmetric_pair_storage(E, O, case):
+    """cfg.sym_pairs: an in-partition pair a_ij == a_ji is stored once and the owning lane also adds
+    a_ij * x_i to row j's accumulator.  The layout must stand for exactly the same matrix whatever the
+    input looks like: symmetric (most in-partition entries pair up), unsymmetric or symmetric in
+    pattern only (nothing pairs up, nothing breaks)."""
+    cfg = E.make_config(lds_doubles=2048, sym_pairs=1)
+    if case == "fem3d":
+        c = Case(E, O, "fem3d", (9000, 3, 12, 12, 20000, 1, 5), cfg)
+    elif case == "stencil":
+        c = Case(E, O, "stencil2d", (70, 60, 9, 500, 3), cfg)
+    elif case == "rmat":
+        c = Case(E, O, "rmat", (12, 1 << 15, 2), cfg)
+    else:
+        c = Case(E, O, "stencil2d", (70, 60, 5, 0, 3), cfg)
+        v = c.m.V
+        v[:] = np.arange(1, len(v) + 1) * 1e-3          # a_ij != a_ji everywhere off the diagonal
+        c = c.refresh_reference() if hasattr(c, "refresh_reference") else c
+    plan = E.Plan(c.m, cfg, upload=False)
+    st = plan.stats
+    assert st["nnz_ell"] + st["nnz_er"] == st["nnz"] == c.m.nnz
+    assert st["size_block_ell"] - st["ell_padding"] + st["sym_pairs"] == st["nnz_ell"]   # stored + mirrored = represented
+    items = plan.array("items").reshape(-1, 8)
+    assert len(items) == st["n_parts"] and np.all(items[:, 1] - items[:, 0] == 1)         # one workgroup per partition
+    assert st["lds_bytes"] <= cfg.lds_doubles * 8
+    if case in ("fem3d", "stencil"):
+        assert st["sym_pairs"] > 0.25 * st["nnz"], "most in-partition entries of a symmetric matrix pair up"
+        # balanced orientation: the rows of a slab stay about equally long
+        assert st["ell_padding"] < (0.25 if case == "fem3d" else 0.4) * st["size_block_ell"]   # 9-point rows: 5 or 6 stored entries in 3 pairs
+    if case == "pattern-symmetric-only":
+        assert st["sym_pairs"] == 0
+    if case != "pattern-symmetric-only":
+        _walk_ok(E, O, c, plan)
+    else:
+        yp, written = O.walk_plan(plan, c.xp)
+        A = c.m.to_scipy()
+        assert np.allclose(yp, A @ c.xp, rtol=1e-12, atol=1e-12)

@@ -32,6 +32,7 @@ def main():
     ap.add_argument("--capsplit", type=int, default=1, help="cap_split of the reorder step: 1 on, 2 off")
     ap.add_argument("--iters", type=int, default=100)
     ap.add_argument("--rounds", type=int, default=2)
+    ap.add_argument("--sym", type=int, default=0, help="sym_pairs: 1 symmetric pair storage (changes the partitioning), 2 off")
     args = ap.parse_args()
 
     import numpy as np
@@ -45,7 +46,7 @@ def main():
         for lds in ints(args.lds):
             for frac in ints(args.rows_frac):
                 part_rows = max(64, lds * frac // 1000 // 64 * 64)
-                cfg0 = E.make_config(lds_doubles=lds, part_rows=part_rows, window_mode=mode, cap_split=args.capsplit)
+                cfg0 = E.make_config(lds_doubles=lds, part_rows=part_rows, window_mode=mode, cap_split=args.capsplit, sym_pairs=args.sym)
                 t0 = time.time()
                 m = E.Matrix.generate(gen, *gargs, cfg=cfg0)
                 n, nnz = m.n, m.nnz
@@ -61,7 +62,7 @@ def main():
                             for sh in ints(args.sharing):
                                 for fu in ints(args.fuse):
                                     cfg = E.make_config(lds_doubles=lds, part_rows=part_rows, window_mode=mode, threads=threads,
-                                                        ell_variant=var, items_per_cu=ipc, col_sharing=sh, fuse_er=fu)
+                                                        ell_variant=var, items_per_cu=ipc, col_sharing=sh, fuse_er=fu, sym_pairs=args.sym)
                                     plans.append(((threads, var, ipc, sh * 10 + fu), E.Plan(m, cfg)))
                 ref = None
                 best = {}
