@@ -45,6 +45,9 @@ WORKLOADS = {
 }
 
 
+SYMMETRIC_GENERATORS = ("fem3d", "kkt3d", "stencil2d")  # A == A^T by construction (include/ehyb.h)
+
+
 def timed_steps(step, args, torch, dist, world, dev):
     """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks."""
     for _ in range(args.warmup):
@@ -121,6 +124,7 @@ def run_weak(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
             "config": {"workload": args.workload, "rows": n_glob, "nnz": nnz, "rows_per_gpu": n_loc,
                        "lds_doubles": int(cfg.lds_doubles), "part_rows": int(cfg.part_rows), "threads": int(cfg.threads),
                        "window_mode": "halo" if cfg.window_mode != 1 else "reference",
+                       "sym_pairs_rank0": st["sym_pairs"], "stored_values_rank0": st["size_block_ell"],
                        "ghost_slots_per_gpu_max": int(mx[1].item()), "ghost_slots_total": int(tot[2].item()),
                        "exchange": "halo: gather of the requested x entries + RCCL all_to_all_single into the ghost slots, "
                                    "overlapped with the ELL phase" if not stage_on_cpu else "halo via gloo point-to-point (functional mode)"},
@@ -143,6 +147,8 @@ def main():
     ap.add_argument("--window-mode", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange first, then multiply (no stream overlap)")
+    ap.add_argument("--sym-pairs", default="auto", choices=["auto", "on", "off"],
+                    help="symmetric pair storage (cfg.sym_pairs): auto = on for the symmetric workloads")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
                     help="N>1: weak = the N=1 matrix once per GPU, rank-local build, halo exchange (fem3d workloads); "
                          "strong = the N=1 matrix sharded by rows, all-gatherv of x")
@@ -191,11 +197,16 @@ def main():
         # torch.distributed.run pins every rank to one OpenMP thread; the host pre-step (partitioner,
         # layout builder) of each rank gets its share of the node's cores instead
         kw["host_threads"] = max(1, (os.cpu_count() or world) // world)
-    cfg = E.make_config(n_top=world, verbose=1 if (args.verbose and rank == 0) else 0, **kw)
-
     gen, gargs, desc = WORKLOADS[args.workload]
-    if world > 1 and args.scaling == "weak" and gen == "fem3d":
-        cfg.n_top = 1  # every rank partitions its own block
+    weak = world > 1 and args.scaling == "weak" and gen == "fem3d"
+    # Symmetric pair storage for matrices that are symmetric (the reference reads such files with
+    # matrixRead_sym, solver_test.c:127-265, and knows it too): an in-partition pair is stored once.
+    sym = args.sym_pairs == "on" or (args.sym_pairs == "auto" and gen in SYMMETRIC_GENERATORS)
+    if sym:
+        kw["sym_pairs"] = 1
+    cfg = E.make_config(n_top=1 if weak else world, verbose=1 if (args.verbose and rank == 0) else 0, **kw)
+
+    if weak:  # every rank partitions its own block
         run_weak(args, E, torch, dist, rank, world, torch.device("cuda", local_rank), cfg, log, stage_on_cpu=backend != "nccl")
         dist.destroy_process_group()
         return
@@ -274,8 +285,9 @@ def main():
         r = plan.bench(x_d.data_ptr(), y_d.data_ptr(), stream, warmup=5, iters=min(args.steps, 200))
         ell_ms, er_ms = r["ms_ell_avg"], r["ms_er_avg"]
         inline = st["er_inline"] > 0  # the ELL launch also multiplies the (tiny) residual: one launch per SpMV
-        if inline:
-            er_ms = 0.0
+        empty = st["nnz_er"] == 0
+        if inline or empty:
+            er_ms = 0.0  # no residual launch: the interval between the two events is event overhead
         bytes_ell = 12 * (st["nnz_ell"] + (st["nnz_er"] if inline else 0)) + 4 * (st["n_rows"] + 1) + 8 * st["n_cols"] + 8 * st["n_rows"]
         achieved = bytes_ell / (ell_ms * 1e-3) / 1e9
         traffic = None
@@ -288,9 +300,17 @@ def main():
         roofline = {"bound": "hbm", "kernel": "ehyb_ell_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
                     "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
                     "alg_bytes_per_launch": bytes_ell, "avg_launch_ms": round(ell_ms, 5),
-                    "er_kernel_avg_launch_ms": None if inline else round(er_ms, 5), "residual": "inline in the ELL launch" if inline else "own launch",
+                    "er_kernel_avg_launch_ms": None if (inline or empty) else round(er_ms, 5),
+                    "residual": "empty" if empty else ("inline in the ELL launch" if inline else "own launch"),
                     "format_bytes_per_spmv": st["bytes_format"],
                     "whole_spmv_alg_GBps": round(st["bytes_alg"] / ((ell_ms + er_ms) * 1e-3) / 1e9, 1)}
+        if traffic:
+            roofline["hbm_GBps_from_traffic"] = round(traffic / (ell_ms * 1e-3) / 1e9, 1)
+        if st["sym_pairs"] > 0:
+            roofline["note"] = ("symmetric pair storage: %d of the %d entries are in-partition pairs a_ij == a_ji stored once "
+                                "(one value read, two FMAs, the mirror product added in LDS), so the algorithmic rate "
+                                "(12 B per entry, SURVEY 8d) can exceed the HBM peak; traffic and hbm_GBps_from_traffic "
+                                "are the bytes really moved" % (2 * st["sym_pairs"], st["nnz"]))
 
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
@@ -305,6 +325,7 @@ def main():
                        "lds_doubles": int(cfg.lds_doubles), "part_rows": int(cfg.part_rows), "threads": int(cfg.threads),
                        "window_mode": "halo" if cfg.window_mode != 1 else "reference",
                        "nnz_ell": st["nnz_ell"], "nnz_er": st["nnz_er"], "ell_padding": st["ell_padding"],
+                       "sym_pairs": st["sym_pairs"], "stored_values": st["size_block_ell"],
                        "alg_bytes_per_spmv": st["bytes_alg"] if world == 1 else None,
                        "exchange": "none" if world == 1 else "RCCL all-gatherv of x segments"},
             "alg_GBps": round((12 * nnz + 4 * (n + 1) + 16 * n) / (elapsed / args.steps) / 1e9, 1),

@@ -90,6 +90,7 @@ SIGNATURES = {
     "ehyb_last_error": (C.c_char_p, []),
     "ehyb_version": (C.c_char_p, []),
     "ehyb_config_default": (None, [_cfgp]),
+    "ehyb_config_resolve": (None, [_cfgp, _cfgp]),
     "ehyb_sizing": (C.c_int, [C.c_int, _cfgp, _ip, _ip, _ip]),
     "ehyb_partition_graph": (C.c_int, [C.c_int, _i64p, _ip, _ip, C.c_int, C.c_int, _cfgp, _ip, _i64p]),
     "ehyb_matrix_reorder": (C.c_int, [_mp, C.c_int, _cfgp]),

@@ -33,7 +33,13 @@ Config resolve_config(const ehyb_config* in)
     if (in) z = *in;
     Config c;
     c.window_mode = z.window_mode == EHYB_WINDOW_REFERENCE ? EHYB_WINDOW_REFERENCE : EHYB_WINDOW_HALO;
-    c.lds_doubles = z.lds_doubles > 0 ? std::min(z.lds_doubles, EHYB_LDS_MAX_DOUBLES) : 10240;
+    c.n_top = z.n_top > 1 ? z.n_top : 1;
+    // Symmetric pair storage: the window also holds one accumulator per own row, so a partition gets
+    // at most 30 % of the budget as rows (x: own + halo, y: own), and one workgroup owns a partition.
+    // Measured best (tools/sweep.py --sym 1): 256 partitions, one 1024-thread workgroup per CU, which
+    // a 112 KiB budget gives; two per CU (80 KiB, 512 partitions) is 7 % slower.
+    c.sym_pairs = (z.sym_pairs == 1 && c.window_mode == EHYB_WINDOW_HALO) ? 1 : 2;
+    c.lds_doubles = z.lds_doubles > 0 ? std::min(z.lds_doubles, EHYB_LDS_MAX_DOUBLES) : (c.sym_pairs == 1 ? 14336 : 10240);
     c.lds_doubles = std::max(kSlabRows, round_down(c.lds_doubles, 2));
     // Rows per partition: the whole window in reference mode (convert.c:247 tests against
     // partStart + vectorCacheSize); 55 % of it in halo mode (measured best), the rest holds gathered columns.
@@ -50,7 +56,6 @@ Config resolve_config(const ehyb_config* in)
     c.host_threads = z.host_threads;
     c.verbose = z.verbose;
     c.seed = z.seed;
-    c.n_top = z.n_top > 1 ? z.n_top : 1;
     c.er_threads = z.er_threads > 0 ? std::min(1024, std::max(64, round_down(z.er_threads, 64))) : 256;
     c.ell_variant = z.ell_variant == 3 ? 3 : 1;
     c.col_sharing = z.col_sharing == 2 ? 2 : 1;
@@ -59,10 +64,7 @@ Config resolve_config(const ehyb_config* in)
     c.fuse_er = (z.fuse_er == 1 || z.fuse_er == 2) ? z.fuse_er : 0;  // 0 = automatic (ehyb_hip.hip: fuse_residual)
     c.cap_split = z.cap_split == 2 ? 2 : 1;
     c.hub_rule = z.hub_rule == 2 ? 2 : 1;
-    // Symmetric pair storage: the window also holds one accumulator per own row, so a partition gets
-    // at most 30 % of the budget as rows (x: own + halo, y: own); whole rows may not leave the ELL
-    // part (a residual row cannot scatter), so the hub rule is off.
-    c.sym_pairs = (z.sym_pairs == 1 && c.window_mode == EHYB_WINDOW_HALO && c.n_top <= 1) ? 1 : 2;
+    // symmetric pairs: whole rows may not leave the ELL part (a residual row cannot scatter): no hub rule
     if (c.sym_pairs == 1) {
         c.part_rows = std::max(kSlabRows, std::min(c.part_rows, round_down(c.lds_doubles * 3 / 10, kSlabRows)));
         c.hub_rule = 2;
@@ -78,6 +80,35 @@ extern "C" {
 
 const char* ehyb_last_error(void) { return g_err; }
 const char* ehyb_version(void) { return "ehyb-mi355x 0.1.0 gfx950"; }
+
+// Every "0 = default" field of *in replaced by the value the library will use, given the other
+// fields (the window and partition sizes depend on window_mode and sym_pairs).  in == NULL: all defaults.
+void ehyb_config_resolve(const ehyb_config* in, ehyb_config* out)
+{
+    if (!out) return;
+    const Config c = resolve_config(in);
+    ehyb_config r;
+    memset(&r, 0, sizeof r);
+    r.lds_doubles = c.lds_doubles;
+    r.part_rows = c.part_rows;
+    r.threads = c.threads;
+    r.window_mode = c.window_mode;
+    r.items_per_cu = c.items_per_cu;
+    r.partitioner = c.partitioner;
+    r.er_seg_len = c.er_seg_len;
+    r.host_threads = c.host_threads;
+    r.verbose = c.verbose;
+    r.seed = c.seed;
+    r.n_top = c.n_top;
+    r.er_threads = c.er_threads;
+    r.ell_variant = c.ell_variant;
+    r.col_sharing = c.col_sharing;
+    r.fuse_er = c.fuse_er;
+    r.cap_split = c.cap_split;
+    r.hub_rule = c.hub_rule;
+    r.sym_pairs = c.sym_pairs;
+    *out = r;
+}
 
 void ehyb_config_default(ehyb_config* cfg)
 {

@@ -157,6 +157,7 @@ __device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restr
     const int lrow = row - base;  // the row's place in the LDS image (x) and among the accumulators (y)
     const double xi = (SYM && row < pe) ? win[lrow] : 0.0;
     int k = 0;
+    // (an 8-pair step for SYM, 128 VGPRs at 16 waves per CU, measured 1 % slower than this one)
     for (; k + 4 <= np; k += 4) {
         const double2 v0 = v[(k + 0) * 64], v1 = v[(k + 1) * 64], v2 = v[(k + 2) * 64], v3 = v[(k + 3) * 64];
         const uint32_t c0 = c[(k + 0) * G], c1 = c[(k + 1) * G], c2 = c[(k + 2) * G], c3 = c[(k + 3) * G];
@@ -224,8 +225,9 @@ __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict
 }
 
 template <int THREADS, bool DYN, bool STAMP, bool INLINE_ER, bool SYM>
-// 8 waves per SIMD (<= 64 VGPRs): two 1024-thread workgroups per CU, the occupancy the 80 KiB window is sized for
-__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(8, 8))) void ehyb_ell_kernel(const EllArgs A)
+// 8 waves per SIMD (<= 64 VGPRs): two 1024-thread workgroups per CU, the occupancy the 80 KiB window is sized
+// for.  SYM runs one workgroup per CU (its window holds x and the y accumulators): 4 waves per SIMD, 128 VGPRs.
+__global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(SYM ? 4 : 8, 8))) void ehyb_ell_kernel(const EllArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double win[];
     int* next_slab = reinterpret_cast<int*>(win + A.win_cap);  // one word behind the window

@@ -167,7 +167,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     // 10,240-double budget is exactly 80 KiB and two workgroups still fit one CU's 160 KiB.
     const int lds = std::max(kSlabRows, cfg.lds_doubles - 2);
     const bool halo_mode = cfg.window_mode == EHYB_WINDOW_HALO;
-    const bool sym = cfg.sym_pairs == 1 && halo_mode && cfg.n_top <= 1;  // symmetric pair storage
+    const bool sym = cfg.sym_pairs == 1 && halo_mode;  // symmetric pair storage (in-partition pairs; remote columns are untouched)
 
     // ---- partitions: the caller's, cut down to the window capacity where needed
     std::vector<int32_t>& pb = L->part_boundary;

@@ -41,15 +41,13 @@ def _check(code, where):
 
 def make_config(**kw):
     """ehyb_config with defaults, overridden by keyword (field names of ehyb.h)."""
-    cfg = Config()
-    _lib.load().ehyb_config_default(C.byref(cfg))
-    explicit_rows = "part_rows" in kw
+    cfg = Config()  # all zero = all defaults
     for k, v in kw.items():
         if not hasattr(cfg, k):
             raise TypeError(f"unknown ehyb_config field {k!r}")
         setattr(cfg, k, int(v))
-    if not explicit_rows and ("lds_doubles" in kw or "window_mode" in kw):
-        cfg.part_rows = 0  # re-derive from the window size / mode
+    # fill in what the library will use (window and partition sizes depend on the mode fields)
+    _lib.load().ehyb_config_resolve(C.byref(cfg), C.byref(cfg))
     return cfg
 
 

@@ -102,6 +102,10 @@ typedef struct ehyb_config {
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);
+/* *out = *in with every "0 = default" field replaced by the value the library will use given the
+ * other fields (window and partition sizes depend on window_mode and sym_pairs).  in may be NULL
+ * (all defaults) and may alias out. */
+void ehyb_config_resolve(const ehyb_config* in, ehyb_config* out);
 
 /* ------------------------------------------------- host pre-step (a-7, a-9) */
 

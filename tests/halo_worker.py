@@ -59,6 +59,10 @@ def main():
     m = E.Matrix.generate("fem3d_block", n, 3, 12, 12, 20000, 1, 7, rank, world, cfg=cfg)
     cuts = [n * r for r in range(world + 1)]
     bad += check_rank("fem3d_block", m.I.copy(), m.J.copy(), m.V.copy(), cuts, rank, world, cfg, symmetric=False)
+    # 1b. the same with symmetric pair storage inside every rank's diagonal block (ghost columns untouched)
+    cfg = E.make_config(lds_doubles=1024, sym_pairs=1)
+    m = E.Matrix.generate("fem3d_block", n, 3, 12, 12, 20000, 1, 7, rank, world, cfg=cfg)
+    bad += check_rank("fem3d_block-sym", m.I.copy(), m.J.copy(), m.V.copy(), cuts, rank, world, cfg, symmetric=True)
     # 2. a matrix with no locality cut into ragged row ranges: nearly every column is a ghost somewhere
     cfg = E.make_config(lds_doubles=256)
     g = E.Matrix.generate("rmat", 12, 1 << 15, 2, cfg=cfg)

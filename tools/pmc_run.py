@@ -27,7 +27,7 @@ def main():
     bw = C.c_double()
     lib.ehyb_measure_read_bw(1 << 30, 5, C.byref(bw))  # 8 launches of ehyb_read_kernel over 1 GiB
     gen, gargs, _ = B.WORKLOADS[args.workload]
-    cfg = E.make_config()
+    cfg = E.make_config(sym_pairs=1 if gen in B.SYMMETRIC_GENERATORS else 0)  # as bench.py does
     m = E.Matrix.generate(gen, *gargs, cfg=cfg)
     x = E.x_glibc(m.n)
     m.reorder(cfg)
