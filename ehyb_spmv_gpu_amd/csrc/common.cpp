@@ -143,7 +143,11 @@ int ehyb_sizing(int dimension, const ehyb_config* cfg, int* nParts, int* vectorC
     int64_t parts = (dimension + usable - 1) / usable;
     if (c.n_top > 1) parts = (parts + c.n_top - 1) / c.n_top * c.n_top;
     if (parts < 1) parts = 1;
-    if (c.sym_pairs == 1 && parts > kNumCU / 2) {
+    if (c.sym_pairs == 1 && parts <= kNumCU / 2) {
+        // small matrix, one workgroup per partition: more, smaller partitions (>= 512 rows) keep more CUs busy
+        parts = std::max<int64_t>(parts, std::min<int64_t>(kNumCU, dimension / 512));
+        cache = (int)std::min<int64_t>(cache, (int64_t)((double)dimension / parts * 1.05) + kSlabRows);
+    } else if (c.sym_pairs == 1) {
         // one workgroup per partition, all of equal size: whole rounds of 256 workgroups, and a cap
         // just above the mean so that the partitioner keeps them equal
         parts = (parts + kNumCU - 1) / kNumCU * kNumCU;

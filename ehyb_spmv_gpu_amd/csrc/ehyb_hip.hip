@@ -660,7 +660,8 @@ int spmvGPuEHYB_status(matrixCOO* localMatrix, const double* vectorIn, double* v
     if (!localMatrix || !vectorIn || !vectorOut || MAXIter < 0)
         EHYB_FAIL(EHYB_ERR_ARG, "spmvGPuEHYB: bad arguments");
     ehyb_config cfg;
-    ehyb_config_default(&cfg);
+    memset(&cfg, 0, sizeof cfg);  // zero = default; the sizes follow from the mode fields set below
+    if (const char* v = getenv("EHYB_SYM_PAIRS")) cfg.sym_pairs = atoi(v);  // 1: symmetric pair storage (caller's matrix is symmetric)
     if (const char* v = getenv("EHYB_VERBOSE")) cfg.verbose = atoi(v);
     if (const char* v = getenv("EHYB_LDS_DOUBLES")) cfg.lds_doubles = atoi(v);
     if (const char* v = getenv("EHYB_THREADS")) cfg.threads = atoi(v);

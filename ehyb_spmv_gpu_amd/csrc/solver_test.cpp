@@ -60,7 +60,9 @@ static std::vector<long long> split_numbers(const char* s)
 
 static void usage()
 {
-    printf("usage: solver_test -i <iters> (-m <name> | -g <spec>) [-w 1|2] [-l lds_doubles] [-T threads] [-c plan.cache] [-v]\n"
+    printf("usage: solver_test -i <iters> (-m <name> | -g <spec>) [-w 1|2] [-l lds_doubles] [-T threads] [-c plan.cache] [-S 0|1] [-v]\n"
+           "  -S 0      no symmetric pair storage (default: on for symmetric matrices -- each in-partition pair\n"
+           "            a_ij == a_ji is stored once)\n"
            "  -c file   plan cache: reuse the permutation + layout saved by an earlier run on the same matrix,\n"
            "            or write it (the reference repeats mt-metis + COO2EHYB on every run)\n"
            "  -m name   ./read/name.mtx (Matrix Market, general or symmetric)\n"
@@ -78,13 +80,15 @@ int main(int argc, char* argv[])
     cb_s cb;
     init_cb(&cb);
     ehyb_config cfg;
-    ehyb_config_default(&cfg);
+    memset(&cfg, 0, sizeof cfg);  // zero = default; resolved once the matrix (and its symmetry) is known
+    int sym_opt = -1;             // -S: symmetric pair storage for symmetric matrices (default on)
 
     int oc;
     std::string cache;
-    while ((oc = getopt(argc, argv, "m:i:r:t:f:p:g:w:l:T:c:vh")) != -1) {
+    while ((oc = getopt(argc, argv, "m:i:r:t:f:p:g:w:l:T:c:S:vh")) != -1) {
         switch (oc) {
             case 'c': cache = optarg; break;
+            case 'S': sym_opt = atoi(optarg); break;
             case 'm':
                 snprintf(fileName, sizeof fileName, "./read/%s.mtx", optarg);
                 printf("filename is %s\n", fileName);
@@ -115,14 +119,6 @@ int main(int argc, char* argv[])
         printf("this program only test RODR, BLOCK, and CACHE enabled case\n");
         return 2;
     }
-    {   // re-resolve defaults that depend on the window mode / LDS size
-        ehyb_config tmp = cfg;
-        tmp.part_rows = 0;
-        int cache = 0;
-        ehyb_sizing(1, &tmp, nullptr, &cache, nullptr);
-        cfg.part_rows = cache;
-    }
-
     // --------------------------------- read / generate the matrix
     matrixCOO A;
     int symmetric = 0;
@@ -160,6 +156,21 @@ int main(int argc, char* argv[])
         return 1;
     }
     const int n = A.dimension;
+    // A symmetric matrix (MM banner, as solver_test.c:348-354 branches on it) gets symmetric pair
+    // storage unless -S 0; the partition sizing depends on that, so it is (re)done here.
+    if (symmetric && sym_opt != 0 && cfg.window_mode != EHYB_WINDOW_REFERENCE) cfg.sym_pairs = 1;
+    ehyb_config_resolve(&cfg, &cfg);
+    {
+        int np = 1, cache_rows = 0, kpp = 1;
+        if (ehyb_sizing(n, &cfg, &np, &cache_rows, &kpp) != EHYB_OK) {
+            printf("%s\n", ehyb_last_error());
+            return 1;
+        }
+        A.nParts = np;
+        A.vectorCacheSize = (uint16_t)(cache_rows > 65535 ? 65535 : cache_rows);
+        A.kernelPerPart = (int16_t)kpp;
+    }
+    if (cfg.sym_pairs == 1) printf("symmetric pair storage on\n");
     printf("parts is %d with cachSize %d\n", A.nParts, (int)A.vectorCacheSize);  // solver_test.c:78,183
     printf("maxCol is %d\n", A.maxCol);
 
@@ -218,6 +229,7 @@ int main(int argc, char* argv[])
         snprintf(buf, sizeof buf, "%d", cfg.lds_doubles), setenv("EHYB_LDS_DOUBLES", buf, 1);
         snprintf(buf, sizeof buf, "%d", cfg.threads), setenv("EHYB_THREADS", buf, 1);
         snprintf(buf, sizeof buf, "%d", cfg.window_mode), setenv("EHYB_WINDOW_MODE", buf, 1);
+        snprintf(buf, sizeof buf, "%d", cfg.sym_pairs), setenv("EHYB_SYM_PAIRS", buf, 1);
         rc = spmvGPuEHYB_status(&A, xReorder, yReorder, MAXIter, &realIter);
         if (rc != EHYB_OK) {
             printf("spmvGPuEHYB failed (%d): %s\n", rc, ehyb_last_error());
