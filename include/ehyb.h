@@ -91,13 +91,15 @@ typedef struct ehyb_config {
     int32_t cap_split;     /* 0/1 = bisect partitions whose halo overflows the window (reorder step), 2 = off */
     int32_t hub_rule;      /* 0/1 = rows that would pad their slab by > 25 % go to the residual whole
                               (the reference's long-row intent, convert.c:92-101), 2 = off          */
-    int32_t sym_pairs;     /* symmetric pair storage (single GPU, halo window): an in-partition pair a_ij == a_ji is
-                              stored once; the owning lane adds a_ij*x_j to its own row and a_ij*x_i to row
-                              j's accumulator in LDS (ds_add_f64), so the value stream is read once for two
-                              entries.  One workgroup per partition, nParts a multiple of 256.  Results do
-                              not depend on the matrix being symmetric (unmatched entries stay as they are)
-                              but the order of the LDS adds varies from run to run (last-bit differences).
-                              0 = default (on for the single-GPU halo window), 1 = on, 2 = off            */
+    int32_t sym_pairs;     /* symmetric pair storage (halo window): an in-partition pair a_ij == a_ji is stored
+                              once; the owning lane adds a_ij*x_j to its own row and a_ij*x_i to row j's
+                              accumulator in LDS (ds_add_f64), so one value read serves two entries.  One
+                              workgroup per partition; ehyb_sizing makes nParts a multiple of 256 and the
+                              window 112 KiB.  Set it BEFORE reading/generating/reordering the matrix (the
+                              partition sizes depend on it).  Results do not depend on the matrix being
+                              symmetric (entries without an equal partner stay as they are), but the order
+                              of the LDS adds varies from run to run (last-bit differences).
+                              1 = on -- what solver_test and bench.py choose for symmetric inputs; 0/2 = off */
     int32_t reserved[6];
 } ehyb_config;
 

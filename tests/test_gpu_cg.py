@@ -47,17 +47,21 @@ def cpu_cg(A, b, max_iter, rtol):
     return x, it, hist
 
 
-@pytest.mark.parametrize("mode,lds", [(2, 2048), (1, 512)])
-def test_cg_matches_cpu_and_scipy(E, O, gpu, mode, lds):
+@pytest.mark.parametrize("mode,lds,sym", [(2, 2048, 0), (1, 512, 0), (2, 2048, 1)], ids=["halo", "refwindow", "symmetric-pairs"])
+def test_cg_matches_cpu_and_scipy(E, O, gpu, mode, lds, sym):
+    """The third arm runs CG on symmetric pair storage -- an SPD matrix is symmetric, so the solver's
+    multiply reads every in-partition pair once."""
     A = spd_matrix(120, 100, 3000, 1)
     n = A.shape[0]
-    cfg = E.make_config(window_mode=mode, lds_doubles=lds)
+    cfg = E.make_config(window_mode=mode, lds_doubles=lds, sym_pairs=sym)
     m = E.Matrix.from_csr(A.indptr, A.indices, A.data, cfg, symmetric=True)
     m.reorder(cfg)
     perm = m.reorder_list.copy()
     plan = E.Plan(m, cfg)
     if mode == 1:
         assert plan.stats["nnz_er"] > 0, "this arm must exercise the residual on every iteration"
+    if sym:
+        assert plan.stats["sym_pairs"] > 0.25 * A.nnz
     b = O.x_glibc(n) + 0.3
     xp, iters, rel = plan.cg(E.vector_reorder(b, perm), max_iter=400, rtol=1e-10, check_every=1)
     x = E.vector_recover(xp, perm)
