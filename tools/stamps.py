@@ -16,7 +16,8 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="audikw_1-like")
-    ap.add_argument("--lds", type=int, default=10240)
+    ap.add_argument("--lds", type=int, default=0, help="window budget in doubles (0 = the mode's default)")
+    ap.add_argument("--sym", type=int, default=0, help="1 = symmetric pair storage (one workgroup per partition)")
     ap.add_argument("--part-rows", type=int, default=0)
     ap.add_argument("--threads", type=int, default=1024)
     ap.add_argument("--items", type=int, default=2)
@@ -35,7 +36,7 @@ def main():
         print(f"streaming read of {mb} MiB: {bw.value:.0f} GB/s")
 
     gen, gargs, _ = B.WORKLOADS[args.workload]
-    kw = dict(lds_doubles=args.lds, threads=args.threads, items_per_cu=args.items, ell_variant=args.variant)
+    kw = dict(lds_doubles=args.lds, threads=args.threads, items_per_cu=args.items, ell_variant=args.variant, sym_pairs=args.sym)
     if args.part_rows:
         kw["part_rows"] = args.part_rows
     cfg = E.make_config(**kw)
