@@ -120,6 +120,7 @@ SIGNATURES = {
     "ehyb_dev_sync": (C.c_int, []),
     "ehyb_measure_read_bw": (C.c_int, [C.c_size_t, C.c_int, _dp]),
     "ehyb_cg": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp, _ip, _dp]),
+    "ehyb_pcg": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp, _ip, _dp]),
     "ehyb_mm_read": (C.c_int, [C.c_char_p, _cfgp, _mp, _ip]),
     "ehyb_mm_write": (C.c_int, [C.c_char_p, _mp, C.c_int]),
     "ehyb_matrix_from_csr": (C.c_int, [C.c_int, _i64p, _ip, _dp, _cfgp, _mp]),

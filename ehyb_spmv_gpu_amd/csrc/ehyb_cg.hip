@@ -6,9 +6,11 @@
 // Per iteration: one ehyb_spmv (q = A p) and three memory-bound vector kernels, each a grid-stride
 // pass with one wave shuffle + LDS reduction and one fp64 atomic per workgroup:
 //   1. pq   = p . q
-//   2. x += alpha p ; r -= alpha q ; rs_new = r . r          (alpha = rs / pq, read from the device)
-//   3. p  = r + beta p                                        (beta  = rs_new / rs)  [kernelMyxpy]
-// The five scalars live in one device array; nothing is copied to the host inside the loop except
+//   2. x += alpha p ; r -= alpha q ; rz_new = r . z ; rr = r . r   (alpha = rz / pq, read from the device)
+//   3. p  = z + beta p                                              (beta  = rz_new / rz)  [kernelMyxpy]
+// with z = M^-1 r for the diagonal (Jacobi) preconditioner -- the PRECOND switch of the reference's
+// cb_s (spmv.h:7-15) -- recomputed on the fly from 1/diag, or z = r without one.
+// The scalars live in one device array; nothing is copied to the host inside the loop except
 // the residual norm every `check_every` iterations.
 #include <hip/hip_runtime.h>
 
@@ -29,7 +31,7 @@ using namespace ehyb;
 
 namespace {
 
-enum { S_RS = 0, S_PQ = 1, S_RS_NEW = 2, S_BB = 3 };  // r.r, p.q, next r.r, b.b
+enum { S_RS = 0, S_PQ = 1, S_RS_NEW = 2, S_BB = 3, S_RR = 4 };  // r.z, p.q, next r.z, b.b, r.r
 
 constexpr int kThreads = 256;
 
@@ -48,22 +50,27 @@ __device__ __forceinline__ void block_add(double v, double* __restrict__ target)
     }
 }
 
-// r = b - q (q = A x0), p = r, rs = r.r, bb = b.b
+// r = b - q (q = A x0), z = dinv .* r (or r), p = z, rs = r.z, rr = r.r, bb = b.b
 __global__ __launch_bounds__(kThreads) void cg_init_kernel(int n, const double* __restrict__ b,
-                                                           const double* __restrict__ q, double* __restrict__ r,
-                                                           double* __restrict__ p, double* __restrict__ s)
+                                                           const double* __restrict__ q, const double* __restrict__ dinv,
+                                                           double* __restrict__ r, double* __restrict__ p,
+                                                           double* __restrict__ s)
 {
-    double rs = 0.0, bb = 0.0;
+    double rs = 0.0, rr = 0.0, bb = 0.0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         const double bi = b[i], ri = bi - q[i];
+        const double zi = dinv ? ri * dinv[i] : ri;
         r[i] = ri;
-        p[i] = ri;
-        rs = fma(ri, ri, rs);
+        p[i] = zi;
+        rs = fma(ri, zi, rs);
+        rr = fma(ri, ri, rr);
         bb = fma(bi, bi, bb);
     }
     block_add(rs, s + S_RS);
     __syncthreads();
     block_add(bb, s + S_BB);
+    __syncthreads();
+    block_add(rr, s + S_RR + 1);  // the slot the host reads; S_RR itself stays zero for the first iteration
 }
 
 __global__ __launch_bounds__(kThreads) void cg_dot_kernel(int n, const double* __restrict__ p,
@@ -75,26 +82,32 @@ __global__ __launch_bounds__(kThreads) void cg_dot_kernel(int n, const double* _
 }
 
 __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, const double* __restrict__ p,
-                                                             const double* __restrict__ q, double* __restrict__ x,
-                                                             double* __restrict__ r, double* __restrict__ s)
+                                                             const double* __restrict__ q, const double* __restrict__ dinv,
+                                                             double* __restrict__ x, double* __restrict__ r,
+                                                             double* __restrict__ s)
 {
     const double alpha = s[S_RS] / s[S_PQ];
-    double acc = 0.0;
+    double rz = 0.0, rr = 0.0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         x[i] = fma(alpha, p[i], x[i]);
         const double ri = fma(-alpha, q[i], r[i]);
         r[i] = ri;
-        acc = fma(ri, ri, acc);
+        rz = fma(ri, dinv ? ri * dinv[i] : ri, rz);
+        rr = fma(ri, ri, rr);
     }
-    block_add(acc, s + S_RS_NEW);
+    block_add(rz, s + S_RS_NEW);
+    __syncthreads();
+    block_add(rr, s + S_RR);
 }
 
-// p = r + beta p  (the reference's kernelMyxpy with gamma = beta), then roll the scalars
+// p = z + beta p  (the reference's kernelMyxpy with gamma = beta), then roll the scalars
 __global__ __launch_bounds__(kThreads) void cg_direction_kernel(int n, const double* __restrict__ r,
-                                                                double* __restrict__ p, const double* __restrict__ s)
+                                                                const double* __restrict__ dinv, double* __restrict__ p,
+                                                                const double* __restrict__ s)
 {
     const double beta = s[S_RS_NEW] / s[S_RS];
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) p[i] = fma(beta, p[i], r[i]);
+    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
+        p[i] = fma(beta, p[i], dinv ? r[i] * dinv[i] : r[i]);
 }
 
 __global__ void cg_roll_kernel(double* __restrict__ s)
@@ -102,12 +115,20 @@ __global__ void cg_roll_kernel(double* __restrict__ s)
     s[S_RS] = s[S_RS_NEW];
     s[S_RS_NEW] = 0.0;
     s[S_PQ] = 0.0;
+    s[S_RR + 1] = s[S_RR];  // the residual norm the host reads
+    s[S_RR] = 0.0;
 }
 
 }  // namespace
 
 extern "C" int ehyb_cg(ehyb_plan* P, const double* b, double* x, int max_iter, double rtol, int check_every,
                        void* stream, int* iters_done, double* rel_residual)
+{
+    return ehyb_pcg(P, nullptr, b, x, max_iter, rtol, check_every, stream, iters_done, rel_residual);
+}
+
+extern "C" int ehyb_pcg(ehyb_plan* P, const double* dinv, const double* b, double* x, int max_iter, double rtol,
+                        int check_every, void* stream, int* iters_done, double* rel_residual)
 {
     clear_error();
     if (!P || !b || !x || max_iter < 0 || !(rtol >= 0)) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_cg: bad arguments");
@@ -136,12 +157,12 @@ extern "C" int ehyb_cg(ehyb_plan* P, const double* b, double* x, int max_iter, d
         cleanup();
         return rc;
     }
-    hipLaunchKernelGGL(cg_init_kernel, dim3(grid), dim3(kThreads), 0, st, n, b, q, r, p, s);
-    double h[4] = {0, 0, 0, 0};
+    hipLaunchKernelGGL(cg_init_kernel, dim3(grid), dim3(kThreads), 0, st, n, b, q, dinv, r, p, s);
+    double h[6] = {0, 0, 0, 0, 0, 0};
     CG_TRY(hipMemcpyAsync(h, s, sizeof h, hipMemcpyDeviceToHost, st));
     CG_TRY(hipStreamSynchronize(st));
     const double bb = h[S_BB] > 0 ? h[S_BB] : 1.0;
-    double rs = h[S_RS];
+    double rs = h[S_RR + 1];  // ||r||^2 (the preconditioned product r.z drives the recurrences, not the stop test)
     int it = 0;
     while (it < max_iter && std::sqrt(rs / bb) > rtol) {
         const int burst = std::min(check_every, max_iter - it);
@@ -151,16 +172,19 @@ extern "C" int ehyb_cg(ehyb_plan* P, const double* b, double* x, int max_iter, d
                 return rc;
             }
             hipLaunchKernelGGL(cg_dot_kernel, dim3(grid), dim3(kThreads), 0, st, n, p, q, s);
-            hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kThreads), 0, st, n, p, q, x, r, s);
-            hipLaunchKernelGGL(cg_direction_kernel, dim3(grid), dim3(kThreads), 0, st, n, r, p, s);
+            hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kThreads), 0, st, n, p, q, dinv, x, r, s);
+            hipLaunchKernelGGL(cg_direction_kernel, dim3(grid), dim3(kThreads), 0, st, n, r, dinv, p, s);
             hipLaunchKernelGGL(cg_roll_kernel, dim3(1), dim3(1), 0, st, s);
         }
         it += burst;
         CG_TRY(hipGetLastError());
         CG_TRY(hipMemcpyAsync(h, s, sizeof h, hipMemcpyDeviceToHost, st));
         CG_TRY(hipStreamSynchronize(st));
-        rs = h[S_RS];
-        if (!(rs == rs)) break;  // NaN: breakdown (matrix not positive definite)
+        rs = h[S_RR + 1];
+        if (!(rs == rs) || !(h[S_RS] == h[S_RS])) {
+            rs = NAN;
+            break;  // NaN: breakdown (matrix or preconditioner not positive definite)
+        }
     }
     cleanup();
     if (iters_done) *iters_done = it;

@@ -340,15 +340,16 @@ class Plan:
                                         C.byref(r) if per_kernel else None), "ehyb_spmv_bench")
         return {"ms_total": t.value, "ms_ell_avg": e.value, "ms_er_avg": r.value}
 
-    def cg(self, b, x0=None, max_iter=1000, rtol=1e-10, check_every=10):
-        """ehyb_cg: conjugate gradients on the device (b, x in the permuted numbering).
-        -> (x, iterations, relative residual)"""
+    def cg(self, b, x0=None, max_iter=1000, rtol=1e-10, check_every=10, inv_diag=None):
+        """ehyb_cg / ehyb_pcg: (Jacobi-preconditioned if inv_diag is given) conjugate gradients on the
+        device; b, x, inv_diag in the permuted numbering.  -> (x, iterations, relative residual)"""
         b = np.ascontiguousarray(b, dtype=np.float64)
         db, dx = DeviceBuffer(self.n).upload(b), DeviceBuffer(self.n)
         dx.upload(np.zeros(self.n) if x0 is None else x0)
+        dd = None if inv_diag is None else DeviceBuffer(self.n).upload(np.ascontiguousarray(inv_diag, dtype=np.float64))
         it, rel = C.c_int(0), C.c_double(0)
-        _check(self.lib.ehyb_cg(self.h, C.c_void_p(db.ptr), C.c_void_p(dx.ptr), max_iter, rtol, check_every, None,
-                                C.byref(it), C.byref(rel)), "ehyb_cg")
+        _check(self.lib.ehyb_pcg(self.h, C.c_void_p(dd.ptr) if dd else None, C.c_void_p(db.ptr), C.c_void_p(dx.ptr),
+                                 max_iter, rtol, check_every, None, C.byref(it), C.byref(rel)), "ehyb_pcg")
         return dx.download(), it.value, rel.value
 
     def destroy(self):

@@ -307,6 +307,11 @@ int ehyb_measure_read_bw(size_t bytes, int iters, double* gbps);
  */
 int ehyb_cg(ehyb_plan* plan, const double* b_dev, double* x_dev, int max_iter, double rtol,
             int check_every, void* stream, int* iters_done, double* rel_residual);
+/* The same with the diagonal (Jacobi) preconditioner -- the PRECOND switch of the reference's cb_s
+ * (spmv.h:7-15): inv_diag_dev[i] = 1 / a_ii in the permuted numbering (matrixCOO.diag, permuted
+ * like x); NULL = ehyb_cg.  z = M^-1 r is recomputed on the fly, no extra vector is stored. */
+int ehyb_pcg(ehyb_plan* plan, const double* inv_diag_dev, const double* b_dev, double* x_dev, int max_iter,
+             double rtol, int check_every, void* stream, int* iters_done, double* rel_residual);
 
 /* -------------------------------------------- harness pieces (solver_test.c) */
 

@@ -73,6 +73,44 @@ def test_cg_matches_cpu_and_scipy(E, O, gpu, mode, lds, sym):
     assert info == 0 and np.linalg.norm(x - x_sp) <= 1e-7 * np.linalg.norm(x_sp)
 
 
+def test_jacobi_pcg_on_a_badly_scaled_system(E, O, gpu):
+    """ehyb_pcg: the diagonal preconditioner (the reference's PRECOND switch).  D A D with a widely
+    varying D is SPD but badly scaled: plain CG needs many times the iterations of Jacobi-PCG, and
+    both reach the same solution."""
+    A0 = spd_matrix(100, 90, 2000, 3)
+    n = A0.shape[0]
+    d = 10.0 ** np.random.default_rng(5).uniform(-2, 2, n)
+    A = (sp.diags(d) @ A0 @ sp.diags(d)).tocsr()
+    cfg = E.make_config(lds_doubles=2048, sym_pairs=1)
+    m = E.Matrix.from_csr(A.indptr, A.indices, A.data, cfg, symmetric=True)
+    m.reorder(cfg)
+    perm = m.reorder_list.copy()
+    plan = E.Plan(m, cfg)
+    b = A @ np.ones(n)
+    bp = E.vector_reorder(b, perm)
+    inv_diag = E.vector_reorder(1.0 / A.diagonal(), perm)
+    xp, it_pcg, rel = plan.cg(bp, max_iter=3000, rtol=1e-9, check_every=5, inv_diag=inv_diag)
+    x = E.vector_recover(xp, perm)
+    assert rel <= 1e-9 and np.linalg.norm(A @ x - b) <= 5e-9 * np.linalg.norm(b)
+    _, it_cg, rel_cg = plan.cg(bp, max_iter=3000, rtol=1e-9, check_every=5)
+    assert it_pcg * 3 < it_cg or rel_cg > 1e-9, (it_pcg, it_cg, rel_cg)
+    # the same recurrences on the CPU stop within a few iterations of the device
+    Minv = sp.diags(1.0 / A.diagonal())
+    xc, rc = np.zeros(n), b.copy()
+    zc = Minv @ rc
+    pc, rz, k = zc.copy(), rc @ zc, 0
+    while np.linalg.norm(rc) > 1e-9 * np.linalg.norm(b) and k < 3000:
+        q = A @ pc
+        alpha = rz / (pc @ q)
+        xc += alpha * pc
+        rc -= alpha * q
+        zc = Minv @ rc
+        rz, rz_old = rc @ zc, rz
+        pc = zc + (rz / rz_old) * pc
+        k += 1
+    assert abs(k - it_pcg) <= 5 + 0.05 * k, (k, it_pcg)
+
+
 def test_cg_stops_at_max_iter_and_reports_breakdown(E, O, gpu):
     A = spd_matrix(60, 50, 500, 2)
     cfg = E.make_config(lds_doubles=1024)
