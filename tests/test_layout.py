@@ -218,12 +218,27 @@ def _case_from_csr(E, O, A, cfg):
     return m, x, y_ref, scale
 
 
-@pytest.mark.parametrize("mode", [1, 2])
+@pytest.mark.parametrize("mode", [1, 2, 3], ids=["refwindow", "halo", "halo+symmetric-pairs"])
 def test_edge_cases(E, O, mode):
-    """Empty rows, a dense row, a matrix smaller than one slab, a zero matrix, diagonal only."""
-    cfg = E.make_config(window_mode=mode, lds_doubles=128, er_seg_len=64)
+    """Empty rows, a dense row, a matrix smaller than one slab, a zero matrix, diagonal only -- and,
+    for symmetric pair storage, symmetric matrices with dense rows/columns, repeated coordinates and
+    a partner that differs in the last bit."""
+    cfg = E.make_config(window_mode=min(mode, 2), lds_doubles=128 if mode < 3 else 256, er_seg_len=64, sym_pairs=int(mode == 3))
     rng = np.random.default_rng(0)
+    S = sp.random(400, 400, density=0.02, random_state=7, format="csr")
+    S = (S + S.T).tocsr()
+    arrow = sp.lil_matrix((300, 300))
+    arrow[0, :] = 1.5
+    arrow[:, 0] = 1.5
+    arrow.setdiag(4.0)
+    almost = S.copy().tolil()
+    i0, j0 = np.argwhere(S.toarray() != 0)[5]
+    if i0 != j0:
+        almost[i0, j0] = np.nextafter(S[i0, j0], 10.0)     # a_ij and a_ji differ in the last bit: must stay two entries
     mats = {
+        "sym_random": S,
+        "sym_arrow": arrow.tocsr(),
+        "sym_last_bit": almost.tocsr(),
         "tiny_3x3": sp.csr_matrix(np.array([[1.0, 0, 2], [0, 0, 0], [3, 0, 4]])),
         "one_by_one": sp.csr_matrix(np.array([[2.5]])),
         "zero_5x5": sp.csr_matrix((5, 5)),
@@ -246,6 +261,41 @@ def test_edge_cases(E, O, mode):
         y = E.vector_recover(yp, m.reorder_list)
         assert O.check_tolerance(y, y_ref, scale + 1e-300)[0] == 0, name
     del rng
+
+
+def test_symmetric_pairs_with_repeated_coordinates(E, O):
+    """A coordinate that appears more than once (the reference's reader would keep both,
+    solver_test.c:96-103): every copy is either paired with exactly one equal partner or kept as it is."""
+    n = 130
+    rows, cols, vals = [], [], []
+    rng = np.random.default_rng(3)
+    for i in range(n):
+        rows.append(i), cols.append(i), vals.append(5.0 + i * 1e-3)
+    for _ in range(400):
+        i, j = rng.integers(0, n, 2)
+        if i == j:
+            continue
+        v = float(rng.integers(1, 9)) / 8
+        copies = int(rng.integers(1, 4))                      # (i,j) up to three times ...
+        mirror = int(rng.integers(0, 4))                      # ... and (j,i) a different number of times
+        rows += [i] * copies + [j] * mirror
+        cols += [j] * copies + [i] * mirror
+        vals += [v] * (copies + mirror)
+    order = np.argsort(np.array(rows), kind="stable")
+    r, c, v = np.array(rows)[order], np.array(cols)[order], np.array(vals)[order]
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(r, minlength=n), out=indptr[1:])
+    cfg = E.make_config(lds_doubles=256, sym_pairs=1)
+    m = E.Matrix.from_csr(indptr, c, v, cfg)
+    x = O.x_glibc(n)
+    y_ref = O.spmv_coo(n, m.I, m.J, m.V, x)
+    scale = O.abs_rowsum(n, m.I, m.J, m.V, x)
+    m.reorder(cfg, symmetric=False)
+    plan = E.Plan(m, cfg, upload=False)
+    assert plan.stats["sym_pairs"] > 0
+    yp, written = O.walk_plan(plan, E.vector_reorder(x, m.reorder_list))
+    assert (written == 1).all()
+    assert O.check_tolerance(E.vector_recover(yp, m.reorder_list), y_ref, scale)[0] == 0
 
 
 def test_oversized_partition_is_split(E, O):
