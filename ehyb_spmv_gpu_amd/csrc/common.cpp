@@ -59,9 +59,9 @@ Config resolve_config(const ehyb_config* in)
     c.er_threads = z.er_threads > 0 ? std::min(1024, std::max(64, round_down(z.er_threads, 64))) : 256;
     c.ell_variant = z.ell_variant == 3 ? 3 : 1;
     c.col_sharing = z.col_sharing == 2 ? 2 : 1;
-    // measured (tools/sweep.py --fuse 1,2): the fused tail saves ~1 % at best on the bench matrix and
-    // loses badly on residual-heavy inputs, where the flat residual kernel has far more parallelism
-    c.fuse_er = (z.fuse_er == 1 || z.fuse_er == 2) ? z.fuse_er : 0;  // 0 = automatic (ehyb_hip.hip: fuse_residual)
+    // residual inside the ELL launch (inline pairs) or as its own launch: 0 = the layout builder decides
+    // (inline iff it holds < 0.2 % of the entries and its padded slices < 1 %: layout.cpp)
+    c.fuse_er = (z.fuse_er == 1 || z.fuse_er == 2) ? z.fuse_er : 0;
     c.cap_split = z.cap_split == 2 ? 2 : 1;
     c.hub_rule = z.hub_rule == 2 ? 2 : 1;
     // symmetric pairs: whole rows may not leave the ELL part (a residual row cannot scatter): no hub rule

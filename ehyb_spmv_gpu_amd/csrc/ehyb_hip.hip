@@ -14,18 +14,26 @@
 //                         column lists), two LDS gathers (ds_read_b64) and two fp64 FMAs
 //                         (kernel.cu:150-163);
 //                      3. y[row] = dot, 512 B coalesced per slab.
+//                    Two more forms of the same kernel:
+//                      INLINE_ER  a tiny residual rides along as extra pairs behind every slab's
+//                                 ELL pairs (global columns, x gathered from L2): one launch;
+//                      SYM        symmetric pair storage: one workgroup per partition, the rows'
+//                                 accumulators in LDS behind the x image; an entry marked in bit 15
+//                                 of its column also adds value * x[own row] to row `column`
+//                                 (ds_add_f64), so an in-partition pair a_ij == a_ji is read once.
 //   ehyb_er_kernel   CSR residual: G lanes per segment (64/16/4 by segment length), strided
 //                    coalesced (col,val) reads, x gathered from global memory (L2/MALL),
 //                    wavefront shuffle reduction, y[row] += sum -- or one fp64 atomic per
 //                    segment for rows split into several segments (the working form of
-//                    kernel.cu:43-67 longRowKernel).  Runs on every multiply (the reference
-//                    skips it after the first launch: SURVEY 8 a-10 item 1); as its own launch or,
-//                    when tiny, as the tail of the ELL workgroups.
-// No MFMA: 2 flops per 8.7-10 streamed bytes, HBM-bound.
+//                    kernel.cu:43-67 longRowKernel).  Runs on every multiply that has a residual
+//                    not carried inline (the reference skips it after the first launch: SURVEY 8
+//                    a-10 item 1); it is also phase 2 of the multi-GPU multiply (all remote columns).
+// No MFMA: 2 flops per 5.8-10 streamed bytes, HBM-bound.
 //
-// Arms tried and dropped (measurements in DESIGN.md): software-pipelined slab walk with ping-pong
-// register groups, 4-deep unrolled double2 staging, early slab-record loads.  None beat this loop
-// at 32 waves per CU; the decisive levers were bytes (shared column lists) and scheduling.
+// Arms tried and dropped (measurements in DESIGN.md 3.1): software-pipelined slab walk with ping-pong
+// register groups, 4-deep unrolled double2 staging, early slab-record loads, batched remainder
+// pairs, global slab counters with work stealing, an 8-pair step for SYM.  The decisive levers were
+// bytes (shared column lists, symmetric pairs) and scheduling (equal-cost items, one resident wave).
 #include <hip/hip_runtime.h>
 
 #include <algorithm>
@@ -44,13 +52,12 @@ using namespace ehyb;
         }                                                                                     \
     } while (0)
 
-// ------------------------------------------------------------------ residual tail
-// The residual segments of a work item's rows, multiplied by the whole workgroup: G lanes per
-// segment (64 / 16 / 4 by segment length, longest first), strided coalesced (col,val) reads, x
-// gathered from global memory, shuffle reduction, then y[row] += sum -- plain for rows with one
-// segment (rows are unique, kernel.cu:69-77), one fp64 atomic per segment for split rows (the
-// working form of kernel.cu:43-67).  Called after the workgroup's own `y[row] = dot` stores
-// and a __syncthreads() (fused), or from ehyb_er_kernel behind the ELL launch.
+// ------------------------------------------------------------------ residual segments
+// Residual segments [lo, hi) multiplied by one workgroup: G lanes per segment (64 / 16 / 4 by
+// segment length, longest first), strided coalesced (col,val) reads, x gathered from global
+// memory, shuffle reduction, then y[row] += sum -- plain for rows with one segment (rows are
+// unique, kernel.cu:69-77), one fp64 atomic per segment for split rows (the working form of
+// kernel.cu:43-67).  Called from ehyb_er_kernel, which runs behind the ELL launch.
 template <int G, int THREADS>
 __device__ __forceinline__ void er_bin(int lo, int hi, const int64_t* __restrict__ seg_ptr,
                                        const int* __restrict__ seg_row, const int* __restrict__ col,
