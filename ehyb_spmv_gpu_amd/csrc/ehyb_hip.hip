@@ -111,6 +111,7 @@ struct EllArgs {
     const int* __restrict__ halo_cols;
     const uint4* __restrict__ slab_meta;
     const uint8_t* __restrict__ lane_group;
+    const uint16_t* __restrict__ slab_lrow;  // SYM: the row (place in the LDS image) of every lane, 0xFFFF = none
     const double2* __restrict__ ell_val;
     const uint32_t* __restrict__ ell_col;
     const double* __restrict__ x;
@@ -160,9 +161,12 @@ __device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restr
             acc1 = fma(vv.y, A.x[cb], acc1);
         }
     }
+    // Plain: lane l works on row sm.z + l.  SYM: the rows of a partition sit in its slabs longest
+    // first (any order will do: sums go to the LDS accumulators by row), slab_lrow names the row.
     const int row = (int)sm.z + lane;
-    const int lrow = row - base;  // the row's place in the LDS image (x) and among the accumulators (y)
-    const double xi = (SYM && row < pe) ? win[lrow] : 0.0;
+    const int lrow = SYM ? (int)A.slab_lrow[(size_t)s * 64 + lane] : row - base;  // place in the LDS image
+    const bool has_row = SYM ? lrow != 0xFFFF : row < pe;
+    const double xi = (SYM && has_row) ? win[lrow] : 0.0;
     int k = 0;
     // (an 8-pair step for SYM, 128 VGPRs at 16 waves per CU, measured 1 % slower than this one)
     for (; k + 4 <= np; k += 4) {
@@ -183,7 +187,7 @@ __device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restr
         ell_entry<SYM>(v0.x, c0 & 0xffffu, win, yacc, xi, acc0);
         ell_entry<SYM>(v0.y, c0 >> 16, win, yacc, xi, acc1);
     }
-    if (row < pe) {
+    if (has_row) {
         if (SYM)
             unsafeAtomicAdd(&yacc[lrow], acc0 + acc1);  // other lanes scatter into the same accumulator
         else
@@ -301,6 +305,7 @@ static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long 
     A.halo_cols = P->d_halo_cols;
     A.slab_meta = (const uint4*)P->d_slab_meta;
     A.lane_group = P->d_lane_group;
+    A.slab_lrow = P->d_slab_lrow;
     A.ell_val = (const double2*)P->d_ell_val;
     A.ell_col = P->d_ell_col;
     A.x = x;
@@ -390,7 +395,8 @@ static void free_device(ehyb_plan* P)
 {
     void** ptrs[] = {(void**)&P->d_halo_cols,  (void**)&P->d_ell_val,   (void**)&P->d_ell_col,    (void**)&P->d_lane_group,
                      (void**)&P->d_slab_meta,  (void**)&P->d_items,     (void**)&P->d_segs,       (void**)&P->d_er_seg_ptr,
-                     (void**)&P->d_er_seg_row, (void**)&P->d_er_col,    (void**)&P->d_er_val,     (void**)&P->d_er_blocks};
+                     (void**)&P->d_er_seg_row, (void**)&P->d_er_col,    (void**)&P->d_er_val,     (void**)&P->d_er_blocks,
+                     (void**)&P->d_slab_lrow};
     for (void** q : ptrs) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
@@ -530,6 +536,7 @@ int ehyb_plan_upload(ehyb_plan* P)
     UP(d_er_col, er_col)
     UP(d_er_val, er_val)
     UP(d_er_blocks, er_blocks)
+    UP(d_slab_lrow, slab_lrow)
 #undef UP
     // opt in to the full 160 KiB of LDS (the role of cudaFuncSetAttribute at kernel.cu:351,411)
     const int lds = (int)ell_lds_bytes(H);

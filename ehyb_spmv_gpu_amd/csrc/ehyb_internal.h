@@ -99,6 +99,7 @@ struct HostLayout {
     // the accumulators of a partition's rows live in LDS behind the window (yacc_doubles of them)
     bool sym = false;
     int yacc_doubles = 0;
+    std::vector<uint16_t> slab_lrow;  // [n_slabs*64] sym only: image-local row of every lane (0xFFFF: none)
 
     ehyb_stats stats{};
 };
@@ -153,4 +154,5 @@ struct ehyb_plan {
     int32_t* d_er_col = nullptr;
     double* d_er_val = nullptr;
     int32_t* d_er_blocks = nullptr;
+    uint16_t* d_slab_lrow = nullptr;
 };

@@ -247,6 +247,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     std::vector<int32_t> cnt_ell(nrows, 0);
     std::vector<uint8_t> lead_row(nrows, 1);
     std::vector<uint8_t> row_to_er(nrows, 0);  // whole row in the residual (hub rows)
+    // lane order inside a partition: slot t (slab t / 64, lane t % 64) holds row row_at[first + t]
+    std::vector<int32_t> row_at(nrows), slot_of(nrows);
     const bool share = cfg.col_sharing != 2;
     L->win_len.assign(np, 0);
     int bad_col = 0, bad_row = 0;
@@ -321,6 +323,17 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 }
                 cnt_ell[r - row_begin] = c;
             }
+            // Lane order.  Normally slot t of the partition is row s + t.  With symmetric pairs the
+            // lanes add their sums into the LDS accumulators by row index, so the rows of a
+            // partition may sit in the slabs in any order: longest stored row first, which makes
+            // the rows of a slab equally long (rows with equal column lists are neighbours with
+            // equal counts and stay neighbours).
+            for (int t = 0; t < own; ++t) row_at[s - row_begin + t] = s + t;
+            if (sym)
+                std::stable_sort(row_at.begin() + (s - row_begin), row_at.begin() + (e - row_begin),
+                                 [&](int a, int b) { return cnt_ell[a - row_begin] > cnt_ell[b - row_begin]; });
+            for (int t = 0; t < own; ++t) slot_of[row_at[s - row_begin + t] - row_begin] = t;
+            const int32_t* rows_p = &row_at[s - row_begin];  // slot -> row of this partition
             // Slab widths.  A slab is as wide as its longest row, so a few very long rows (R-MAT
             // hubs) would pad 60-odd short rows up to their length.  Per slab the rows are taken
             // longest first and moved to the residual -- whole row, the CSR segments handle any
@@ -329,10 +342,10 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             // of the reference's long-row path (rows with > 512 in-window entries,
             // convert.c:92-101), which it never launches.
             for (int q = 0; q < nslab; ++q) {
-                const int r0 = s + q * kSlabRows, r1 = std::min(e, r0 + kSlabRows);
+                const int t0 = q * kSlabRows, t1 = std::min(own, t0 + kSlabRows);
                 int idx[kSlabRows];
-                int m_rows = r1 - r0;
-                for (int i = 0; i < m_rows; ++i) idx[i] = r0 + i;
+                int m_rows = t1 - t0;
+                for (int i = 0; i < m_rows; ++i) idx[i] = rows_p[t0 + i];
                 std::sort(idx, idx + m_rows, [&](int a, int b) {
                     int ca = cnt_ell[a - row_begin], cb = cnt_ell[b - row_begin];
                     return ca != cb ? ca > cb : a < b;
@@ -355,24 +368,25 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                     row_to_er[idx[j] - row_begin] = 1;
                 }
                 uint32_t w2 = 0;
-                for (int r = r0; r < r1; ++r) w2 = std::max(w2, (uint32_t)(cnt_ell[r - row_begin] + 1) / 2);
+                for (int t = t0; t < t1; ++t) w2 = std::max(w2, (uint32_t)(cnt_ell[rows_p[t] - row_begin] + 1) / 2);
                 S.slab_w2[q] = w2;
             }
             // Column-list sharing: a row whose column sequence equals that of the row above it
             // (same slab) joins that row's group and stores no column indices of its own.
             // Finite-element matrices with d unknowns per node give groups of d rows.
             S.slab_g.assign(nslab, 0);
-            for (int r = s; r < e; ++r) {
+            for (int t = 0; t < own; ++t) {
+                const int r = rows_p[t], rprev = t > 0 ? rows_p[t - 1] : r;  // the row in the lane before
                 bool lead = true;
-                if (share && (r - s) % kSlabRows != 0 && !row_to_er[r - row_begin] && !row_to_er[r - 1 - row_begin]) {
+                if (share && t % kSlabRows != 0 && !row_to_er[r - row_begin] && !row_to_er[rprev - row_begin]) {
                     const int len = rp[r + 1] - rp[r];
-                    lead = len != rp[r] - rp[r - 1] ||
-                           (len > 0 && memcmp(m->J + rp[r], m->J + rp[r - 1], sizeof(int) * (size_t)len) != 0);
+                    lead = len != rp[rprev + 1] - rp[rprev] ||
+                           (len > 0 && memcmp(m->J + rp[r], m->J + rp[rprev], sizeof(int) * (size_t)len) != 0);
                     // symmetric pairs: the kept / scatter / dropped pattern must be the same as well
-                    if (!lead && sym && len > 0 && memcmp(&state[rp[r] - k0], &state[rp[r - 1] - k0], (size_t)len) != 0) lead = true;
+                    if (!lead && sym && len > 0 && memcmp(&state[rp[r] - k0], &state[rp[rprev] - k0], (size_t)len) != 0) lead = true;
                 }
                 lead_row[r - row_begin] = lead ? 1 : 0;
-                S.slab_g[(r - s) / kSlabRows] += lead ? 1 : 0;
+                S.slab_g[t / kSlabRows] += lead ? 1 : 0;
             }
         }
     }
@@ -410,7 +424,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             S.slab_ner.assign(S.slab_w2.size(), 0);
             for (int r = pb[p]; r < pb[p + 1]; ++r) {
                 const int64_t c = er_rp[r - row_begin + 1] - er_rp[r - row_begin];
-                uint32_t& ner = S.slab_ner[(r - pb[p]) / kSlabRows];
+                uint32_t& ner = S.slab_ner[slot_of[r - row_begin] / kSlabRows];
                 ner = std::max<uint32_t>(ner, (uint32_t)std::min<int64_t>((c + 1) / 2, 1 << 20));
                 if (ner > 255) L->inline_er = false;  // a long residual row: the CSR kernel is the better tool
             }
@@ -483,6 +497,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     L->ell_val.assign((size_t)size_stream, 0.0);
     L->ell_col.assign((size_t)col_words, 0);
     L->lane_group.assign((size_t)nslabs * kSlabRows, 0);
+    // symmetric pairs: which row (place in the partition's LDS image) a lane works on; 0xFFFF = none
+    L->slab_lrow.assign(sym ? (size_t)nslabs * kSlabRows : 0, (uint16_t)0xFFFF);
     std::vector<int32_t> tcol((size_t)nnz_er);
     std::vector<double> tval((size_t)nnz_er);
     int overflow = 0;
@@ -492,9 +508,11 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         const int wlen = L->win_len[p];
         const PartScratch& S = ps[p];
         int gid = 0;
-        for (int r = s; r < e; ++r) {
-            const int64_t sidx = slab_base[p] + (r - s) / kSlabRows;
-            const int lane = (r - s) % kSlabRows;
+        for (int t = 0; t < e - s; ++t) {
+            const int r = row_at[s - row_begin + t];
+            const int64_t sidx = slab_base[p] + t / kSlabRows;
+            const int lane = t % kSlabRows;
+            if (sym) L->slab_lrow[(size_t)sidx * kSlabRows + lane] = (uint16_t)(r - (s & ~1));
             const uint64_t pp = L->slab_pair_ptr[sidx];
             const uint32_t w2 = L->slab_meta[4 * sidx + 3] >> 16;
             const uint32_t ner = (L->slab_meta[4 * sidx + 3] >> 8) & 0xFF;
@@ -503,7 +521,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             const bool lead = lead_row[r - row_begin] != 0;
             gid = lane == 0 ? 0 : gid + (lead ? 1 : 0);
             L->lane_group[(size_t)sidx * kSlabRows + lane] = (uint8_t)gid;
-            if (r + 1 == e)  // lanes past the last row of the partition read the last group (values 0)
+            if (t + 1 == e - s)  // lanes past the last row of the partition read the last group (values 0)
                 for (int l2 = lane + 1; l2 < kSlabRows; ++l2) L->lane_group[(size_t)sidx * kSlabRows + l2] = (uint8_t)gid;
             uint32_t k_ell = 0;
             int64_t k_er = er_rp[r - row_begin];
@@ -564,7 +582,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     std::vector<int64_t> slab_er(nslabs, 0);
     for (int p = 0; p < np; ++p)
         for (int r = pb[p]; r < pb[p + 1]; ++r)
-            slab_er[slab_base[p] + (r - pb[p]) / kSlabRows] += er_rp[r - row_begin + 1] - er_rp[r - row_begin];
+            slab_er[slab_base[p] + slot_of[r - row_begin] / kSlabRows] += er_rp[r - row_begin + 1] - er_rp[r - row_begin];
     std::vector<int32_t> item_of_slab(nslabs, 0);
     {
         auto slab_cost = [&](int64_t sidx) {
@@ -646,7 +664,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             int64_t len = er_rp[rr + 1] - er_rp[rr];
             if (len == 0) continue;
             ++rows_er;
-            const int32_t item = item_of_slab[slab_base[p] + (r - pb[p]) / kSlabRows];
+            const int32_t item = item_of_slab[slab_base[p] + slot_of[r - row_begin] / kSlabRows];
             int pieces = (int)((len + cfg.er_seg_len - 1) / cfg.er_seg_len);
             for (int q = 0; q < pieces; ++q) {
                 int64_t b = er_rp[rr] + len * q / pieces, e2 = er_rp[rr] + len * (q + 1) / pieces;

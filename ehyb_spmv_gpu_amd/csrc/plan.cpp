@@ -67,6 +67,7 @@ int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int
         case EHYB_ARR_SLAB_META: VIEW(H.slab_meta);
         case EHYB_ARR_SEGS: VIEW(H.segs);
         case EHYB_ARR_PERM: VIEW(plan->perm);
+        case EHYB_ARR_SLAB_LROW: VIEW(H.slab_lrow);
         case EHYB_ARR_ER_BINS:
             *ptr = (const void*)H.er_bins;
             *count = 8;

@@ -3,8 +3,8 @@
 // mt-metis + COO2EHYB on every run (solver_test.c:369-382, spmv.cu:74); on the bench matrix that
 // is seconds of host work in front of a 0.14 ms multiply.
 //
-// File: "EHYBPLN3", key, resolved Config, layout scalars, stats, then every array as
-// {u64 count, bytes}, then "EHYBEND3".  Native byte order, same-machine cache -- not an
+// File: "EHYBPLN4", key, resolved Config, layout scalars, stats, then every array as
+// {u64 count, bytes}, then "EHYBEND4".  Native byte order, same-machine cache -- not an
 // interchange format.  A file whose magic, version, key or sizes do not fit is rejected.
 #include "ehyb_internal.h"
 
@@ -17,8 +17,8 @@ using namespace ehyb;
 
 namespace {
 
-const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '3'};
-const char kEnd[8] = {'E', 'H', 'Y', 'B', 'E', 'N', 'D', '3'};
+const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '4'};
+const char kEnd[8] = {'E', 'H', 'Y', 'B', 'E', 'N', 'D', '4'};
 
 struct FileCloser {
     void operator()(FILE* f) const
@@ -61,7 +61,7 @@ bool each_array(HostLayout& H, F&& io)
     return io(H.part_boundary) && io(H.win_len) && io(H.halo_ptr) && io(H.halo_cols) && io(H.slab_pair_ptr) &&
            io(H.slab_row) && io(H.slab_part) && io(H.ell_val) && io(H.ell_col) && io(H.slab_col_ptr) && io(H.lane_group) &&
            io(H.slab_meta) && io(H.items) && io(H.segs) && io(H.er_seg_ptr) && io(H.er_seg_row) && io(H.er_col) &&
-           io(H.er_val) && io(H.er_blocks);
+           io(H.er_val) && io(H.er_blocks) && io(H.slab_lrow);
 }
 
 struct Scalars {
@@ -163,7 +163,7 @@ int ehyb_plan_load(const char* path, uint64_t expect_key, ehyb_plan** plan, int*
         H.slab_meta.size() == nslab * 4 && H.lane_group.size() == nslab * kSlabRows &&
         H.ell_val.size() == (size_t)H.slab_pair_ptr.back() * 2 * kSlabRows && H.ell_col.size() == (size_t)H.slab_col_ptr.back() &&
         H.items.size() % 8 == 0 && H.segs.size() % 8 == 0 && H.er_seg_ptr.size() == nseg + 1 &&
-        H.er_col.size() == (size_t)H.er_seg_ptr.back() && H.er_val.size() == H.er_col.size() && H.er_blocks.size() % 4 == 0 &&
+        H.er_col.size() == (size_t)H.er_seg_ptr.back() && H.er_val.size() == H.er_col.size() && H.er_blocks.size() % 4 == 0 && (H.sym ? H.slab_lrow.size() == nslab * kSlabRows : H.slab_lrow.empty()) &&
         H.lds_doubles > 0 && H.lds_doubles <= EHYB_LDS_MAX_DOUBLES && (perm.empty() || perm.size() == (size_t)H.n_cols);
     if (!consistent) EHYB_FAIL(EHYB_ERR_FORMAT, "ehyb_plan_load: %s holds inconsistent array sizes", path);
     if (reorder_list) {

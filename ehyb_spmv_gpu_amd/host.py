@@ -23,7 +23,7 @@ ARRAYS = {
     "items": (9, np.int32), "er_seg_ptr": (10, np.int64), "er_seg_row": (11, np.int32),
     "er_col": (12, np.int32), "er_val": (13, np.float64), "er_bins": (14, np.int32),
     "slab_col_ptr": (15, np.uint32), "lane_group": (16, np.uint8), "slab_meta": (17, np.uint32),
-    "segs": (18, np.int32), "perm": (19, np.int32),
+    "segs": (18, np.int32), "perm": (19, np.int32), "slab_lrow": (20, np.uint16),
 }
 
 

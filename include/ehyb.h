@@ -245,8 +245,11 @@ enum {
                                    words the column stream holds [er pair][2][lane] GLOBAL 32-bit columns */
     EHYB_ARR_SEGS          = 18,/* int32  [n_segs*8]   {partition, slab_begin, slab_end, halo_count, first row,
                                    end row, win_len, halo_begin}: one LDS window staging each       */
-    EHYB_ARR_PERM          = 19 /* int32  [n_cols]     reorderList stored with a plan that came from
+    EHYB_ARR_PERM          = 19,/* int32  [n_cols]     reorderList stored with a plan that came from
                                    ehyb_plan_load (empty for plans built in this process)          */
+    EHYB_ARR_SLAB_LROW     = 20 /* uint16 [n_slabs*64] symmetric pair storage only: the row every lane works on, as
+                                   its place in the partition's LDS image (row - even(partition start));
+                                   0xFFFF = no row.  The rows of a partition sit in its slabs longest first. */
 };
 int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int64_t* count);
 

@@ -169,7 +169,9 @@ def walk_plan(plan, x):
     seg_done = np.zeros(len(seg_row), dtype=np.int32)
     inline = plan.stats["er_inline"] > 0
     y_inl = np.zeros(n)
-    sym = plan.stats["sym_pairs"] > 0
+    lrow_tab = plan.array("slab_lrow").astype(np.int64).reshape(-1, 64)
+    sym = len(lrow_tab) > 0          # symmetric pair storage: lanes name their rows, one workgroup per partition
+    assert sym or plan.stats["sym_pairs"] == 0
     y_mirror = np.zeros(n)
     next_seg, next_slab = 0, 0
     for g0, g1, is0, is1, e0, e64, e16, e1 in items:
@@ -205,6 +207,17 @@ def walk_plan(plan, x):
                 assert meta[s, 0] == p0 and meta[s, 1] == scp[s] and meta[s, 2] == slab_row[s] and spp[s + 1] == p1 + ner
                 assert (scp[s + 1] - scp[s]) == npairs * G + ner * 128
                 assert ner == 0 or inline, "inline residual pairs only in the inline form"
+                # which row every lane works on: plain = first row + lane; symmetric pairs = the
+                # slab_lrow table (place in the partition's LDS image, 0xFFFF = none)
+                if sym:
+                    lr = lrow_tab[s]
+                    has = lr != 0xFFFF
+                    assert np.all((lr[has] >= (ps & 1)) & (lr[has] < (ps & 1) + wl)), "lane row outside the partition"
+                    rows_l = np.where(has, base + lr, -1)
+                else:
+                    r0 = int(slab_row[s])
+                    has = np.arange(64) < pe - r0
+                    rows_l = np.where(has, r0 + np.arange(64), -1)
                 if p1 > p0:
                     v = ell_val[p0 * 128:p1 * 128].reshape(npairs, 64, 2)
                     words = ell_col[scp[s]:scp[s] + npairs * G].reshape(npairs, G)[:, lane_group[s]]  # [pair][lane]
@@ -215,26 +228,22 @@ def walk_plan(plan, x):
                         mirror = (c >> 15).astype(bool)
                         c = c & 0x7FFF
                         assert not mirror.any() or (c[mirror].max() < (ps & 1) + wl and c[mirror].min() >= (ps & 1)), "mirror target outside the partition's rows"
-                        r0s = int(slab_row[s])
-                        xrow = np.zeros(64)
-                        xrow[:min(64, pe - r0s)] = x[r0s:min(r0s + 64, pe)]
+                        xrow = np.where(has, x[np.maximum(rows_l, 0)], 0.0)
                         contrib = v * xrow[None, :, None]
-                        # lanes past the partition end read the last group's words: their values are zero
-                        assert not contrib[mirror & (np.arange(64)[None, :, None] >= pe - r0s)].any(), "a padding lane scatters a value"
+                        # lanes without a row read the last group's words: their values are zero
+                        assert not (v[:, ~has, :]).any(), "a lane without a row holds a value"
                         np.add.at(y_mirror, base + c[mirror], contrib[mirror])
                     assert c.max() < len(win), "window-local column outside the window"
                     acc = (v * win[c]).sum(axis=(0, 2))
-                r0 = int(slab_row[s])
-                cnt = min(64, pe - r0)
-                y[r0:r0 + cnt] = acc[:cnt]
-                written[r0:r0 + cnt] += 1
+                y[rows_l[has]] = acc[has]
+                written[rows_l[has]] += 1
                 if ner:
                     # inline residual: values behind the ELL pairs, global columns [pair][2][lane]
-                    # behind the shared column words; lanes past the partition end hold zeros
+                    # behind the shared column words; lanes without a row hold zeros
                     ve = ell_val[p1 * 128:(p1 + ner) * 128].reshape(ner, 64, 2)
                     ce = ell_col[scp[s] + npairs * G:scp[s + 1]].reshape(ner, 2, 64).transpose(0, 2, 1)
-                    assert ce.max() < n and not np.any(ve[:, cnt:, :])
-                    y_inl[r0:r0 + cnt] = (ve * x[ce]).sum(axis=(0, 2))[:cnt]
+                    assert ce.max() < n and not np.any(ve[:, ~has, :])
+                    y_inl[rows_l[has]] = (ve * x[ce]).sum(axis=(0, 2))[has]
     er_col = plan.array("er_col")
     er_val = plan.array("er_val")
     assert np.all(seg_done == 1), "every residual segment belongs to exactly one work item"
