@@ -577,19 +577,15 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     }
     if (overflow) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: entry counts changed between passes");
 
-    // ---- work items: contiguous slab ranges of roughly equal cost.  The residual entries of
-    // an item's rows are charged to it (they are multiplied by the same workgroup).
-    std::vector<int64_t> slab_er(nslabs, 0);
-    for (int p = 0; p < np; ++p)
-        for (int r = pb[p]; r < pb[p + 1]; ++r)
-            slab_er[slab_base[p] + slot_of[r - row_begin] / kSlabRows] += er_rp[r - row_begin + 1] - er_rp[r - row_begin];
+    // ---- work items: contiguous slab ranges of roughly equal cost = the bytes the ELL launch streams
+    // for them.  (An inline residual is part of `pairs`; a residual with a launch of its own costs
+    // this one nothing -- charging it here made the ELL phase of R-MAT twice as long: 198 vs 94 us.)
     std::vector<int32_t> item_of_slab(nslabs, 0);
     {
         auto slab_cost = [&](int64_t sidx) {
-            // streamed bytes: values + shared column words; residual entries cost an x gather each
             const int64_t pairs = L->slab_pair_ptr[sidx + 1] - L->slab_pair_ptr[sidx];
             const int64_t words = L->slab_col_ptr[sidx + 1] - L->slab_col_ptr[sidx];
-            return pairs * (kSlabRows * 16) + words * 4 + slab_er[sidx] * 40 + 1024;
+            return pairs * (kSlabRows * 16) + words * 4 + 1024;
         };
         // Work items: the global slab sequence cut into `want` = items_per_cu x 256 runs of equal cost
         // (2 workgroups are resident per CU, so 512 items are exactly one wave of workgroups; 513
