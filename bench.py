@@ -147,6 +147,8 @@ def main():
     ap.add_argument("--window-mode", type=int, default=0)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange first, then multiply (no stream overlap)")
+    ap.add_argument("--no-plain-arm", action="store_true",
+                    help="N=1 with symmetric pair storage: skip the extra plain-storage measurement of the same matrix")
     ap.add_argument("--sym-pairs", default="auto", choices=["auto", "on", "off"],
                     help="symmetric pair storage (cfg.sym_pairs): auto = on for the symmetric workloads")
     ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
@@ -312,6 +314,35 @@ def main():
                                 "(12 B per entry, SURVEY 8d) can exceed the HBM peak; traffic and hbm_GBps_from_traffic "
                                 "are the bytes really moved" % (2 * st["sym_pairs"], st["nnz"]))
 
+    # ---- the same matrix with plain storage (every entry stored, as the reference does), for the record
+    plain = None
+    if world == 1 and st["sym_pairs"] > 0 and not args.no_plain_arm:
+        t0 = time.time()
+        cfg_p = E.make_config(verbose=0, **{k: v for k, v in kw.items() if k != "sym_pairs"})
+        mp = E.Matrix.generate(gen, *gargs, cfg=cfg_p)
+        mp.reorder(cfg_p)
+        plan_p = E.Plan(mp, cfg_p)
+        xp_d = E.DeviceBuffer(n).upload(E.vector_reorder(x, mp.reorder_list))
+        yp_d = E.DeviceBuffer(n)
+        rp_ = plan_p.bench(xp_d.ptr, yp_d.ptr, warmup=args.warmup, iters=args.steps)
+        ms_p = rp_["ms_total"] / args.steps
+        stp = plan_p.stats
+        bytes_p = 12 * (stp["nnz_ell"] + (stp["nnz_er"] if stp["er_inline"] else 0)) + 4 * (n + 1) + 16 * n
+        plain = {"value": round(2.0 * nnz / ms_p / 1e6, 2), "unit": "GFLOP/s", "ms_per_step": round(ms_p, 5),
+                 "ell_kernel_avg_launch_ms": round(rp_["ms_ell_avg"], 5),
+                 "roofline_frac": round(bytes_p / (rp_["ms_ell_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                 "stored_values": stp["size_block_ell"], "format_bytes_per_spmv": stp["bytes_format"],
+                 "note": "every entry stored (bench.py --sym-pairs off); same run, same GPU"}
+        if y_cpu is not None:
+            from oracle import oracle as O
+
+            badp, worstp = O.check_tolerance(E.vector_recover(yp_d.download(), mp.reorder_list), y_cpu, scale)
+            plain["parity"] = {"rows_over_1e-12": badp, "worst_rel": worstp}
+            if badp:
+                raise SystemExit("bench.py: plain-storage result differs from the CPU oracle")
+        log(f"[bench] plain-storage arm: {plain['value']} GFLOP/s ({time.time() - t0:.1f}s incl. its own pre-step)")
+        plan_p.destroy()
+
     if rank == 0:
         ms_per_step = elapsed / args.steps * 1e3
         value = 2.0 * nnz * args.steps / elapsed / 1e9
@@ -331,6 +362,8 @@ def main():
             "alg_GBps": round((12 * nnz + 4 * (n + 1) + 16 * n) / (elapsed / args.steps) / 1e9, 1),
             "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
         }
+        if plain:
+            out["plain_storage"] = plain
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
