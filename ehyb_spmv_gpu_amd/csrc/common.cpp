@@ -39,18 +39,23 @@ Config resolve_config(const ehyb_config* in)
     // Measured best (tools/sweep.py --sym 1): 256 partitions, one 1024-thread workgroup per CU, which
     // a 112 KiB budget gives; two per CU (80 KiB, 512 partitions) is 7 % slower.
     c.sym_pairs = (z.sym_pairs == 1 && c.window_mode == EHYB_WINDOW_HALO) ? 1 : 2;
-    c.lds_doubles = z.lds_doubles > 0 ? std::min(z.lds_doubles, EHYB_LDS_MAX_DOUBLES) : (c.sym_pairs == 1 ? 14336 : 10240);
+    // Plain storage: the whole 160 KiB of a CU as one window, one workgroup per CU, 256 equal-cost work
+    // items -- fewer, larger partitions mean fewer halo columns to stage and less padding (audikw_1-like:
+    // 136 us against 153 us with two 80 KiB workgroups per CU on the same box; banded +4 %, KKT and
+    // R-MAT unchanged).
+    c.lds_doubles = z.lds_doubles > 0 ? std::min(z.lds_doubles, EHYB_LDS_MAX_DOUBLES) : (c.sym_pairs == 1 ? 14336 : EHYB_LDS_MAX_DOUBLES);
     c.lds_doubles = std::max(kSlabRows, round_down(c.lds_doubles, 2));
     // Rows per partition: the whole window in reference mode (convert.c:247 tests against
     // partStart + vectorCacheSize); 55 % of it in halo mode (measured best), the rest holds gathered columns.
     int dflt_rows = c.window_mode == EHYB_WINDOW_REFERENCE ? c.lds_doubles : c.lds_doubles * 11 / 20;
     c.part_rows = z.part_rows > 0 ? std::min(z.part_rows, c.lds_doubles) : dflt_rows;
     c.part_rows = std::max(kSlabRows, round_down(c.part_rows, kSlabRows));
-    c.threads = z.threads > 0 ? z.threads : 1024;  // 2 workgroups x 16 waves per CU at the default window
+    c.threads = z.threads > 0 ? z.threads : 1024;  // 16 waves per workgroup
     c.threads = std::min(1024, std::max(64, round_down(c.threads, 64)));
-    // 2 workgroups are resident per CU: 2 items per CU = exactly one wave of workgroups.  Measured:
-    // 512 and 1024 items are good, 768 (one and a half waves) loses up to 12 % (tools/sweep.py).
-    c.items_per_cu = z.items_per_cu > 0 ? z.items_per_cu : 2;
+    // As many work items per CU as workgroups are resident there (LDS and thread limits): exactly one
+    // resident round.  Measured: one or two whole rounds are good, one and a half loses up to 12 %.
+    const int resident = std::max(1, std::min(EHYB_LDS_MAX_DOUBLES / c.lds_doubles, 2048 / c.threads));
+    c.items_per_cu = z.items_per_cu > 0 ? z.items_per_cu : resident;
     c.partitioner = z.partitioner;
     c.er_seg_len = z.er_seg_len > 0 ? std::max(64, z.er_seg_len) : 4096;
     c.host_threads = z.host_threads;
