@@ -240,8 +240,10 @@ __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict
 }
 
 template <int THREADS, bool DYN, bool STAMP, bool INLINE_ER, bool SYM>
-// 8 waves per SIMD (<= 64 VGPRs): two 1024-thread workgroups per CU, the occupancy the 80 KiB window is sized
-// for.  SYM runs one workgroup per CU (its window holds x and the y accumulators): 4 waves per SIMD, 128 VGPRs.
+// Plain: <= 64 VGPRs (8 waves per SIMD), so that two 1024-thread workgroups share a CU when the caller picks
+// a window of <= 80 KiB; at the default 160 KiB window one runs per CU (an 8-pair step with 128 VGPRs was
+// measured there too: no gain).  SYM always runs one workgroup per CU (its window holds x and the y
+// accumulators): 4 waves per SIMD, up to 128 VGPRs, no spills.
 __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(SYM ? 4 : 8, 8))) void ehyb_ell_kernel(const EllArgs A)
 {
     extern __shared__ __attribute__((aligned(16))) double win[];
