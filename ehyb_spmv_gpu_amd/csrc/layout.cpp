@@ -37,6 +37,8 @@ struct PartScratch {
     std::vector<uint32_t> slab_ner;  // residual pairs per slab (inline form only)
 };
 
+constexpr int kWideRow = 128;  // ELL entries per row above which the row is multiplied by the residual kernel
+
 inline int halo_lookup(const std::vector<int32_t>& halo, int col)
 {
     auto it = std::lower_bound(halo.begin(), halo.end(), col);
@@ -320,6 +322,15 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                         ++c;
                     else if (halo_mode && !S.halo.empty() && halo_lookup(S.halo, j) >= 0)
                         ++c;
+                }
+                // A slab is walked by ONE wave, four pairs per memory round trip: a slab of rows with
+                // hundreds of entries keeps a single wave busy for longer than the rest of its
+                // workgroup needs for everything else (R-MAT: a 5-slab item of 131 pairs each ended
+                // at 116 us of a 120 us launch).  Such rows go to the residual whole, where 64 lanes
+                // share a row.
+                if (cfg.hub_rule != 2 && c > kWideRow) {
+                    row_to_er[r - row_begin] = 1;
+                    c = 0;
                 }
                 cnt_ell[r - row_begin] = c;
             }
