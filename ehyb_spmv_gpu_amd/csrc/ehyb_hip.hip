@@ -122,14 +122,36 @@ struct EllArgs {
 
 // One entry of a slab: gather x from the window; SYM: bit 15 of the column says "this entry also
 // stands for its mirror image": value * x[own row] goes to row `column`'s accumulator in LDS.
+// The value of the next lane (lane + 1), 0 behind the last one: two DPP moves, no LDS traffic.
+__device__ __forceinline__ double next_lane(double v)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), 0x130 /* wave_shl:1 */, 0xf, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), 0x130, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+
+// Lanes of a group (equal column lists: the unknowns of a node) send their mirror products to the
+// SAME accumulator.  Summed across the lanes first (`code`: this lane adds for itself and the next
+// 0/1/2 lanes, 3 = a lane before it adds for this one), a group of three costs one ds_add_f64
+// instead of three that the hardware has to serialise.
+#ifndef EHYB_SYM_GROUP_SUM
+#define EHYB_SYM_GROUP_SUM 1
+#endif
 template <bool SYM>
 __device__ __forceinline__ void ell_entry(double v, uint32_t col16, const double* __restrict__ win, double* yacc, double xi,
-                                          double& acc)
+                                          int code, double& acc)
 {
     if (SYM) {
         const uint32_t idx = col16 & 0x7fffu;
         acc = fma(v, win[idx], acc);
-        if (col16 & 0x8000u) unsafeAtomicAdd(&yacc[idx], v * xi);  // ds_add_f64
+        if (EHYB_SYM_GROUP_SUM) {
+            const double mine = (col16 & 0x8000u) ? v * xi : 0.0;
+            const double n1 = next_lane(mine), n2 = next_lane(n1);
+            const double sum = mine + ((code == 1 || code == 2) ? n1 : 0.0) + (code == 2 ? n2 : 0.0);
+            if ((col16 & 0x8000u) && code != 3) unsafeAtomicAdd(&yacc[idx], sum);  // ds_add_f64
+        } else {
+            if (col16 & 0x8000u) unsafeAtomicAdd(&yacc[idx], v * xi);
+        }
     } else {
         acc = fma(v, win[col16], acc);
     }
@@ -144,7 +166,10 @@ __device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restr
     const int np = (int)(sm.w >> 16);
     const int G = (int)(sm.w & 0x3fu) + 1;  // lanes with equal column lists share one word per pair
     const double2* __restrict__ v = A.ell_val + (size_t)sm.x * 64 + lane;
-    const uint32_t* __restrict__ c = A.ell_col + sm.y + A.lane_group[(size_t)s * 64 + lane];
+    // the lane's group (bits 0-5) and, with symmetric pairs, its part in the group's sum (bits 6-7)
+    const uint32_t lgb = A.lane_group[(size_t)s * 64 + lane];
+    const int code = SYM ? (int)(lgb >> 6) : 0;
+    const uint32_t* __restrict__ c = A.ell_col + sm.y + (SYM ? (lgb & 0x3fu) : lgb);
     double acc0 = 0.0, acc1 = 0.0;
     if (INLINE_ER) {
         // Inline residual (tiny residuals only): `ner` more pairs behind the slab's ELL pairs, their
@@ -172,20 +197,20 @@ __device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restr
     for (; k + 4 <= np; k += 4) {
         const double2 v0 = v[(k + 0) * 64], v1 = v[(k + 1) * 64], v2 = v[(k + 2) * 64], v3 = v[(k + 3) * 64];
         const uint32_t c0 = c[(k + 0) * G], c1 = c[(k + 1) * G], c2 = c[(k + 2) * G], c3 = c[(k + 3) * G];
-        ell_entry<SYM>(v0.x, c0 & 0xffffu, win, yacc, xi, acc0);
-        ell_entry<SYM>(v0.y, c0 >> 16, win, yacc, xi, acc1);
-        ell_entry<SYM>(v1.x, c1 & 0xffffu, win, yacc, xi, acc0);
-        ell_entry<SYM>(v1.y, c1 >> 16, win, yacc, xi, acc1);
-        ell_entry<SYM>(v2.x, c2 & 0xffffu, win, yacc, xi, acc0);
-        ell_entry<SYM>(v2.y, c2 >> 16, win, yacc, xi, acc1);
-        ell_entry<SYM>(v3.x, c3 & 0xffffu, win, yacc, xi, acc0);
-        ell_entry<SYM>(v3.y, c3 >> 16, win, yacc, xi, acc1);
+        ell_entry<SYM>(v0.x, c0 & 0xffffu, win, yacc, xi, code, acc0);
+        ell_entry<SYM>(v0.y, c0 >> 16, win, yacc, xi, code, acc1);
+        ell_entry<SYM>(v1.x, c1 & 0xffffu, win, yacc, xi, code, acc0);
+        ell_entry<SYM>(v1.y, c1 >> 16, win, yacc, xi, code, acc1);
+        ell_entry<SYM>(v2.x, c2 & 0xffffu, win, yacc, xi, code, acc0);
+        ell_entry<SYM>(v2.y, c2 >> 16, win, yacc, xi, code, acc1);
+        ell_entry<SYM>(v3.x, c3 & 0xffffu, win, yacc, xi, code, acc0);
+        ell_entry<SYM>(v3.y, c3 >> 16, win, yacc, xi, code, acc1);
     }
     for (; k < np; ++k) {
         const double2 v0 = v[k * 64];
         const uint32_t c0 = c[k * G];
-        ell_entry<SYM>(v0.x, c0 & 0xffffu, win, yacc, xi, acc0);
-        ell_entry<SYM>(v0.y, c0 >> 16, win, yacc, xi, acc1);
+        ell_entry<SYM>(v0.x, c0 & 0xffffu, win, yacc, xi, code, acc0);
+        ell_entry<SYM>(v0.y, c0 >> 16, win, yacc, xi, code, acc1);
     }
     if (has_row) {
         if (SYM)

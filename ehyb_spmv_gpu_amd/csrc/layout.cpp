@@ -585,6 +585,25 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             }
             if (k_er != er_rp[r - row_begin + 1] || (int)k_ell != cnt_ell[r - row_begin]) overflow = 1;
         }
+        if (sym) {
+            // Lanes of a group read the same column word, so their mirror products go to the same
+            // accumulator: the kernel sums them across lanes first and lets one lane add.  Bits 6-7
+            // of the lane's group byte say how: 0/1/2 = add, together with the next 0/1/2 lanes;
+            // 3 = another lane adds for this one.  (Runs longer than three are cut into threes.)
+            const int64_t s0 = slab_base[p], s1 = slab_base[p + 1];
+            for (int64_t sidx = s0; sidx < s1; ++sidx) {
+                uint8_t* lg = &L->lane_group[(size_t)sidx * kSlabRows];
+                for (int l = 0; l < kSlabRows;) {
+                    int run = 1;
+                    while (l + run < kSlabRows && lg[l + run] == lg[l]) ++run;
+                    for (int q = 0; q < run; ++q) {
+                        const int code = q % 3 == 0 ? std::min(2, run - q - 1) : 3;
+                        lg[l + q] = (uint8_t)(lg[l + q] | (code << 6));
+                    }
+                    l += run;
+                }
+            }
+        }
     }
     if (overflow) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: entry counts changed between passes");
 

@@ -158,7 +158,9 @@ def walk_plan(plan, x):
     ell_val = plan.array("ell_val")
     ell_col = plan.array("ell_col").astype(np.int64)
     scp = plan.array("slab_col_ptr").astype(np.int64)
-    lane_group = plan.array("lane_group").astype(np.int64).reshape(-1, 64)
+    lane_byte = plan.array("lane_group").astype(np.int64).reshape(-1, 64)
+    lane_group = lane_byte & 0x3F      # bits 6-7: the lane's part in its group's mirror sum (symmetric pairs only)
+    lane_code = lane_byte >> 6
     meta = plan.array("slab_meta").astype(np.int64).reshape(-1, 4)
     items = plan.array("items").reshape(-1, 8)
     segs = plan.array("segs").reshape(-1, 8)
@@ -210,6 +212,14 @@ def walk_plan(plan, x):
                 # which row every lane works on: plain = first row + lane; symmetric pairs = the
                 # slab_lrow table (place in the partition's LDS image, 0xFFFF = none)
                 if sym:
+                    # every lane is covered exactly once by an adding lane of its own group:
+                    # code 0/1/2 = adds for itself and the next 0/1/2 lanes, 3 = covered by a lane before
+                    covered = np.zeros(64, dtype=int)
+                    for l in np.flatnonzero(lane_code[s] != 3):
+                        span = int(lane_code[s][l]) + 1
+                        assert l + span <= 64 and np.all(lane_group[s][l:l + span] == lane_group[s][l])
+                        covered[l:l + span] += 1
+                    assert np.all(covered == 1), "group sums do not cover every lane exactly once"
                     lr = lrow_tab[s]
                     has = lr != 0xFFFF
                     assert np.all((lr[has] >= (ps & 1)) & (lr[has] < (ps & 1) + wl)), "lane row outside the partition"
