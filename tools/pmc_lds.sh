@@ -6,7 +6,7 @@ cd "${GRAFT_REPO_ROOT:-$(dirname "$0")/..}"
 export TMPDIR=/tmp
 OUT=gpurun_out/pmc_lds
 rm -rf "$OUT"
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d "$OUT" -- python3 tools/pmc_run.py --iters 5 > "$OUT.log" 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAVE_CYCLES SQ_WAIT_ANY --kernel-trace --output-format csv -d "$OUT" -- python3 tools/pmc_run.py --iters 5 "$@" > "$OUT.log" 2>&1   # e.g. --plain, --workload kkt3d-110
 python3 - <<'PY'
 import csv, glob, collections
 acc = collections.defaultdict(lambda: collections.defaultdict(list))

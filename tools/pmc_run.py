@@ -18,6 +18,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="audikw_1-like")
     ap.add_argument("--iters", type=int, default=10)
+    ap.add_argument("--plain", action="store_true", help="every entry stored even for a symmetric workload")
     args = ap.parse_args()
     import bench as B
     import ehyb_spmv_gpu_amd as E
@@ -27,7 +28,7 @@ def main():
     bw = C.c_double()
     lib.ehyb_measure_read_bw(1 << 30, 5, C.byref(bw))  # 8 launches of ehyb_read_kernel over 1 GiB
     gen, gargs, _ = B.WORKLOADS[args.workload]
-    cfg = E.make_config(sym_pairs=1 if gen in B.SYMMETRIC_GENERATORS else 0)  # as bench.py does
+    cfg = E.make_config(sym_pairs=1 if (gen in B.SYMMETRIC_GENERATORS and not args.plain) else 0)  # as bench.py does
     m = E.Matrix.generate(gen, *gargs, cfg=cfg)
     x = E.x_glibc(m.n)
     m.reorder(cfg)
