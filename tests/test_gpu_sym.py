@@ -12,6 +12,8 @@ pytestmark = pytest.mark.gpu
 CASES = [
     ("fem3d-3dof", "fem3d", (30000, 3, 22, 22, 13500, 1, 1)),      # symmetric, shared column lists
     ("fem3d-1dof", "fem3d", (20000, 1, 30, 30, 50000, 1, 2)),
+    ("fem3d-2dof", "fem3d", (20000, 2, 25, 25, 30000, 1, 3)),      # groups of two: the lane sums take one neighbour
+    ("fem3d-6dof", "fem3d", (30000, 6, 18, 18, 13500, 1, 4)),      # groups of six: cut into two sums of three
     ("stencil", "stencil2d", (150, 150, 9, 3000, 1)),               # symmetric, short rows
     ("kkt", "kkt3d", (18,)),                                        # symmetric saddle point, zero diagonal block
     ("rmat", "rmat", (13, 1 << 16, 9)),                             # unsymmetric: almost nothing pairs up
