@@ -4,23 +4,33 @@
 // (kernel.cu:20-42), myxpy / initialize_all wrappers (kernel.cu:298-321).
 //
 // Per iteration: one ehyb_spmv (q = A p) and three memory-bound vector kernels, each a grid-stride
-// pass with one wave shuffle + LDS reduction and one fp64 atomic per workgroup:
+// pass over the vectors:
 //   1. pq   = p . q
-//   2. x += alpha p ; r -= alpha q ; rz_new = r . z ; rr = r . r   (alpha = rz / pq, read from the device)
+//   2. x += alpha p ; r -= alpha q ; rz_new = r . z ; rr = r . r   (alpha = rz / pq)
 //   3. p  = z + beta p                                              (beta  = rz_new / rz)  [kernelMyxpy]
 // with z = M^-1 r for the diagonal (Jacobi) preconditioner -- the PRECOND switch of the reference's
 // cb_s (spmv.h:7-15) -- recomputed on the fly from 1/diag, or z = r without one.
-// The scalars live in one device array; nothing is copied to the host inside the loop except
-// the residual norm every `check_every` iterations.
+//
+// Dot products never leave the device and use no atomics: a kernel writes one partial sum per
+// workgroup, and the kernel that needs the scalar adds the (at most 1024) partials up again in a
+// fixed order -- every workgroup for itself, 8 KiB out of L2.  (A first version added the partials
+// with one fp64 atomic per workgroup: 2048 same-address atomics cost 28 us per dot product,
+// profiles/r01_j_cg.txt.)  Nothing has to be zeroed or rolled between iterations; r.z alternates
+// between two partial arrays, so an even and an odd iteration differ in one kernel argument and
+// are captured together into one hipGraph, replayed once per two iterations.  The sums have a
+// fixed order, so a solve is reproducible run to run wherever the multiply is (plain storage).
+// The host reads the partials every `check_every` iterations for the stopping test.
 #include <hip/hip_runtime.h>
 
 #include <cmath>
+#include <cstdlib>
+#include <vector>
 
 #include "ehyb_internal.h"
 
 using namespace ehyb;
 
-#define CG_TRY(expr)                                                                                        \
+#define HIP_TRY(expr)                                                                                       \
     do {                                                                                                    \
         hipError_t _e = (expr);                                                                             \
         if (_e != hipSuccess) {                                                                             \
@@ -31,46 +41,59 @@ using namespace ehyb;
 
 namespace {
 
-enum { S_RS = 0, S_PQ = 1, S_RS_NEW = 2, S_BB = 3, S_RR = 4 };  // r.z, p.q, next r.z, b.b, r.r
-
 constexpr int kThreads = 256;
+constexpr int kMaxGrid = 1024;  // partial sums per dot product
 
-__device__ __forceinline__ void block_add(double v, double* __restrict__ target)
+// partial arrays, kMaxGrid doubles each
+enum { A_BB = 0, A_PQ = 1, A_RR = 2, A_RZ0 = 3, A_RZ1 = 4, A_COUNT = 5 };
+
+// sum over the workgroup, returned to every thread; fixed order
+__device__ __forceinline__ double block_sum(double v)
 {
     __shared__ double part[kThreads / 64];
 #pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    __syncthreads();  // a previous call's readers are done with part[]
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        double s = 0.0;
+    double s = 0.0;
 #pragma unroll
-        for (int w = 0; w < kThreads / 64; ++w) s += part[w];
-        unsafeAtomicAdd(target, s);
-    }
+    for (int w = 0; w < kThreads / 64; ++w) s += part[w];
+    return s;
 }
 
-// r = b - q (q = A x0), z = dinv .* r (or r), p = z, rs = r.z, rr = r.r, bb = b.b
+__device__ __forceinline__ double sum_partials(const double* __restrict__ part)
+{
+    double v = 0.0;
+    for (int i = threadIdx.x; i < (int)gridDim.x; i += kThreads) v += part[i];
+    return block_sum(v);
+}
+
+__device__ __forceinline__ void put_partial(double v, double* __restrict__ part)
+{
+    const double s = block_sum(v);
+    if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+
+// r = b - q (q = A x0), z = dinv .* r (or r), p = z; partials of r.z, r.r, b.b
 __global__ __launch_bounds__(kThreads) void cg_init_kernel(int n, const double* __restrict__ b,
                                                            const double* __restrict__ q, const double* __restrict__ dinv,
                                                            double* __restrict__ r, double* __restrict__ p,
                                                            double* __restrict__ s)
 {
-    double rs = 0.0, rr = 0.0, bb = 0.0;
+    double rz = 0.0, rr = 0.0, bb = 0.0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         const double bi = b[i], ri = bi - q[i];
         const double zi = dinv ? ri * dinv[i] : ri;
         r[i] = ri;
         p[i] = zi;
-        rs = fma(ri, zi, rs);
+        rz = fma(ri, zi, rz);
         rr = fma(ri, ri, rr);
         bb = fma(bi, bi, bb);
     }
-    block_add(rs, s + S_RS);
-    __syncthreads();
-    block_add(bb, s + S_BB);
-    __syncthreads();
-    block_add(rr, s + S_RR + 1);  // the slot the host reads; S_RR itself stays zero for the first iteration
+    put_partial(rz, s + A_RZ0 * kMaxGrid);
+    put_partial(rr, s + A_RR * kMaxGrid);
+    put_partial(bb, s + A_BB * kMaxGrid);
 }
 
 __global__ __launch_bounds__(kThreads) void cg_dot_kernel(int n, const double* __restrict__ p,
@@ -78,15 +101,16 @@ __global__ __launch_bounds__(kThreads) void cg_dot_kernel(int n, const double* _
 {
     double acc = 0.0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) acc = fma(p[i], q[i], acc);
-    block_add(acc, s + S_PQ);
+    put_partial(acc, s + A_PQ * kMaxGrid);
 }
 
+// cur: which of the two r.z arrays holds this iteration's r.z; the new one goes to the other
 __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, const double* __restrict__ p,
                                                              const double* __restrict__ q, const double* __restrict__ dinv,
                                                              double* __restrict__ x, double* __restrict__ r,
-                                                             double* __restrict__ s)
+                                                             double* __restrict__ s, int cur)
 {
-    const double alpha = s[S_RS] / s[S_PQ];
+    const double alpha = sum_partials(s + (A_RZ0 + cur) * kMaxGrid) / sum_partials(s + A_PQ * kMaxGrid);
     double rz = 0.0, rr = 0.0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         x[i] = fma(alpha, p[i], x[i]);
@@ -95,29 +119,37 @@ __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, const double
         rz = fma(ri, dinv ? ri * dinv[i] : ri, rz);
         rr = fma(ri, ri, rr);
     }
-    block_add(rz, s + S_RS_NEW);
-    __syncthreads();
-    block_add(rr, s + S_RR);
+    put_partial(rz, s + (A_RZ0 + (cur ^ 1)) * kMaxGrid);
+    put_partial(rr, s + A_RR * kMaxGrid);
 }
 
-// p = z + beta p  (the reference's kernelMyxpy with gamma = beta), then roll the scalars
+// p = z + beta p  (the reference's kernelMyxpy with gamma = beta)
 __global__ __launch_bounds__(kThreads) void cg_direction_kernel(int n, const double* __restrict__ r,
                                                                 const double* __restrict__ dinv, double* __restrict__ p,
-                                                                const double* __restrict__ s)
+                                                                const double* __restrict__ s, int cur)
 {
-    const double beta = s[S_RS_NEW] / s[S_RS];
+    const double beta = sum_partials(s + (A_RZ0 + (cur ^ 1)) * kMaxGrid) / sum_partials(s + (A_RZ0 + cur) * kMaxGrid);
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
         p[i] = fma(beta, p[i], dinv ? r[i] * dinv[i] : r[i]);
 }
 
-__global__ void cg_roll_kernel(double* __restrict__ s)
-{
-    s[S_RS] = s[S_RS_NEW];
-    s[S_RS_NEW] = 0.0;
-    s[S_PQ] = 0.0;
-    s[S_RR + 1] = s[S_RR];  // the residual norm the host reads
-    s[S_RR] = 0.0;
-}
+// everything a solve owns; released on every way out
+struct Workspace {
+    double *r = nullptr, *p = nullptr, *q = nullptr, *s = nullptr;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    hipStream_t own = nullptr;
+    ~Workspace()
+    {
+        if (exec) (void)hipGraphExecDestroy(exec);
+        if (graph) (void)hipGraphDestroy(graph);
+        if (own) (void)hipStreamDestroy(own);
+        if (r) (void)hipFree(r);
+        if (p) (void)hipFree(p);
+        if (q) (void)hipFree(q);
+        if (s) (void)hipFree(s);
+    }
+};
 
 }  // namespace
 
@@ -138,55 +170,78 @@ extern "C" int ehyb_pcg(ehyb_plan* P, const double* dinv, const double* b, doubl
     const int n = P->host.n_cols;
     hipStream_t st = (hipStream_t)stream;
     if (check_every <= 0) check_every = 10;
-    double *r = nullptr, *p = nullptr, *q = nullptr, *s = nullptr;
-    auto cleanup = [&]() {
-        if (r) (void)hipFree(r);
-        if (p) (void)hipFree(p);
-        if (q) (void)hipFree(q);
-        if (s) (void)hipFree(s);
-    };
-    CG_TRY(hipMalloc((void**)&r, (size_t)n * 8));
-    CG_TRY(hipMalloc((void**)&p, (size_t)n * 8));
-    CG_TRY(hipMalloc((void**)&q, (size_t)n * 8));
-    CG_TRY(hipMalloc((void**)&s, 8 * sizeof(double)));
-    CG_TRY(hipMemsetAsync(s, 0, 8 * sizeof(double), st));
-    const int grid = std::max(1, std::min((n + kThreads - 1) / kThreads, 2048));
+    check_every += check_every & 1;  // iterations are issued in even/odd pairs
+    Workspace W;
+    if (!st) {  // the legacy default stream cannot be captured: solve on a private (blocking) stream instead
+        HIP_TRY(hipStreamCreate(&W.own));
+        st = W.own;
+        stream = (void*)W.own;
+    }
+    HIP_TRY(hipMalloc((void**)&W.r, (size_t)n * 8));
+    HIP_TRY(hipMalloc((void**)&W.p, (size_t)n * 8));
+    HIP_TRY(hipMalloc((void**)&W.q, (size_t)n * 8));
+    HIP_TRY(hipMalloc((void**)&W.s, (size_t)A_COUNT * kMaxGrid * sizeof(double)));
+    double *r = W.r, *p = W.p, *q = W.q, *s = W.s;
+    const int grid = std::max(1, std::min((n + kThreads - 1) / kThreads, kMaxGrid));
 
     int rc = ehyb_spmv(P, x, q, stream);  // q = A x0
-    if (rc != EHYB_OK) {
-        cleanup();
-        return rc;
-    }
+    if (rc != EHYB_OK) return rc;
     hipLaunchKernelGGL(cg_init_kernel, dim3(grid), dim3(kThreads), 0, st, n, b, q, dinv, r, p, s);
-    double h[6] = {0, 0, 0, 0, 0, 0};
-    CG_TRY(hipMemcpyAsync(h, s, sizeof h, hipMemcpyDeviceToHost, st));
-    CG_TRY(hipStreamSynchronize(st));
-    const double bb = h[S_BB] > 0 ? h[S_BB] : 1.0;
-    double rs = h[S_RR + 1];  // ||r||^2 (the preconditioned product r.z drives the recurrences, not the stop test)
+    std::vector<double> h((size_t)A_COUNT * kMaxGrid);
+    auto read_scalar = [&](int which) {  // fixed order, like the device
+        double t = 0.0;
+        for (int i = 0; i < grid; ++i) t += h[(size_t)which * kMaxGrid + i];
+        return t;
+    };
+    HIP_TRY(hipMemcpyAsync(h.data(), s, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const double bb0 = read_scalar(A_BB), bb = bb0 > 0 ? bb0 : 1.0;
+    double rs = read_scalar(A_RR);  // ||r||^2 (the preconditioned product r.z drives the recurrences, not the stop test)
+
+    auto enqueue_iteration = [&](int cur) -> int {
+        const int e = ehyb_spmv(P, p, q, stream);  // q = A p: x of the multiply changes every time
+        if (e != EHYB_OK) return e;
+        hipLaunchKernelGGL(cg_dot_kernel, dim3(grid), dim3(kThreads), 0, st, n, p, q, s);
+        hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kThreads), 0, st, n, p, q, dinv, x, r, s, cur);
+        hipLaunchKernelGGL(cg_direction_kernel, dim3(grid), dim3(kThreads), 0, st, n, r, dinv, p, s, cur);
+        return EHYB_OK;
+    };
+    // An even and an odd iteration, captured once and replayed: one submission per two iterations
+    // instead of eight or ten launches.  EHYB_CG_GRAPH=0 keeps the plain launches (A/B, debugging).
+    const char* genv = getenv("EHYB_CG_GRAPH");
+    if (!(genv && genv[0] == '0') && max_iter >= 2 &&
+        hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+        int erc = enqueue_iteration(0);
+        if (erc == EHYB_OK) erc = enqueue_iteration(1);
+        const hipError_t eend = hipStreamEndCapture(st, &W.graph);
+        if (erc != EHYB_OK || eend != hipSuccess ||
+            hipGraphInstantiate(&W.exec, W.graph, nullptr, nullptr, 0) != hipSuccess)
+            W.exec = nullptr;
+        (void)hipGetLastError();
+    }
     int it = 0;
     while (it < max_iter && std::sqrt(rs / bb) > rtol) {
-        const int burst = std::min(check_every, max_iter - it);
-        for (int k = 0; k < burst; ++k) {
-            if ((rc = ehyb_spmv(P, p, q, stream)) != EHYB_OK) {  // q = A p: x of the multiply changes every time
-                cleanup();
-                return rc;
+        const int burst = std::min(check_every, max_iter - it);  // even, except possibly the very last one
+        int k = 0;
+        for (; k + 2 <= burst; k += 2) {
+            if (W.exec) {
+                HIP_TRY(hipGraphLaunch(W.exec, st));
+            } else {
+                if ((rc = enqueue_iteration(0)) != EHYB_OK || (rc = enqueue_iteration(1)) != EHYB_OK) return rc;
             }
-            hipLaunchKernelGGL(cg_dot_kernel, dim3(grid), dim3(kThreads), 0, st, n, p, q, s);
-            hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kThreads), 0, st, n, p, q, dinv, x, r, s);
-            hipLaunchKernelGGL(cg_direction_kernel, dim3(grid), dim3(kThreads), 0, st, n, r, dinv, p, s);
-            hipLaunchKernelGGL(cg_roll_kernel, dim3(1), dim3(1), 0, st, s);
         }
+        if (k < burst && (rc = enqueue_iteration(0)) != EHYB_OK) return rc;
         it += burst;
-        CG_TRY(hipGetLastError());
-        CG_TRY(hipMemcpyAsync(h, s, sizeof h, hipMemcpyDeviceToHost, st));
-        CG_TRY(hipStreamSynchronize(st));
-        rs = h[S_RR + 1];
-        if (!(rs == rs) || !(h[S_RS] == h[S_RS])) {
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(h.data(), s, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
+        HIP_TRY(hipStreamSynchronize(st));
+        rs = read_scalar(A_RR);
+        const double rz = read_scalar(A_RZ0 + (burst & 1));
+        if (!(rs == rs) || !(rz == rz)) {
             rs = NAN;
             break;  // NaN: breakdown (matrix or preconditioner not positive definite)
         }
     }
-    cleanup();
     if (iters_done) *iters_done = it;
     if (rel_residual) *rel_residual = std::sqrt(rs / bb);
     if (!(rs == rs)) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_cg: breakdown (is the matrix symmetric positive definite?)");

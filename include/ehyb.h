@@ -303,10 +303,13 @@ int ehyb_measure_read_bw(size_t bytes, int iters, double* gbps);
  * both in the permuted numbering.  This is the solver the reference was cut down from (its
  * leftovers: kernelMyxpy y = x + gamma*y, kernel.cu:288-296; initialize_all, kernel.cu:20-31;
  * the PRECOND/FACT switches of cb_s) and the caller for which "x changes every multiply" matters.
- * One ehyb_spmv plus three fused vector kernels per iteration; scalars stay on the device, the
- * host looks at the residual every `check_every` iterations (<= 0: 10).
+ * One ehyb_spmv plus three fused vector kernels per iteration; dot products stay on the device
+ * (per-workgroup partial sums added in a fixed order, no atomics), two iterations are replayed
+ * from one hipGraph, and the host looks at the residual every `check_every` iterations (<= 0: 10;
+ * odd values are rounded up to even).
  * Stops when ||r|| <= rtol * ||b|| or after max_iter iterations.  Outputs may be NULL.
- * Needs a plan over all rows (single GPU).
+ * Needs a plan over all rows (single GPU).  stream NULL: a private stream, synchronised with the
+ * default stream on entry and finished on return.
  */
 int ehyb_cg(ehyb_plan* plan, const double* b_dev, double* x_dev, int max_iter, double rtol,
             int check_every, void* stream, int* iters_done, double* rel_residual);
