@@ -117,8 +117,18 @@ struct EllArgs {
     const double* __restrict__ x;
     double* __restrict__ y;
     int win_cap;
+    int xcd_map;  // 1: workgroup b takes item xcd_item(b), so that each XCD works on one contiguous run of items
     unsigned long long* __restrict__ stamps;
 };
+
+// Workgroups are handed to the 8 XCDs round robin (b mod 8).  With this map XCD k gets the k-th
+// contiguous eighth of the items: neighbouring partitions, whose halo columns are each other's
+// rows, then share one L2.
+__device__ __forceinline__ int xcd_item(int b, int n)
+{
+    const int k = b & 7, j = b >> 3, chunk = n >> 3, rem = n & 7;
+    return k * chunk + min(k, rem) + j;
+}
 
 // One entry of a slab: gather x from the window; SYM: bit 15 of the column says "this entry also
 // stands for its mirror image": value * x[own row] goes to row `column`'s accumulator in LDS.
@@ -246,7 +256,9 @@ __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict
     if (DYN && threadIdx.x == 0) *next_slab = sb + WAVES;  // slabs sb..sb+WAVES-1 are pre-assigned
     __syncthreads();
     // diagnostic launches only (tools/stamps.py): when the first window of the item was staged
-    if (A.stamps != nullptr && threadIdx.x == 0 && g == A.items[2 * blockIdx.x].x) A.stamps[4 * blockIdx.x + 1] = wall_clock64();
+    if (A.stamps != nullptr && threadIdx.x == 0 &&
+        g == A.items[2 * (A.xcd_map ? xcd_item(blockIdx.x, gridDim.x) : (int)blockIdx.x)].x)
+        A.stamps[4 * blockIdx.x + 1] = wall_clock64();
     int s = sb + wave;
     while (s < se) {
         ell_slab<INLINE_ER, SYM>(A, win, yacc, s, base, pe, lane);
@@ -274,7 +286,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(SYM ? 4
     extern __shared__ __attribute__((aligned(16))) double win[];
     int* next_slab = reinterpret_cast<int*>(win + A.win_cap);  // one word behind the window
     if (STAMP && threadIdx.x == 0) A.stamps[4 * blockIdx.x + 0] = wall_clock64();
-    const int4 it = A.items[2 * blockIdx.x];
+    const int4 it = A.items[2 * (A.xcd_map ? xcd_item(blockIdx.x, gridDim.x) : (int)blockIdx.x)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int sg = it.x; sg < it.y; ++sg) {
@@ -302,7 +314,7 @@ __global__ __launch_bounds__(THREADS) void ehyb_er_kernel(const int4* __restrict
                                                           const double* __restrict__ val,
                                                           const double* __restrict__ x, double* __restrict__ y)
 {
-    const int4 b = blocks[blockIdx.x];
+    const int4 b = blocks[blockIdx.x];  // (the XCD map of the ELL kernel was tried here: no difference on R-MAT)
     if (b.z == 64)
         er_bin<64, THREADS>(b.x, b.y, seg_ptr, seg_row, col, val, x, y);
     else if (b.z == 16)
@@ -342,6 +354,9 @@ static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long 
     A.y = y;
     A.win_cap = ell_win_cap(P->host);
     A.stamps = stamps;
+    // on by default: plain storage 143 -> 134 us on the audikw_1-like matrix; EHYB_XCD_MAP=0 for the A/B
+    static const int xcd_env = [] { const char* e = getenv("EHYB_XCD_MAP"); return e ? atoi(e) : 1; }();
+    A.xcd_map = xcd_env;
     return A;
 }
 
