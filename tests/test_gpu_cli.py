@@ -62,3 +62,16 @@ def test_cli_plan_cache_miss_then_hit(E, gpu, tmp_path):
     assert "plan cache hit" in p2.stdout and "reorder time is" not in p2.stdout and "PASSED" in p2.stdout
     p3 = _run(["-i", "5", "-g", "fem3d:30000:3:22:22:13400:1", "-c", cache], tmp_path)   # other matrix, same file
     assert p3.returncode == 0 and "plan cache miss" in p3.stdout and "another matrix" in p3.stdout and "PASSED" in p3.stdout
+
+
+@pytest.mark.parametrize("gen,items", [("fem3d:200000:3:40:40:13500:1", 700), ("rmat:15:300000", 13)],
+                         ids=["fem3d-many-items", "rmat-odd-items"])
+def test_cli_item_order_switch(gpu, tmp_path, gen, items):
+    """EHYB_XCD_MAP=0/1: workgroups take the work items in blockIdx order or one contiguous run per
+    XCD (the default).  Either way every item is taken exactly once -- including item counts that
+    are not a multiple of 8 -- so both runs pass the harness's comparison with the CPU product."""
+    for xcd in ("0", "1"):
+        env = dict(os.environ, EHYB_XCD_MAP=xcd, EHYB_ITEMS_PER_CU=str(max(1, items // 256)))
+        p = subprocess.run([BIN, "-i", "5", "-g", gen, "-l", "2048"], cwd=tmp_path, capture_output=True, text=True,
+                           timeout=600, env=env)
+        assert p.returncode == 0 and "PASSED" in p.stdout, (xcd, p.stdout[-1500:] + p.stderr[-1500:])
