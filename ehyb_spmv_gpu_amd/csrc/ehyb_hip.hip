@@ -272,6 +272,9 @@ __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict
     }
     if (SYM) {
         __syncthreads();  // all sums and scatters of the partition are in
+        // (Folding the pairs that straddle two partitions as well -- 13 % fewer bytes on the bench
+        // matrix -- would need y zeroed first and this write-out plus one add per halo column done
+        // with global atomics: that alone was measured at +12.5 us per launch, more than the bytes save.)
         for (int i = threadIdx.x + (ps & 1); i < cnt; i += THREADS) A.y[base + i] = yacc[i];
     }
 }
@@ -372,7 +375,7 @@ static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t
     const bool dyn = P->cfg.ell_variant != 3;
     const EllArgs A = ell_args(P, x, y, stamps);
     const bool sym = H.sym;
-#define ELL_GO(T, M, I, S)                                                                                   \
+#define ELL_GO(T, M, I, S)                                                                                  \
     {                                                                                                        \
         if (STAMP) HIP_TRY(hipFuncSetAttribute((const void*)ehyb_ell_kernel<T, M, STAMP, I, S>,              \
                                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));       \

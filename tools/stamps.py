@@ -61,8 +61,22 @@ def main():
     t0 = s[:, 0].min()
     start, staged, end, xcc = (s[:, 0] - t0) / 100.0, (s[:, 1] - t0) / 100.0, (s[:, 2] - t0) / 100.0, s[:, 3]
     items = plan.array("items").reshape(-1, 8)
+    if os.environ.get("EHYB_XCD_MAP", "1") != "0":  # workgroup b took item xcd_item(b) (ehyb_hip.hip)
+        b = np.arange(n_items)
+        k, j, chunk, rem = b & 7, b >> 3, n_items >> 3, n_items & 7
+        items = items[k * chunk + np.minimum(k, rem) + j]
     spp = plan.array("slab_pair_ptr").astype(np.int64)
     pairs = spp[items[:, 3]] - spp[items[:, 2]]
+    segs = plan.array("segs").reshape(-1, 8)
+    first = segs[items[:, 0]]  # first segment of every item: {part, slab range, halo count, row range, window, halo base}
+    rows, halo = (first[:, 5] - first[:, 4]).astype(np.int64), first[:, 3].astype(np.int64)
+    dur = end - start
+    A = np.stack([pairs, rows, halo, np.ones(n_items)], axis=1).astype(np.float64)
+    coef, *_ = np.linalg.lstsq(A, dur, rcond=None)
+    fit = A @ coef
+    print(f"duration ~ {coef[0] * 1e3:.2f} ns/pair-row + {coef[1] * 1e3:.2f} ns/row + {coef[2] * 1e3:.2f} ns/halo column + {coef[3]:.1f} us; "
+          f"residual rms {np.sqrt(np.mean((dur - fit) ** 2)):.2f} us; corr(duration, pairs) {np.corrcoef(dur, pairs)[0, 1]:.2f} "
+          f"rows {np.corrcoef(dur, rows)[0, 1]:.2f} halo {np.corrcoef(dur, halo)[0, 1]:.2f}")
     print(f"items {n_items}  kernel span {end.max():.1f} us")
     print(f"start   : min {start.min():.1f} med {np.median(start):.1f} max {start.max():.1f} us")
     print(f"staging : min {(staged - start).min():.1f} med {np.median(staged - start):.1f} max {(staged - start).max():.1f} us")
