@@ -75,6 +75,22 @@ def main():
     g = E.Matrix.generate("banded", 2048, 16, 1024, cfg=cfg)
     cuts = [2048 * r for r in range(world + 1)]
     bad += check_rank("block-diagonal", g.I + 2048 * rank, g.J + 2048 * rank, g.V.copy(), cuts, rank, world, cfg, symmetric=False)
+    # 4. fuzz: random matrices (tests/fuzz_cases.py) cut into ragged row ranges, random plan configurations
+    from fuzz_cases import random_config_kwargs, random_matrix
+
+    for seed in range(300, 308):
+        rng = np.random.default_rng(seed)            # the same stream on every rank
+        A = random_matrix(rng)
+        while A.shape[0] < 2 * world:
+            A = random_matrix(rng)
+        kw = random_config_kwargs(rng)
+        nA = A.shape[0]
+        inner = np.sort(rng.choice(np.arange(1, nA), size=world - 1, replace=False)) if world > 1 else np.zeros(0, int)
+        fcuts = [0] + [int(c) for c in inner] + [nA]
+        a, b = int(A.indptr[fcuts[rank]]), int(A.indptr[fcuts[rank + 1]])
+        rows = np.repeat(np.arange(nA, dtype=np.int32), np.diff(A.indptr))
+        bad += check_rank(f"fuzz-{seed}", rows[a:b].copy(), A.indices[a:b].astype(np.int32), A.data[a:b].copy(), fcuts, rank, world,
+                          E.make_config(**kw), symmetric=False)
     dist.barrier()
     if rank == 0:
         print("HALO_OK" if bad == 0 else f"HALO_FAIL {bad}", flush=True)
