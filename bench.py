@@ -40,6 +40,8 @@ WORKLOADS = {
     "rmat-24": ("rmat", (24, 1 << 27, 1), "config 5: R-MAT 2^24 rows, 2^27 edge samples"),
     "kkt3d-200": ("kkt3d", (200,), "config 4 stand-in: KKT-like saddle point system on a 200^3 grid"),
     "small": ("fem3d", (120000, 3, 35, 35, 13500, 1, 1), "reduced-size smoke workload (NOT a valid bench result)"),
+    "bcsstk17-like": ("fem3d", (10974, 3, 62, 59, 250000, 1, 17),
+                      "config 1's size (bcsstk17: 10,974 rows, ~430 k entries): the reference's small-matrix branch"),
     "rmat-22": ("rmat", (22, 1 << 25, 1), "R-MAT 2^22 rows, 2^25 edge samples (scaled config 5)"),
     "kkt3d-110": ("kkt3d", (110,), "KKT-like saddle point system on a 110^3 grid (scaled config 4)"),
 }
