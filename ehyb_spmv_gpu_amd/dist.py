@@ -274,3 +274,69 @@ class HaloSpmv:
     def y_local(self):
         """This rank's y segment in global label order (host array)."""
         return self.L.y_from_plan(self.y.cpu().numpy())
+
+
+class HaloCG:
+    """(Jacobi-)preconditioned conjugate gradients over the ranks of a HaloSpmv: the iterating caller
+    of the multi-GPU path ("iterating x <- y requires every GPU to obtain the other
+    segments" -- here the direction vector p is what travels, through the halo exchange inside
+    HaloSpmv.step).  Every rank holds its rows of x, r, p, q in plan order on its GPU; the three
+    dot products of an iteration are two all_reduce calls on device scalars ([p.q], then
+    [r.z, r.r]); the host reads the residual norm every `check_every` iterations only.
+    Same recurrences as the single-GPU ehyb_pcg (csrc/ehyb_cg.hip)."""
+
+    def __init__(self, halo_spmv, inv_diag_local=None):
+        import torch
+        import torch.distributed as dist
+
+        self.torch, self.dist = torch, dist
+        self.sh = halo_spmv
+        self.L = halo_spmv.L
+        self.dev = halo_spmv.x.device
+        self.dinv = None
+        if inv_diag_local is not None:
+            self.dinv = torch.from_numpy(self.L.x_to_plan(np.asarray(inv_diag_local, dtype=np.float64))).to(self.dev)
+
+    def _sum(self, t):
+        if self.L.world > 1:
+            self.dist.all_reduce(t, group=self.L.group)
+        return t
+
+    def solve(self, b_local, max_iter=1000, rtol=1e-10, check_every=10, x0_local=None):
+        """b_local, x0_local: this rank's segments in global label order (host arrays).
+        -> (x_local, iterations, relative residual)"""
+        torch, L, sh = self.torch, self.L, self.sh
+        n = L.n_loc
+        b = torch.from_numpy(L.x_to_plan(np.asarray(b_local, dtype=np.float64))).to(self.dev)
+        x = torch.zeros(n, dtype=torch.float64, device=self.dev)
+        if x0_local is not None:
+            x.copy_(torch.from_numpy(L.x_to_plan(np.asarray(x0_local, dtype=np.float64))))
+        apply_m = (lambda r: r * self.dinv) if self.dinv is not None else (lambda r: r)
+        sh.x[:n].copy_(x)
+        sh.step()                                   # q = A x0
+        r = b - sh.y
+        z = apply_m(r)
+        p = z.clone()
+        s = self._sum(torch.stack([torch.dot(r, z), torch.dot(r, r), torch.dot(b, b)]))
+        rz = s[0].clone()
+        bb = float(s[2].item()) or 1.0
+        rr = float(s[1].item())
+        it = 0
+        while it < max_iter and (rr / bb) ** 0.5 > rtol:
+            for _ in range(min(check_every, max_iter - it)):
+                sh.x[:n].copy_(p)
+                sh.step()                           # q = A p: halo exchange of p + two-phase multiply
+                q = sh.y
+                pq = self._sum(torch.dot(p, q).reshape(1))
+                alpha = rz / pq[0]
+                x.add_(p * alpha)
+                r.sub_(q * alpha)
+                z = apply_m(r)
+                s = self._sum(torch.stack([torch.dot(r, z), torch.dot(r, r)]))
+                p = z + p * (s[0] / rz)
+                rz = s[0].clone()
+                it += 1
+            rr = float(s[1].item())                 # the only host read in the loop
+            if rr != rr:
+                raise RuntimeError("HaloCG: breakdown (is the matrix symmetric positive definite?)")
+        return L.y_from_plan(x.cpu().numpy()), it, (rr / bb) ** 0.5

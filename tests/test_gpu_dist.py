@@ -43,3 +43,16 @@ def test_strong_allgather_three_ranks(gpu):
     out = _bench(3, ["--scaling", "strong"])
     assert out["n_gpus"] == 3 and out["scaling"] == "strong"
     assert out["parity"]["rows_over_1e-12"] == 0
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_halo_cg_ranks_on_one_gpu(gpu, world):
+    """HaloCG: conjugate gradients over the rank-local plans -- the direction vector travels through the
+    halo exchange, the dot products through all_reduce -- plain and Jacobi-preconditioned with
+    symmetric pair storage; checked by the true residual of the global system."""
+    env = dict(os.environ)
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "cg_worker.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "CG_OK" in p.stdout and p.stdout.count("CG_CASE") == 2, p.stdout[-2000:]
