@@ -146,3 +146,23 @@ def test_sizing(E):
     assert small[0] >= 1 and small[1] <= 20480
     with pytest.raises(E.EhybError):
         E.sizing(0)
+
+
+def test_partition_does_not_depend_on_the_thread_count(E):
+    """Large graphs are matched in parallel rounds of mutual proposals before the greedy pass, and
+    contracted in parallel: both are written so that the outcome is the same for any number of
+    threads (40,000 vertices: above the size where the parallel rounds start)."""
+    from threadpoolctl import threadpool_limits
+
+    A = grid_graph(250, 160)
+    n = A.shape[0]
+    cap = int(np.ceil(n / 48 * 1.03))
+    part_many, cut_many = E.partition_graph(A.indptr, A.indices, 48, cap)
+    with threadpool_limits(limits=1, user_api="openmp"):
+        part_one, cut_one = E.partition_graph(A.indptr, A.indices, 48, cap)
+    with threadpool_limits(limits=3, user_api="openmp"):
+        part_three, _ = E.partition_graph(A.indptr, A.indices, 48, cap)
+    assert np.array_equal(part_many, part_one) and np.array_equal(part_many, part_three) and cut_many == cut_one
+    assert np.bincount(part_many, minlength=48).max() <= cap
+    ideal = 4 * np.sqrt(n / 48) * 48 / 2
+    assert cut_many < 1.5 * ideal + 40, (cut_many, ideal)
