@@ -41,7 +41,10 @@ using namespace ehyb;
 
 namespace {
 
-constexpr int kThreads = 256;
+#ifndef EHYB_CG_THREADS
+#define EHYB_CG_THREADS 256
+#endif
+constexpr int kThreads = EHYB_CG_THREADS;
 constexpr int kMaxGrid = 1024;  // partial sums per dot product
 
 // partial arrays, kMaxGrid doubles each
@@ -182,7 +185,9 @@ extern "C" int ehyb_pcg(ehyb_plan* P, const double* dinv, const double* b, doubl
     HIP_TRY(hipMalloc((void**)&W.q, (size_t)n * 8));
     HIP_TRY(hipMalloc((void**)&W.s, (size_t)A_COUNT * kMaxGrid * sizeof(double)));
     double *r = W.r, *p = W.p, *q = W.q, *s = W.s;
-    const int grid = std::max(1, std::min((n + kThreads - 1) / kThreads, kMaxGrid));
+    // two workgroups per CU: 115.7 us per iteration on the audikw_1-like matrix against 118-120 with
+    // 1024 workgroups (twice the partials to re-add) and 126 with 256
+    const int grid = std::max(1, std::min((n + kThreads - 1) / kThreads, kMaxGrid / 2));
 
     int rc = ehyb_spmv(P, x, q, stream);  // q = A x0
     if (rc != EHYB_OK) return rc;
