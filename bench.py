@@ -48,6 +48,13 @@ WORKLOADS = {
 
 
 SYMMETRIC_GENERATORS = ("fem3d", "kkt3d", "stencil2d")  # A == A^T by construction (include/ehyb.h)
+SYM_MIN_ROWS = 32768  # EHYB_SYM_MIN_ROWS (include/ehyb.h): below it plain storage is faster
+
+
+def symmetric_storage_pays(gen, gargs):
+    """What `--sym-pairs auto` means: a symmetric generator and at least EHYB_SYM_MIN_ROWS rows."""
+    rows = {"kkt3d": lambda a: 2 * a[0] ** 3, "stencil2d": lambda a: a[0] * a[1]}.get(gen, lambda a: a[0])(gargs)
+    return gen in SYMMETRIC_GENERATORS and rows >= SYM_MIN_ROWS
 
 
 def timed_steps(step, args, torch, dist, world, dev):
@@ -205,7 +212,7 @@ def main():
     weak = world > 1 and args.scaling == "weak" and gen == "fem3d"
     # Symmetric pair storage for matrices that are symmetric (the reference reads such files with
     # matrixRead_sym, solver_test.c:127-265, and knows it too): an in-partition pair is stored once.
-    sym = args.sym_pairs == "on" or (args.sym_pairs == "auto" and gen in SYMMETRIC_GENERATORS)
+    sym = args.sym_pairs == "on" or (args.sym_pairs == "auto" and symmetric_storage_pays(gen, gargs))
     if sym:
         kw["sym_pairs"] = 1
     cfg = E.make_config(n_top=1 if weak else world, verbose=1 if (args.verbose and rank == 0) else 0, **kw)

@@ -61,8 +61,8 @@ static std::vector<long long> split_numbers(const char* s)
 static void usage()
 {
     printf("usage: solver_test -i <iters> (-m <name> | -g <spec>) [-w 1|2] [-l lds_doubles] [-T threads] [-c plan.cache] [-S 0|1] [-v]\n"
-           "  -S 0      no symmetric pair storage (default: on for symmetric matrices -- each in-partition pair\n"
-           "            a_ij == a_ji is stored once)\n"
+           "  -S 0|1    symmetric pair storage off / on (default: on for symmetric matrices of >= 32768 rows --\n"
+           "            each in-partition pair a_ij == a_ji is stored once)\n"
            "  -c file   plan cache: reuse the permutation + layout saved by an earlier run on the same matrix,\n"
            "            or write it (the reference repeats mt-metis + COO2EHYB on every run)\n"
            "  -m name   ./read/name.mtx (Matrix Market, general or symmetric)\n"
@@ -156,9 +156,11 @@ int main(int argc, char* argv[])
         return 1;
     }
     const int n = A.dimension;
-    // A symmetric matrix (MM banner, as solver_test.c:348-354 branches on it) gets symmetric pair
-    // storage unless -S 0; the partition sizing depends on that, so it is (re)done here.
-    if (symmetric && sym_opt != 0 && cfg.window_mode != EHYB_WINDOW_REFERENCE) cfg.sym_pairs = 1;
+    // A symmetric matrix (MM banner, as solver_test.c:348-354 branches on it) of at least
+    // EHYB_SYM_MIN_ROWS rows gets symmetric pair storage; -S 1 asks for it on smaller ones too, -S 0
+    // turns it off.  The partition sizing depends on the choice, so it is (re)done here.
+    if (symmetric && (sym_opt > 0 || (sym_opt < 0 && n >= EHYB_SYM_MIN_ROWS)) && cfg.window_mode != EHYB_WINDOW_REFERENCE)
+        cfg.sym_pairs = 1;
     ehyb_config_resolve(&cfg, &cfg);
     {
         int np = 1, cache_rows = 0, kpp = 1;

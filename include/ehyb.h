@@ -63,6 +63,12 @@ enum { EHYB_PART_AUTO = 0, EHYB_PART_CONTIGUOUS = 1, EHYB_PART_MULTILEVEL = 2, E
 #define EHYB_LDS_MAX_DOUBLES 20480   /* 160 KiB of LDS per workgroup on gfx950 */
 #define EHYB_SLAB_ROWS       64      /* one row per lane of a wave64           */
 
+/* Symmetric pair storage runs one workgroup per partition; below about 30,000 rows there are too
+ * few partitions to fill the 256 CUs and plain storage is faster (tools/sym_crossover.py, fem3d with
+ * 3 unknowns per node: 21,000 rows 9.7 vs 7.3 us, 42,000 rows 9.9 vs 11.0 us, 84,000 rows 13.6 vs 16.8 us).
+ * Callers that pick the storage from the matrix's symmetry (solver_test, bench.py) use this line. */
+#define EHYB_SYM_MIN_ROWS 32768
+
 /*
  * Tuning knobs.  They take the place of the reference's compile-time constants
  * (kernel.h:20-28: warpSize 32, smSize 82, maxSharedMem 93 KiB, threadELL 1024,
@@ -99,7 +105,8 @@ typedef struct ehyb_config {
                               partition sizes depend on it).  Results do not depend on the matrix being
                               symmetric (entries without an equal partner stay as they are), but the order
                               of the LDS adds varies from run to run (last-bit differences).
-                              1 = on -- what solver_test and bench.py choose for symmetric inputs; 0/2 = off */
+                              1 = on -- what solver_test and bench.py choose for symmetric inputs of at
+                              least EHYB_SYM_MIN_ROWS rows; 0/2 = off */
     int32_t reserved[6];
 } ehyb_config;
 

@@ -39,7 +39,7 @@ def main():
     build()
     lib = C.CDLL(LIB)
     gen, gargs, desc = B.WORKLOADS[args.workload]
-    sym = gen in B.SYMMETRIC_GENERATORS and not args.plain      # as bench.py: symmetric pair storage for symmetric inputs
+    sym = B.symmetric_storage_pays(gen, gargs) and not args.plain   # as bench.py: symmetric pair storage for symmetric inputs
     cfg = E.make_config(sym_pairs=1 if sym else 0)
     m = E.Matrix.generate(gen, *gargs, cfg=cfg)
     n, nnz = m.n, m.nnz
