@@ -64,7 +64,7 @@ def test_cli_plan_cache_miss_then_hit(E, gpu, tmp_path):
     assert p3.returncode == 0 and "plan cache miss" in p3.stdout and "another matrix" in p3.stdout and "PASSED" in p3.stdout
 
 
-@pytest.mark.parametrize("gen,items", [("fem3d:201000:3:40:40:13500:1", 700), ("rmat:15:300000", 13)],
+@pytest.mark.parametrize("gen,items", [("fem3d:99000:3:30:30:13500:1", 700), ("rmat:15:300000", 13)],
                          ids=["fem3d-many-items", "rmat-odd-items"])
 def test_cli_item_order_switch(gpu, tmp_path, gen, items):
     """EHYB_XCD_MAP=0/1: workgroups take the work items in blockIdx order or one contiguous run per
