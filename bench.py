@@ -239,6 +239,7 @@ def main():
         from oracle import oracle as O
 
         rowptr = m.row_idx.astype(np.int64)
+        O.set_threads(E.host_threads())  # the CPUs this process owns (cgroup quota), not the ones it sees
         t_coo, y_cpu = O.time_spmv(0, rowptr, m.I, m.J, m.V, x, reps=3)
         t_csr1, _ = O.time_spmv(1, rowptr, m.I, m.J, m.V, x, reps=3)
         t_omp, _ = O.time_spmv(2, rowptr, m.I, m.J, m.V, x, reps=5)

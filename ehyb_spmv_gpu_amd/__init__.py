@@ -17,6 +17,7 @@ from .host import (  # noqa: F401
     Matrix,
     Plan,
     device_count,
+    host_threads,
     make_config,
     partition_graph,
     sizing,

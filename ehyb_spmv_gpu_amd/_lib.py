@@ -89,6 +89,7 @@ SIGNATURES = {
     # ehyb.h
     "ehyb_last_error": (C.c_char_p, []),
     "ehyb_version": (C.c_char_p, []),
+    "ehyb_host_threads": (C.c_int, []),
     "ehyb_config_default": (None, [_cfgp]),
     "ehyb_config_resolve": (None, [_cfgp, _cfgp]),
     "ehyb_sizing": (C.c_int, [C.c_int, _cfgp, _ip, _ip, _ip]),

@@ -1,11 +1,47 @@
 // Error text, configuration defaults, the sizing heuristic and the small vector helpers.
 #include "ehyb_internal.h"
 
+#include <omp.h>
+#include <sched.h>
+
 #include <algorithm>
 #include <chrono>
 #include <cmath>
 
 namespace ehyb {
+
+// Threads for the host builder when the caller names none: what OpenMP would take, but no more than
+// the CPUs this process may really use -- its affinity mask and its cgroup CPU quota.  A container
+// that sees 128 hardware threads and owns 16 ran the pre-step of a 30,000-row matrix in 5.9 s on 128
+// OpenMP threads (spinning at every barrier of the multilevel partitioner) against 1 s on 8.
+int default_host_threads()
+{
+    static int cached = 0;
+    if (cached > 0) return cached;
+    long t = omp_get_max_threads();  // honours OMP_NUM_THREADS
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) t = std::min<long>(t, CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {  // cgroup v2: "<quota|max> <period>"
+        char quota[32];
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0)
+            t = std::min(t, std::max(1L, (atol(quota) + period - 1) / period));
+        fclose(f);
+    } else {  // cgroup v1
+        long quota = -1, period = 0;
+        if (FILE* q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) {
+            if (fscanf(q, "%ld", &quota) != 1) quota = -1;
+            fclose(q);
+        }
+        if (FILE* q = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) {
+            if (fscanf(q, "%ld", &period) != 1) period = 0;
+            fclose(q);
+        }
+        if (quota > 0 && period > 0) t = std::min(t, std::max(1L, (quota + period - 1) / period));
+    }
+    cached = (int)std::max(1L, t);
+    return cached;
+}
 
 static thread_local char g_err[512] = "";
 
@@ -23,6 +59,13 @@ double wall_seconds()
     using namespace std::chrono;
     return duration<double>(steady_clock::now().time_since_epoch()).count();
 }
+
+// Every OpenMP region of the library that runs before a configuration is seen (readers, generators,
+// the stand-alone partitioner call) starts from the same cap; set once when the library is loaded.
+static const int g_thread_cap_set = [] {
+    omp_set_num_threads(default_host_threads());
+    return 0;
+}();
 
 static int round_down(int v, int m) { return v / m * m; }
 
@@ -58,7 +101,7 @@ Config resolve_config(const ehyb_config* in)
     c.items_per_cu = z.items_per_cu > 0 ? z.items_per_cu : resident;
     c.partitioner = z.partitioner;
     c.er_seg_len = z.er_seg_len > 0 ? std::max(64, z.er_seg_len) : 4096;
-    c.host_threads = z.host_threads;
+    c.host_threads = z.host_threads > 0 ? z.host_threads : default_host_threads();
     c.verbose = z.verbose;
     c.seed = z.seed;
     c.er_threads = z.er_threads > 0 ? std::min(1024, std::max(64, round_down(z.er_threads, 64))) : 256;
@@ -84,6 +127,8 @@ using namespace ehyb;
 extern "C" {
 
 const char* ehyb_last_error(void) { return g_err; }
+int ehyb_host_threads(void) { return ehyb::default_host_threads(); }
+
 const char* ehyb_version(void) { return "ehyb-mi355x 0.1.0 gfx950"; }
 
 // Every "0 = default" field of *in replaced by the value the library will use, given the other

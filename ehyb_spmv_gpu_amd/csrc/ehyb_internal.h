@@ -118,6 +118,7 @@ int mtmetis_partition(int n, const int64_t* xadj, const int* adjncy, int nparts,
 
 // ---------------------------------------------------------------- misc
 double wall_seconds();
+int default_host_threads();  // OpenMP threads when cfg.host_threads is 0: capped by affinity and cgroup quota
 inline uint64_t splitmix64(uint64_t& s)
 {
     uint64_t z = (s += 0x9E3779B97F4A7C15ull);

@@ -348,7 +348,7 @@ int ehyb_gen_fem3d_block(int n, int dof, int nx, int ny, int extra_ppm, int scra
         EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_fem3d: need n %% dof == 0 and positive grid sizes");
     if (n_blocks < 1 || block < 0 || block >= n_blocks || (int64_t)n * n_blocks > 0x7FFFFFFFll)
         EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_fem3d_block: block %d of %d, %d rows each", block, n_blocks, n);
-    if (cfg && cfg->host_threads > 0) omp_set_num_threads(cfg->host_threads);
+    omp_set_num_threads(cfg && cfg->host_threads > 0 ? cfg->host_threads : default_host_threads());
     const int N = n / dof;
     const int64_t layer = (int64_t)nx * ny;
     const int nz = (int)((N + layer - 1) / layer);

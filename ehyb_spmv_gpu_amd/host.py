@@ -375,6 +375,11 @@ def spmv_gpu_ehyb(matrix, vector_in, max_iter):
     return y, it.value
 
 
+def host_threads():
+    """ehyb_host_threads: OpenMP threads of the host builder = the CPUs the process owns (affinity, cgroup quota)."""
+    return int(_lib.load().ehyb_host_threads())
+
+
 def device_count():
     c = C.c_int(0)
     _lib.load().ehyb_device_count(C.byref(c))

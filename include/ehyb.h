@@ -69,6 +69,10 @@ enum { EHYB_PART_AUTO = 0, EHYB_PART_CONTIGUOUS = 1, EHYB_PART_MULTILEVEL = 2, E
  * Callers that pick the storage from the matrix's symmetry (solver_test, bench.py) use this line. */
 #define EHYB_SYM_MIN_ROWS 32768
 
+/* OpenMP threads the host builder uses when cfg.host_threads is 0: what OpenMP would take, capped by
+ * the CPUs the process may really use (affinity mask, cgroup CPU quota). */
+int ehyb_host_threads(void);
+
 /*
  * Tuning knobs.  They take the place of the reference's compile-time constants
  * (kernel.h:20-28: warpSize 32, smSize 82, maxSharedMem 93 KiB, threadELL 1024,

@@ -89,6 +89,16 @@ int oracle_max_threads(void)
 #endif
 }
 
+/* the CPU baseline runs on the cores the process really owns (a container may see many more) */
+void oracle_set_threads(int n)
+{
+#ifdef _OPENMP
+    if (n > 0) omp_set_num_threads(n);
+#else
+    (void)n;
+#endif
+}
+
 /* sum_j |a_ij * x_j| per row: the scale of the stated tolerance
  * |y_gpu - y_cpu| <= 1e-12 * sum_j |a_ij x_j|  (BASELINE.md section 4). */
 void oracle_abs_rowsum(int64_t nnz, const int* I, const int* J, const double* V, const double* x, double* s)

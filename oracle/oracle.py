@@ -142,6 +142,11 @@ def max_threads():
     return int(lib().oracle_max_threads())
 
 
+def set_threads(n):
+    """OpenMP threads of the timed CSR product (bench.py: the CPUs the process owns, not the ones it sees)."""
+    lib().oracle_set_threads(int(n))
+
+
 # --------------------------------------------------------------------------------------
 # CPU walk of the MI355X layout (include/ehyb.h EHYB_ARR_*), indexing the arrays exactly as
 # ehyb_ell_kernel / ehyb_er_kernel do.  Checks the host builder without a GPU.
