@@ -51,6 +51,24 @@ SYMMETRIC_GENERATORS = ("fem3d", "kkt3d", "stencil2d")  # A == A^T by constructi
 SYM_MIN_ROWS = 32768  # EHYB_SYM_MIN_ROWS (include/ehyb.h): below it plain storage is faster
 
 
+def owned_cpus():
+    """CPUs this job may really use: the affinity mask, capped by the cgroup CPU quota (v2, then v1)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, -(-int(quota) // int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open("/sys/fs/cgroup/cpu/cpu.cfs_quota_us").read())
+            period = int(open("/sys/fs/cgroup/cpu/cpu.cfs_period_us").read())
+            if quota > 0 and period > 0:
+                n = min(n, max(1, -(-quota // period)))
+        except (OSError, ValueError):
+            pass
+    return max(1, n)
+
+
 def symmetric_storage_pays(gen, gargs):
     """What `--sym-pairs auto` means: a symmetric generator and at least EHYB_SYM_MIN_ROWS rows."""
     rows = {"kkt3d": lambda a: 2 * a[0] ** 3, "stencil2d": lambda a: a[0] * a[1]}.get(gen, lambda a: a[0])(gargs)
@@ -206,8 +224,9 @@ def main():
             kw[k] = v
     if world > 1 and os.environ.get("OMP_NUM_THREADS") == "1":
         # torch.distributed.run pins every rank to one OpenMP thread; the host pre-step (partitioner,
-        # layout builder) of each rank gets its share of the node's cores instead
-        kw["host_threads"] = max(1, (os.cpu_count() or world) // world)
+        # layout builder) of each rank gets its share of the CPUs the job owns instead (affinity mask and
+        # cgroup quota -- a container may see many more hardware threads than it may use)
+        kw["host_threads"] = max(1, owned_cpus() // world)
     gen, gargs, desc = WORKLOADS[args.workload]
     weak = world > 1 and args.scaling == "weak" and gen == "fem3d"
     # Symmetric pair storage for matrices that are symmetric (the reference reads such files with
