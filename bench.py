@@ -3,27 +3,41 @@
 
     python bench.py --gpus N --steps K --warmup W
 
-A "step" is one SpMV of the whole matrix: y = A x through libehyb.so's HIP kernels (N = 1),
-or, for N > 1, one exchange of x entries over RCCL plus each rank's local multiply:
-  --scaling weak (default)  the N = 1 matrix once per GPU: N such grids stacked along z, rank r
-                            generates, partitions and uploads block r only; per step a halo exchange
-                            (all_to_all of the x entries next to the block boundaries) overlapped
-                            with the ELL phase, then the residual phase on the received entries;
-  --scaling strong          the N = 1 matrix sharded by rows (two-level partition), all-gatherv of x.
+A "step" is one SpMV of the whole matrix, y = A x, through libehyb.so's HIP kernels.
 
-Workload at N = 1 (per GPU at N > 1): BASELINE.json configs[1], audikw_1 -- as a
-statistically matched synthetic, because no .mtx file exists offline: 943,695 rows, 3 unknowns
-per node of a 68x68x69 grid truncated to 314,565 nodes, 27-point node coupling plus hashed
-second-shell couplings tuned to audikw_1's 77.65 M entries (82.3 per row), node labels
-scrambled so that locality has to come from the partitioner.  `data` says so.
+N = 1  workload = BASELINE.json configs[1], audikw_1 -- as a statistically matched synthetic, because
+       no .mtx file exists offline: 943,695 rows, 3 unknowns per node of a 68x68x69 grid truncated to
+       314,565 nodes, 27-point node coupling plus hashed second-shell couplings tuned to audikw_1's
+       77.65 M entries (82.3 per row), node labels scrambled so that locality has to come from the
+       partitioner.  `data` says so.  The same line also carries
+         plain_storage   the same matrix with every entry stored (no symmetric pair storage),
+         dropin_path     the same matrix through the reference-named calls with the reference driver's
+                         own sizing (matrixReorder -> vectorReorder -> spmvGPuEHYB -> vectorRecover),
+         scaling_anchor  the N > 1 default workload (R-MAT 2^24, config 5) on this one GPU, i.e. the
+                         N = 1 point of the strong-scaling curve.
+N > 1  one process per GPU (the driver launches them with torch.distributed.run; invoked plainly,
+       `python bench.py --gpus N` starts them itself as a child process before anything touches a GPU).
+         --scaling strong (default)  ONE matrix (default: config 5, R-MAT 2^24 rows / 2^27 samples)
+               sharded by rows over the GPUs: two-level partition (nnz-balanced row blocks, then
+               window-sized partitions inside each), per-GPU y segments, and every step an exchange of x
+               over RCCL/xGMI: --exchange halo (default) = only the entries a GPU's rows reference, one
+               all_to_all_single; --exchange allgather = every segment to everyone, padded to equal
+               length, one all_gather_into_tensor.  Phase 1 (LDS-fed ELL part, local columns only)
+               overlaps the exchange.
+         --scaling weak             the N = 1 matrix once per GPU (fem3d workloads), rank-local build,
+               halo exchange.
 
 Output: ONE JSON line on rank 0 with the contract's keys plus
-  roofline      algorithmic bytes of the dominant kernel / its mean launch time (HIP events)
+  roofline      the dominant kernel: real bytes (PMC traffic if profiles/pmc_traffic.json holds a
+                measurement of this workload, storage and kernel, else the format's bytes) / its mean launch
+                time (HIP events) / 8 TB/s; the algorithmic-byte rate beside it as alg_frac
   cpu_baseline  the CPU oracle (a port of the reference's CPU product) timed on this host.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -33,7 +47,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X data-sheet peak (MI355X_MICROARCH.md: 8.0 TB/s spec, ~6.3 achievable)
 
 WORKLOADS = {
-    # name: (generator, args, symmetric, description)
+    # name: (generator, args, description)
     "audikw_1-like": ("fem3d", (943695, 3, 68, 68, 13500, 1, 1),
                       "synthetic stand-in for audikw_1: 943,695 rows, ~77.7 M entries, 3 dof/node FEM-like, scrambled labels"),
     "banded-4M": ("banded", (1 << 22, 32, 1024), "config 3: block-circulant band, 4,194,304 rows x 32 entries, zero residual"),
@@ -43,12 +57,16 @@ WORKLOADS = {
     "bcsstk17-like": ("fem3d", (10974, 3, 62, 59, 250000, 1, 17),
                       "config 1's size (bcsstk17: 10,974 rows, ~430 k entries): the reference's small-matrix branch"),
     "rmat-22": ("rmat", (22, 1 << 25, 1), "R-MAT 2^22 rows, 2^25 edge samples (scaled config 5)"),
+    "rmat-18": ("rmat", (18, 1 << 21, 1), "R-MAT 2^18 rows, 2^21 edge samples (functional tests of the N > 1 path)"),
     "kkt3d-110": ("kkt3d", (110,), "KKT-like saddle point system on a 110^3 grid (scaled config 4)"),
 }
-
+# the reference driver's own sizing for audikw_1 (solver_test.c:158-182 with n = 943,695): what a
+# drop-in caller hands to matrixReorder / spmvGPuEHYB
+REFERENCE_SIZING = {"audikw_1-like": (164, 6144, 0)}
 
 SYMMETRIC_GENERATORS = ("fem3d", "kkt3d", "stencil2d")  # A == A^T by construction (include/ehyb.h)
 SYM_MIN_ROWS = 32768  # EHYB_SYM_MIN_ROWS (include/ehyb.h): below it plain storage is faster
+PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 
 def owned_cpus():
@@ -75,6 +93,31 @@ def symmetric_storage_pays(gen, gargs):
     return gen in SYMMETRIC_GENERATORS and rows >= SYM_MIN_ROWS
 
 
+def pmc_traffic(workload, sym, kernel):
+    """HBM bytes per launch measured with rocprofv3 --pmc for exactly this workload, storage and kernel
+    (tools/pmc_parse.py writes the table), or None."""
+    try:
+        tab = json.load(open(PMC_FILE))
+    except (OSError, ValueError):
+        return None
+    e = tab.get("entries", {}).get(f"{workload}|{'sym' if sym else 'plain'}|{kernel}")
+    return None if not e else e.get("hbm_bytes_per_launch")
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` invoked plainly: start the N ranks as a CHILD process
+    (torch.distributed.run) before this process has touched a GPU, relay rank 0's JSON line."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    p = subprocess.run(cmd, env=env)
+    raise SystemExit(p.returncode)
+
+
 def timed_steps(step, args, torch, dist, world, dev):
     """W untimed steps, then exactly K steps between barrier + synchronize; max over ranks."""
     for _ in range(args.warmup):
@@ -98,12 +141,32 @@ def timed_steps(step, args, torch, dist, world, dev):
     return elapsed
 
 
+def all_ranks_agree_or_exit(bad, worst, torch, dist, world, dev, what):
+    """Every rank learns the parity verdict of every other and all leave together."""
+    if world > 1:
+        t = torch.tensor([float(bad)], dtype=torch.float64, device=dev)
+        w = torch.tensor([float(worst)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        dist.all_reduce(w, op=dist.ReduceOp.MAX)
+        bad, worst = int(t.item()), float(w.item())
+    if bad:
+        if world > 1:
+            dist.destroy_process_group()
+        raise SystemExit(f"bench.py: {what}: GPU result differs from the CPU oracle in {bad} rows (worst {worst:.3e}); refusing to report a number")
+    return bad, worst
+
+
+def partitioner_for(E, gen):
+    """R-MAT has no locality for a graph partitioner to find (2^24 rows: 124 M of 133 M edges cut after
+    110 s of multilevel k-way); EHYB_PART_AUTO notices that itself after one coarsening attempt, naming
+    the contiguous partitioner up front saves even that."""
+    return E.EHYB_PART_CONTIGUOUS if gen == "rmat" else E.EHYB_PART_AUTO
+
+
 def run_weak(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     """N > 1, weak scaling: the N = 1 matrix once per GPU -- N audikw_1-like grids stacked along z,
     rank r owning (and generating) block r only -- and a halo exchange of the x entries of the two
     grid layers next to each block boundary.  Per-GPU work is the N = 1 workload plus ~1 % coupling."""
-    import numpy as np
-
     from ehyb_spmv_gpu_amd import dist as D
     from oracle import oracle as O
 
@@ -132,14 +195,13 @@ def run_weak(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     elapsed = timed_steps(sh.step, args, torch, dist, world, dev)
     # parity of what was just timed, every rank on its own rows
     bad, worst = O.check_tolerance(sh.y_local(), y_cpu, scale)
-    tot = torch.tensor([float(bad), float(len(V)), float(L.n_ghost)], dtype=torch.float64, device=dev)
-    mx = torch.tensor([float(worst), float(L.n_ghost)], dtype=torch.float64, device=dev)
+    bad, worst = all_ranks_agree_or_exit(bad, worst, torch, dist, world, dev, "weak scaling")
+    tot = torch.tensor([float(len(V)), float(L.n_ghost)], dtype=torch.float64, device=dev)
+    mx = torch.tensor([float(L.n_ghost)], dtype=torch.float64, device=dev)
     dist.all_reduce(tot)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
-    bad, nnz, worst = int(tot[0].item()), int(tot[1].item()), float(mx[0].item())
+    nnz = int(tot[0].item())
     log(f"[bench] parity vs CPU oracle (all ranks, own rows): {bad} rows over 1e-12, worst {worst:.3e}")
-    if bad:
-        raise SystemExit("bench.py: GPU result differs from the CPU oracle; refusing to report a number")
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         out = {
@@ -152,7 +214,7 @@ def run_weak(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
                        "lds_doubles": int(cfg.lds_doubles), "part_rows": int(cfg.part_rows), "threads": int(cfg.threads),
                        "window_mode": "halo" if cfg.window_mode != 1 else "reference",
                        "sym_pairs_rank0": st["sym_pairs"], "stored_values_rank0": st["size_block_ell"],
-                       "ghost_slots_per_gpu_max": int(mx[1].item()), "ghost_slots_total": int(tot[2].item()),
+                       "ghost_slots_per_gpu_max": int(mx[0].item()), "ghost_slots_total": int(tot[1].item()),
                        "exchange": "halo: gather of the requested x entries + RCCL all_to_all_single into the ghost slots, "
                                    "overlapped with the ELL phase" if not stage_on_cpu else "halo via gloo point-to-point (functional mode)"},
             "alg_GBps": round((12 * nnz + 4 * (n_glob + 1) + 16 * n_glob) / (elapsed / args.steps) / 1e9, 1),
@@ -161,40 +223,202 @@ def run_weak(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
         print(json.dumps(out), flush=True)
 
 
+def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
+    """N > 1, strong scaling (BASELINE config 5): ONE matrix sharded by rows.  Every rank
+    generates the matrix (deterministic generators; a real deployment reads its rows from a file),
+    keeps rows [r0, r1) of the nnz-balanced row blocks, builds its plan from them alone and exchanges x
+    every step: `--exchange allgather` = the x segments, padded to equal length, through one RCCL
+    all_gather_into_tensor (what north_star names); `--exchange halo` = only the entries the rank's
+    rows reference, through one all_to_all_single.  The ELL phase (local columns) overlaps either."""
+    import numpy as np
+
+    from ehyb_spmv_gpu_amd import dist as D
+    from oracle import oracle as O
+
+    gen, gargs, desc = WORKLOADS[args.workload]
+    t0 = time.time()
+    m = E.Matrix.generate(gen, *gargs, cfg=cfg)
+    n, nnz = m.n, m.nnz
+    log(f"[bench] every rank generated {args.workload}: n={n} nnz={nnz} in {time.time() - t0:.1f}s")
+    rowptr = m.row_idx.astype(np.int64)
+    cuts = D.balanced_row_cuts(rowptr, world)
+    r0, r1 = cuts[rank], cuts[rank + 1]
+    k0, k1 = int(rowptr[r0]), int(rowptr[r1])
+    I, J, V = m.I[k0:k1].copy(), m.J[k0:k1].copy(), m.V[k0:k1].copy()
+    symmetric = gen in SYMMETRIC_GENERATORS
+    m.free()
+    x = E.x_glibc(n)
+    y_cpu = O.spmv_coo(n, I, J, V, x)[r0:r1]      # checker (not timed): the oracle on this rank's rows
+    scale = O.abs_rowsum(n, I, J, V, x)[r0:r1]
+    t0 = time.time()
+    L = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, symmetric=symmetric, exchange=args.exchange)
+    del I, J
+    if args.exchange == "halo":
+        sh = D.HaloSpmv(L, dev, overlap=not args.no_overlap, stage_on_cpu=stage_on_cpu)
+    else:
+        sh = D.GatherSpmv(L, dev, overlap=not args.no_overlap, stage_on_cpu=stage_on_cpu)
+    sh.set_x_local(x[r0:r1])
+    st = sh.plan.stats
+    log(f"[bench] rank 0: rows [{r0},{r1}) reorder + plan in {time.time() - t0:.1f}s: ell {st['nnz_ell']} residual {st['nnz_er']} "
+        f"ghost columns {L.n_ghost} of {n - (r1 - r0)} remote")
+    elapsed = timed_steps(sh.step, args, torch, dist, world, dev)
+    bad, worst = O.check_tolerance(sh.y_local(), y_cpu, scale)
+    bad, worst = all_ranks_agree_or_exit(bad, worst, torch, dist, world, dev, "strong scaling")
+    # per-rank time of the local multiply alone (no exchange), max over ranks: what is left is the exchange
+    sh_local_ms = sh.time_local(args.steps)
+    stats = torch.tensor([float(L.n_ghost), float(sh_local_ms), float(len(V))], dtype=torch.float64, device=dev)
+    mx = stats.clone()
+    dist.all_reduce(stats)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    log(f"[bench] parity vs CPU oracle (all ranks, own rows): {bad} rows over 1e-12, worst {worst:.3e}")
+    if rank == 0:
+        ms = elapsed / args.steps * 1e3
+        words = int(stats[0].item()) if args.exchange == "halo" else sh.seg_len * world * (world - 1)
+        out = {
+            "metric": "fp64 SpMV GFLOP/s (2*nnz/t_iter), EHYB on MI355X",
+            "value": round(2.0 * nnz * args.steps / elapsed / 1e9, 2), "unit": "GFLOP/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms, 5), "higher_is_better": True,
+            "scaling": "strong", "vs_baseline": None, "dtype": "f64", "data": "synthetic: " + desc,
+            "config": {"workload": args.workload, "rows": n, "nnz": nnz, "rows_per_gpu_max": max(cuts[i + 1] - cuts[i] for i in range(world)),
+                       "nnz_per_gpu_max": int(mx[2].item()),
+                       "lds_doubles": int(cfg.lds_doubles), "part_rows": int(cfg.part_rows), "threads": int(cfg.threads),
+                       "exchange": ("RCCL all_gather_into_tensor of the x segments (padded to %d doubles each), overlapped with the ELL phase" % sh.seg_len)
+                       if args.exchange == "allgather" else
+                       "halo: gather of the requested x entries + RCCL all_to_all_single into the ghost slots, overlapped with the ELL phase",
+                       "exchange_doubles_received_all_gpus": words,
+                       "ghost_columns_per_gpu_max": int(mx[0].item()),
+                       "functional_mode": "gloo, host-staged" if stage_on_cpu else None},
+            "local_multiply_ms_max_over_ranks": round(float(mx[1].item()), 5),
+            "n1_equivalent": "the N = 1 line's scaling_anchor (same matrix, one GPU)",
+            "alg_GBps": round((12 * nnz + 4 * (n + 1) + 16 * n) / (elapsed / args.steps) / 1e9, 1),
+            "roofline": None, "cpu_baseline": None, "parity": {"rows_over_1e-12": bad, "worst_rel": worst},
+        }
+        print(json.dumps(out), flush=True)
+
+
+def one_gpu_case(E, O, np, workload, sym, kw, steps, warmup, log, want_parity=True, y_cpu=None, scale=None, x=None):
+    """Generate -> reorder -> plan -> timed loop of `workload` on the current GPU through the plan API.
+    -> dict with value, ms_per_step, kernel times, stats, parity."""
+    gen, gargs, _ = WORKLOADS[workload]
+    kw = dict(kw)
+    kw.pop("sym_pairs", None)
+    if sym:
+        kw["sym_pairs"] = 1
+    cfg = E.make_config(partitioner=partitioner_for(E, gen), **kw)
+    t0 = time.time()
+    m = E.Matrix.generate(gen, *gargs, cfg=cfg)
+    n, nnz = m.n, m.nnz
+    if x is None:
+        x = E.x_glibc(n)
+    if want_parity and y_cpu is None:
+        y_cpu = O.spmv_coo(n, m.I, m.J, m.V, x)
+        scale = O.abs_rowsum(n, m.I, m.J, m.V, x)
+    m.reorder(cfg)
+    plan = E.Plan(m, cfg)
+    t_pre = time.time() - t0
+    xd = E.DeviceBuffer(n).upload(E.vector_reorder(x, m.reorder_list))
+    yd = E.DeviceBuffer(n)
+    r = plan.bench(xd.ptr, yd.ptr, warmup=warmup, iters=steps)
+    st = plan.stats
+    ms = r["ms_total"] / steps
+    out = {"value": round(2.0 * nnz / ms / 1e6, 2), "unit": "GFLOP/s", "ms_per_step": round(ms, 5), "rows": n, "nnz": nnz,
+           "ell_kernel_avg_launch_ms": round(r["ms_ell_avg"], 5),
+           "er_kernel_avg_launch_ms": round(r["ms_er_avg"], 5) if (st["nnz_er"] and not st["er_inline"]) else None,
+           "nnz_ell": st["nnz_ell"], "nnz_er": st["nnz_er"], "stored_values": st["size_block_ell"],
+           "format_bytes_per_spmv": st["bytes_format"], "alg_bytes_per_spmv": st["bytes_alg"],
+           "real_frac_of_8TBps": round(st["bytes_format"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+           "alg_frac_of_8TBps": round(st["bytes_alg"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+           "pre_step_s": round(t_pre, 1)}
+    if want_parity:
+        bad, worst = O.check_tolerance(E.vector_recover(yd.download(), m.reorder_list), y_cpu, scale)
+        out["parity"] = {"rows_over_1e-12": bad, "worst_rel": worst}
+        if bad:
+            raise SystemExit(f"bench.py: {workload} ({'symmetric pairs' if sym else 'every entry'}): result differs from the CPU oracle")
+    plan.destroy()
+    xd.free()
+    yd.free()
+    m.free()
+    return out
+
+
+def dropin_case(E, O, np, workload, x, y_cpu, scale, steps, log):
+    """The same matrix through the reference-named calls, with the reference driver's own sizing:
+    matrixReorder(&m) -> vectorReorder -> spmvGPuEHYB(&m, x, y, steps, &it) -> vectorRecover."""
+    gen, gargs, _ = WORKLOADS[workload]
+    m = E.Matrix.generate(gen, *gargs)
+    m.c.nParts, m.c.vectorCacheSize, m.c.kernelPerPart = REFERENCE_SIZING[workload]
+    hints = (int(m.c.nParts), int(m.c.vectorCacheSize))
+    t0 = time.time()
+    m.reorder_dropin()
+    t_re = time.time() - t0
+    perm = m.reorder_list.copy()
+    # spmvGPuEHYB prints its two lines (spmv.cu:82,121) on stdout, which belongs to the JSON line here
+    sys.stdout.flush()
+    keep = os.dup(1)
+    os.dup2(2, 1)
+    try:
+        y, it, ms = E.spmv_gpu_ehyb(m, E.vector_reorder(x, perm), steps, timing=True)
+    finally:
+        sys.stdout.flush()
+        os.dup2(keep, 1)
+        os.close(keep)
+    bad, worst = O.check_tolerance(E.vector_recover(y, perm), y_cpu, scale)
+    if bad:
+        raise SystemExit("bench.py: drop-in path: result differs from the CPU oracle")
+    out = {"value": round(2.0 * m.nnz * it / (ms * 1e6), 2), "unit": "GFLOP/s", "ms_per_step": round(ms / it, 5),
+           "calls": "matrixReorder -> vectorReorder -> spmvGPuEHYB -> vectorRecover (include/reordering.h, include/spmv.h), no configuration",
+           "caller_sizing_hints": {"nParts": hints[0], "vectorCacheSize": hints[1], "from": "solver_test.c:158-182 for audikw_1"},
+           "nParts_used": int(m.c.nParts), "reorder_s": round(t_re, 1), "parity": {"rows_over_1e-12": bad, "worst_rel": worst}}
+    m.free()
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
-    ap.add_argument("--workload", default="audikw_1-like", choices=sorted(WORKLOADS))
+    ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
+                    help="default: audikw_1-like at N = 1 (BASELINE config 2) and for --scaling weak, rmat-24 (config 5) for N > 1")
     ap.add_argument("--lds-doubles", type=int, default=0)
     ap.add_argument("--part-rows", type=int, default=0)
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--items-per-cu", type=int, default=0)
     ap.add_argument("--window-mode", type=int, default=0)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the TIMED CPU legs (the parity check stays)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange first, then multiply (no stream overlap)")
     ap.add_argument("--no-plain-arm", action="store_true",
                     help="N=1 with symmetric pair storage: skip the extra plain-storage measurement of the same matrix")
+    ap.add_argument("--no-dropin-arm", action="store_true", help="N=1: skip the run through the reference-named calls")
+    ap.add_argument("--no-scaling-anchor", action="store_true", help="N=1: skip the one-GPU run of the N>1 default workload")
+    ap.add_argument("--vendor-baseline", action="store_true", help="N=1: also time rocSPARSE CSR SpMV on the same matrix (opt-in)")
     ap.add_argument("--sym-pairs", default="auto", choices=["auto", "on", "off"],
                     help="symmetric pair storage (cfg.sym_pairs): auto = on for the symmetric workloads")
-    ap.add_argument("--scaling", default="weak", choices=["weak", "strong"],
-                    help="N>1: weak = the N=1 matrix once per GPU, rank-local build, halo exchange (fem3d workloads); "
-                         "strong = the N=1 matrix sharded by rows, all-gatherv of x")
+    ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
+                    help="N>1: strong = ONE matrix sharded by rows (default workload rmat-24, config 5); "
+                         "weak = the N=1 matrix once per GPU, rank-local build, halo exchange (fem3d workloads)")
+    ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
+                    help="N>1 strong: halo = only the x entries a rank's rows reference (one all_to_all_single); "
+                         "allgather = every x segment to everyone, padded to equal length (one all_gather_into_tensor)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
+
+    world_env = os.environ.get("WORLD_SIZE")
+    if args.gpus > 1 and world_env is None:
+        self_launch(args)  # does not return
+    world = int(world_env or "1")
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node equal to --gpus")
+    if args.workload is None:
+        args.workload = "audikw_1-like" if (world == 1 or args.scaling == "weak") else "rmat-24"
 
     import numpy as np
     import torch
 
     import ehyb_spmv_gpu_amd as E
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with torch.distributed.run --nproc-per-node N for --gpus N > 1")
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the EHYB multiply has no CPU fallback")
     # EHYB_BENCH_ONE_DEVICE=1 + EHYB_BENCH_BACKEND=gloo: all ranks on cuda:0 over gloo -- a functional
@@ -204,12 +428,13 @@ def main():
     if one_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
     dist = None
     if world > 1:
         import torch.distributed as dist
 
         if backend == "nccl":
-            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+            dist.init_process_group("nccl", device_id=dev)
         else:
             dist.init_process_group(backend)
 
@@ -228,35 +453,40 @@ def main():
         # cgroup quota -- a container may see many more hardware threads than it may use)
         kw["host_threads"] = max(1, owned_cpus() // world)
     gen, gargs, desc = WORKLOADS[args.workload]
-    weak = world > 1 and args.scaling == "weak" and gen == "fem3d"
     # Symmetric pair storage for matrices that are symmetric (the reference reads such files with
     # matrixRead_sym, solver_test.c:127-265, and knows it too): an in-partition pair is stored once.
     sym = args.sym_pairs == "on" or (args.sym_pairs == "auto" and symmetric_storage_pays(gen, gargs))
-    if sym:
-        kw["sym_pairs"] = 1
-    cfg = E.make_config(n_top=1 if weak else world, verbose=1 if (args.verbose and rank == 0) else 0, **kw)
 
-    if weak:  # every rank partitions its own block
-        run_weak(args, E, torch, dist, rank, world, torch.device("cuda", local_rank), cfg, log, stage_on_cpu=backend != "nccl")
+    if world > 1:
+        if sym:
+            kw["sym_pairs"] = 1
+        cfg = E.make_config(partitioner=partitioner_for(E, gen), verbose=1 if (args.verbose and rank == 0) else 0, **kw)
+        if args.scaling == "weak":
+            if gen != "fem3d":
+                raise SystemExit("bench.py: --scaling weak stacks fem3d grids; use --scaling strong for " + args.workload)
+            run_weak(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu=backend != "nccl")
+        else:
+            run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu=backend != "nccl")
         dist.destroy_process_group()
         return
+
+    # ================================================================== N = 1
+    from oracle import oracle as O
+
+    if sym:
+        kw["sym_pairs"] = 1
+    cfg = E.make_config(partitioner=partitioner_for(E, gen), verbose=1 if args.verbose else 0, **kw)
     t0 = time.time()
     m = E.Matrix.generate(gen, *gargs, cfg=cfg)
     n, nnz = m.n, m.nnz
     log(f"[bench] generated {args.workload}: n={n} nnz={nnz} in {time.time() - t0:.1f}s")
 
-    # ---- CPU baseline on the un-permuted matrix (rank 0, N = 1 only): the oracle, timed
+    # ---- CPU baseline on the un-permuted matrix: the oracle, timed; its y is also the parity checker
     cpu_baseline = None
     x = E.x_glibc(n)
-    y_cpu = scale = None
-    if rank == 0 and world > 1:
-        from oracle import oracle as O
-
-        y_cpu = O.spmv_coo(n, m.I, m.J, m.V, x)  # checker for the sharded result (not timed)
-        scale = O.abs_rowsum(n, m.I, m.J, m.V, x)
-    if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle import oracle as O
-
+    if args.no_cpu_baseline:
+        y_cpu = O.spmv_coo(n, m.I, m.J, m.V, x)  # checker only, untimed
+    else:
         rowptr = m.row_idx.astype(np.int64)
         O.set_threads(E.host_threads())  # the CPUs this process owns (cgroup quota), not the ones it sees
         t_coo, y_cpu = O.time_spmv(0, rowptr, m.I, m.J, m.V, x, reps=3)
@@ -269,133 +499,136 @@ def main():
                        f"1-thread CSR {2.0 * nnz / t_csr1 / 1e9:.3f} GFLOP/s; literal reference order "
                        f"(solver_test.c:102, 1 thread) {2.0 * nnz / t_coo / 1e9:.3f} GFLOP/s"),
         }
-        scale = O.abs_rowsum(n, m.I, m.J, m.V, x)
         log(f"[bench] cpu baseline: {cpu_baseline['value']} GFLOP/s on {cores} threads")
+    scale = O.abs_rowsum(n, m.I, m.J, m.V, x)
 
-    # ---- host pre-step: partition + permute (matrixReorder), then this rank's plan
+    # ---- host pre-step: partition + permute (matrixReorder), then the plan
     t0 = time.time()
     m.reorder(cfg)
     log(f"[bench] reorder (partition into {m.c.nParts} parts) {time.time() - t0:.1f}s")
     perm = m.reorder_list.copy()
-    xp = E.vector_reorder(x, perm)
-    from ehyb_spmv_gpu_amd import dist as D
-
-    dev = torch.device("cuda", local_rank)
     t0 = time.time()
-    sh = D.ShardedSpmv(m, cfg, rank, world, dev, overlap=not args.no_overlap)   # plan for this rank's row block
-    sh.set_x(xp)
-    plan, r0, r1, row_cuts = sh.plan, sh.r0, sh.r1, sh.cuts
-    x_d, y_d = sh.x, sh.y
+    plan = E.Plan(m, cfg)
+    x_d = torch.from_numpy(E.vector_reorder(x, perm)).to(dev)
+    y_d = torch.zeros(n, dtype=torch.float64, device=dev)
     st = plan.stats
-    log(f"[bench] rank {rank}: rows [{r0},{r1}) plan built+uploaded in {time.time() - t0:.1f}s: "
+    log(f"[bench] plan built+uploaded in {time.time() - t0:.1f}s: "
         f"ell {st['nnz_ell']} er {st['nnz_er']} pad {st['ell_padding']} items {st['n_items']} lds {st['lds_bytes']}B")
     stream = torch.cuda.current_stream().cuda_stream
-    step = sh.step  # N = 1: one SpMV; N > 1: all-gatherv of the x segments over xGMI + local multiply
+    xp, yp = x_d.data_ptr(), y_d.data_ptr()
 
-    elapsed = timed_steps(step, args, torch, dist, world, dev)
+    def step():
+        plan.spmv(xp, yp, stream)
 
-    # ---- parity of what was just timed (rank-local rows) against the CPU oracle
-    parity = None
-    if world > 1:
-        # every rank holds its own y rows: collect all segments (same exchange as for x)
-        D.exchange_segments(y_d, row_cuts, rank)
-        torch.cuda.synchronize()
-    if y_cpu is not None:
-        from oracle import oracle as O
+    elapsed = timed_steps(step, args, torch, dist, 1, dev)
 
-        y = E.vector_recover(y_d.cpu().numpy(), perm)
-        bad, worst = O.check_tolerance(y, y_cpu, scale)
-        parity = {"rows_over_1e-12": bad, "worst_rel": worst}
-        log(f"[bench] parity vs CPU oracle: {bad} rows over 1e-12, worst {worst:.3e}")
-        if bad:
-            raise SystemExit("bench.py: GPU result differs from the CPU oracle; refusing to report a number")
+    # ---- parity of what was just timed against the CPU oracle
+    y = E.vector_recover(y_d.cpu().numpy(), perm)
+    bad, worst = O.check_tolerance(y, y_cpu, scale)
+    parity = {"rows_over_1e-12": bad, "worst_rel": worst}
+    log(f"[bench] parity vs CPU oracle: {bad} rows over 1e-12, worst {worst:.3e}")
+    if bad:
+        raise SystemExit("bench.py: GPU result differs from the CPU oracle; refusing to report a number")
 
-    # ---- per-kernel timing with HIP events on the launch stream (N = 1)
-    roofline = None
-    if world == 1:
-        r = plan.bench(x_d.data_ptr(), y_d.data_ptr(), stream, warmup=5, iters=min(args.steps, 200))
-        ell_ms, er_ms = r["ms_ell_avg"], r["ms_er_avg"]
-        inline = st["er_inline"] > 0  # the ELL launch also multiplies the (tiny) residual: one launch per SpMV
-        empty = st["nnz_er"] == 0
-        if inline or empty:
-            er_ms = 0.0  # no residual launch: the interval between the two events is event overhead
-        bytes_ell = 12 * (st["nnz_ell"] + (st["nnz_er"] if inline else 0)) + 4 * (st["n_rows"] + 1) + 8 * st["n_cols"] + 8 * st["n_rows"]
-        achieved = bytes_ell / (ell_ms * 1e-3) / 1e9
-        traffic = None
-        pmc = os.path.join(ROOT, "profiles", "pmc_latest.json")
-        if os.path.exists(pmc):
-            try:
-                traffic = json.load(open(pmc)).get("ehyb_ell_kernel_hbm_bytes_per_launch")
-            except Exception:
-                traffic = None
-        roofline = {"bound": "hbm", "kernel": "ehyb_ell_kernel", "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS,
-                    "unit": "GB/s", "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                    "alg_bytes_per_launch": bytes_ell, "avg_launch_ms": round(ell_ms, 5),
-                    "er_kernel_avg_launch_ms": None if (inline or empty) else round(er_ms, 5),
-                    "residual": "empty" if empty else ("inline in the ELL launch" if inline else "own launch"),
-                    "format_bytes_per_spmv": st["bytes_format"],
-                    "whole_spmv_alg_GBps": round(st["bytes_alg"] / ((ell_ms + er_ms) * 1e-3) / 1e9, 1)}
-        if traffic:
-            roofline["hbm_GBps_from_traffic"] = round(traffic / (ell_ms * 1e-3) / 1e9, 1)
-        if st["sym_pairs"] > 0:
-            roofline["note"] = ("symmetric pair storage: %d of the %d entries are in-partition pairs a_ij == a_ji stored once "
-                                "(one value read, two FMAs, the mirror product added in LDS), so the algorithmic rate "
-                                "(12 B per entry, SURVEY 8d) can exceed the HBM peak; traffic and hbm_GBps_from_traffic "
-                                "are the bytes really moved" % (2 * st["sym_pairs"], st["nnz"]))
+    # ---- per-kernel timing with HIP events on the launch stream; roofline of the dominant kernel
+    r = plan.bench(xp, yp, stream, warmup=5, iters=min(args.steps, 200))
+    ell_ms, er_ms = r["ms_ell_avg"], r["ms_er_avg"]
+    inline = st["er_inline"] > 0  # the ELL launch also multiplies the (tiny) residual: one launch per SpMV
+    empty = st["nnz_er"] == 0
+    if inline or empty:
+        er_ms = 0.0  # no residual launch: the interval between the two events is event overhead
+    rows, cols = st["n_rows"], st["n_cols"]
+    nnz_ell_launch = st["nnz_ell"] + (st["nnz_er"] if inline else 0)
+    alg_ell = 12 * nnz_ell_launch + 4 * (rows + 1) + 8 * cols + 8 * rows
+    alg_er = 0 if (inline or empty) else 12 * st["nnz_er"] + 8 * st["nnz_er"] + 16 * st["rows_er"]
+    fmt_ell = st["bytes_format_ell"]
+    fmt_er = st["bytes_format"] - fmt_ell
+    if er_ms > ell_ms:
+        kname, k_ms, k_alg, k_fmt = "ehyb_er_kernel", er_ms, alg_er, fmt_er
+    else:
+        kname, k_ms, k_alg, k_fmt = "ehyb_ell_kernel", ell_ms, alg_ell, fmt_ell
+    traffic = pmc_traffic(args.workload, st["sym_pairs"] > 0, kname)
+    real_bytes = traffic if traffic else k_fmt
+    achieved = real_bytes / (k_ms * 1e-3) / 1e9
+    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "bytes_basis": ("rocprofv3 PMC bytes per launch of this workload, storage and kernel (profiles/pmc_traffic.json)"
+                                if traffic else "format bytes per launch (what this layout makes the kernel move; no PMC measurement of this case on file)"),
+                "format_bytes_per_launch": k_fmt, "avg_launch_ms": round(k_ms, 5),
+                "alg_bytes_per_launch": k_alg, "alg_GBps": round(k_alg / (k_ms * 1e-3) / 1e9, 1),
+                "alg_frac": round(k_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "ell_kernel_avg_launch_ms": round(ell_ms, 5),
+                "er_kernel_avg_launch_ms": None if (inline or empty) else round(er_ms, 5),
+                "residual": "empty" if empty else ("inline in the ELL launch" if inline else "own launch"),
+                "format_bytes_per_spmv": st["bytes_format"],
+                "whole_spmv_real_frac": round(st["bytes_format"] / ((ell_ms + er_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+                "whole_spmv_alg_GBps": round(st["bytes_alg"] / ((ell_ms + er_ms) * 1e-3) / 1e9, 1)}
+    if st["sym_pairs"] > 0:
+        roofline["note"] = ("symmetric pair storage: %d of the %d entries are in-partition pairs a_ij == a_ji stored once "
+                            "(one value read, two FMAs, the mirror product added in LDS): frac counts the bytes really "
+                            "moved; alg_frac prices every entry at 12 B (SURVEY 8d) and may exceed 1" % (2 * st["sym_pairs"], st["nnz"]))
+    plan.destroy()
+    del x_d, y_d
+    m.free()
 
     # ---- the same matrix with plain storage (every entry stored, as the reference does), for the record
     plain = None
-    if world == 1 and st["sym_pairs"] > 0 and not args.no_plain_arm:
+    if st["sym_pairs"] > 0 and not args.no_plain_arm:
         t0 = time.time()
-        cfg_p = E.make_config(verbose=0, **{k: v for k, v in kw.items() if k != "sym_pairs"})
-        mp = E.Matrix.generate(gen, *gargs, cfg=cfg_p)
-        mp.reorder(cfg_p)
-        plan_p = E.Plan(mp, cfg_p)
-        xp_d = E.DeviceBuffer(n).upload(E.vector_reorder(x, mp.reorder_list))
-        yp_d = E.DeviceBuffer(n)
-        rp_ = plan_p.bench(xp_d.ptr, yp_d.ptr, warmup=args.warmup, iters=args.steps)
-        ms_p = rp_["ms_total"] / args.steps
-        stp = plan_p.stats
-        bytes_p = 12 * (stp["nnz_ell"] + (stp["nnz_er"] if stp["er_inline"] else 0)) + 4 * (n + 1) + 16 * n
-        plain = {"value": round(2.0 * nnz / ms_p / 1e6, 2), "unit": "GFLOP/s", "ms_per_step": round(ms_p, 5),
-                 "ell_kernel_avg_launch_ms": round(rp_["ms_ell_avg"], 5),
-                 "roofline_frac": round(bytes_p / (rp_["ms_ell_avg"] * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                 "stored_values": stp["size_block_ell"], "format_bytes_per_spmv": stp["bytes_format"],
-                 "note": "every entry stored (bench.py --sym-pairs off); same run, same GPU"}
-        if y_cpu is not None:
-            from oracle import oracle as O
-
-            badp, worstp = O.check_tolerance(E.vector_recover(yp_d.download(), mp.reorder_list), y_cpu, scale)
-            plain["parity"] = {"rows_over_1e-12": badp, "worst_rel": worstp}
-            if badp:
-                raise SystemExit("bench.py: plain-storage result differs from the CPU oracle")
+        plain = one_gpu_case(E, O, np, args.workload, False, kw, args.steps, args.warmup, log, y_cpu=y_cpu, scale=scale, x=x)
+        plain["note"] = "every entry stored (bench.py --sym-pairs off); same run, same GPU"
         log(f"[bench] plain-storage arm: {plain['value']} GFLOP/s ({time.time() - t0:.1f}s incl. its own pre-step)")
-        plan_p.destroy()
 
-    if rank == 0:
-        ms_per_step = elapsed / args.steps * 1e3
-        value = 2.0 * nnz * args.steps / elapsed / 1e9
-        out = {
-            "metric": "fp64 SpMV GFLOP/s (2*nnz/t_iter), EHYB on MI355X",
-            "value": round(value, 2), "unit": "GFLOP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-            "scaling": "strong" if world > 1 else args.scaling, "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic: " + desc,
-            "config": {"workload": args.workload, "rows": n, "nnz": nnz, "parts": int(m.c.nParts),
-                       "lds_doubles": int(cfg.lds_doubles), "part_rows": int(cfg.part_rows), "threads": int(cfg.threads),
-                       "window_mode": "halo" if cfg.window_mode != 1 else "reference",
-                       "nnz_ell": st["nnz_ell"], "nnz_er": st["nnz_er"], "ell_padding": st["ell_padding"],
-                       "sym_pairs": st["sym_pairs"], "stored_values": st["size_block_ell"],
-                       "alg_bytes_per_spmv": st["bytes_alg"] if world == 1 else None,
-                       "exchange": "none" if world == 1 else "RCCL all-gatherv of x segments"},
-            "alg_GBps": round((12 * nnz + 4 * (n + 1) + 16 * n) / (elapsed / args.steps) / 1e9, 1),
-            "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
-        }
-        if plain:
-            out["plain_storage"] = plain
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
+    # ---- the same matrix through the reference-named calls with the reference driver's sizing
+    dropin = None
+    if args.workload in REFERENCE_SIZING and not args.no_dropin_arm:
+        t0 = time.time()
+        dropin = dropin_case(E, O, np, args.workload, x, y_cpu, scale, args.steps, log)
+        log(f"[bench] drop-in path: {dropin['value']} GFLOP/s with {dropin['nParts_used']} partitions ({time.time() - t0:.1f}s)")
+
+    # ---- vendor library on the same matrix (opt-in; not part of the product path)
+    vendor = None
+    if args.vendor_baseline:
+        sys.path.insert(0, os.path.join(ROOT, "tools"))
+        import compare_rocsparse as R
+
+        vendor = R.rocsparse_arm(E, O, np, gen, gargs, x, y_cpu, scale, iters=min(args.steps, 100))
+        log(f"[bench] rocSPARSE CSR: {vendor}")
+
+    # ---- N = 1 point of the strong-scaling curve: the N > 1 default workload on this GPU
+    anchor = None
+    if args.workload == "audikw_1-like" and not args.no_scaling_anchor:
+        t0 = time.time()
+        del y_cpu, scale
+        anchor = one_gpu_case(E, O, np, "rmat-24", False, {}, min(args.steps, 50), min(args.warmup, 5), log)
+        anchor["workload"] = "rmat-24"
+        anchor["note"] = "BASELINE config 5's matrix on ONE GPU: the N = 1 point for `bench.py --gpus N` (strong scaling, same matrix)"
+        log(f"[bench] scaling anchor rmat-24 on one GPU: {anchor['value']} GFLOP/s, {anchor['ms_per_step']} ms ({time.time() - t0:.1f}s)")
+
+    ms_per_step = elapsed / args.steps * 1e3
+    out = {
+        "metric": "fp64 SpMV GFLOP/s (2*nnz/t_iter), EHYB on MI355X",
+        "value": round(2.0 * nnz * args.steps / elapsed / 1e9, 2), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
+        "scaling": "none", "vs_baseline": None, "dtype": "f64", "data": "synthetic: " + desc,
+        "config": {"workload": args.workload, "rows": n, "nnz": nnz, "parts": st["n_parts"],
+                   "lds_doubles": int(cfg.lds_doubles), "part_rows": int(cfg.part_rows), "threads": int(cfg.threads),
+                   "window_mode": "halo" if cfg.window_mode != 1 else "reference",
+                   "nnz_ell": st["nnz_ell"], "nnz_er": st["nnz_er"], "ell_padding": st["ell_padding"],
+                   "sym_pairs": st["sym_pairs"], "stored_values": st["size_block_ell"],
+                   "alg_bytes_per_spmv": st["bytes_alg"], "exchange": "none"},
+        "alg_GBps": round((12 * nnz + 4 * (n + 1) + 16 * n) / (elapsed / args.steps) / 1e9, 1),
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+    }
+    if plain:
+        out["plain_storage"] = plain
+    if dropin:
+        out["dropin_path"] = dropin
+    if vendor:
+        out["vendor_baseline"] = vendor
+    if anchor:
+        out["scaling_anchor"] = anchor
+    print(json.dumps(out), flush=True)
 
 
 if __name__ == "__main__":

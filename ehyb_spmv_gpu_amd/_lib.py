@@ -55,7 +55,8 @@ class Config(C.Structure):
         ("cap_split", C.c_int32),
         ("hub_rule", C.c_int32),
         ("sym_pairs", C.c_int32),
-        ("reserved", C.c_int32 * 6),
+        ("part_boundary_cap", C.c_int32),
+        ("reserved", C.c_int32 * 5),
     ]
 
 
@@ -63,12 +64,12 @@ _STAT_NAMES = [
     "nnz", "nnz_ell", "nnz_er", "ell_padding", "size_block_ell", "size_er", "rows_er",
     "er_segments", "n_rows", "n_cols", "n_parts", "n_slabs", "n_items", "halo_cols",
     "window_loads", "bytes_format", "bytes_alg", "max_row", "lds_bytes", "col_words",
-    "er_inline", "sym_pairs",
+    "er_inline", "sym_pairs", "bytes_format_ell",
 ]
 
 
 class Stats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in _STAT_NAMES] + [("reserved", C.c_int64 * 2)]
+    _fields_ = [(n, C.c_int64) for n in _STAT_NAMES] + [("reserved", C.c_int64 * 1)]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n in _STAT_NAMES}
@@ -95,6 +96,8 @@ SIGNATURES = {
     "ehyb_sizing": (C.c_int, [C.c_int, _cfgp, _ip, _ip, _ip]),
     "ehyb_partition_graph": (C.c_int, [C.c_int, _i64p, _ip, _ip, C.c_int, C.c_int, _cfgp, _ip, _i64p]),
     "ehyb_matrix_reorder": (C.c_int, [_mp, C.c_int, _cfgp]),
+    "ehyb_matrix_reorder_blocks": (C.c_int, [_mp, C.c_int, _cfgp, _ip]),
+    "spmvGPuEHYB_cfg": (C.c_int, [_mp, _dp, _dp, C.c_int, _ip, _cfgp, _dp]),
     "ehyb_vector_reorder": (None, [C.c_int, _dp, _dp, _ip]),
     "ehyb_vector_recover": (None, [C.c_int, _dp, _dp, _ip]),
     "ehyb_top_boundary": (C.c_int, [_mp, _cfgp, C.c_int, _ip]),
@@ -137,6 +140,15 @@ SIGNATURES = {
     "ehyb_gen_kkt3d": (C.c_int, [C.c_int, _cfgp, _mp]),
 }
 
+# C++-linkage names of include/reordering.h, as the reference's driver links them (reordering.h:6-10;
+# the reference compiles its .c files as C++, Makefile:6,21-22)
+CXX_SIGNATURES = {
+    "_Z13matrixReorderP10_matrixCOO": (None, [_mp]),
+    "_Z19matrixReorder_unsymP10_matrixCOO": (None, [_mp]),
+    "_Z13vectorReorderiPKdPdPKi": (None, [C.c_int, _dp, _dp, _ip]),
+    "_Z13vectorRecoveriPKdPdPKi": (None, [C.c_int, _dp, _dp, _ip]),
+}
+
 _lib = None
 
 
@@ -154,6 +166,10 @@ def load():
     lib = C.CDLL(LIB_PATH)
     for name, (res, args) in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+    for name, (res, args) in CXX_SIGNATURES.items():
+        fn = getattr(lib, name)
         fn.restype = res
         fn.argtypes = args
     _lib = lib

@@ -586,8 +586,10 @@ int ehyb_plan_upload(ehyb_plan* P)
     UP(d_er_blocks, er_blocks)
     UP(d_slab_lrow, slab_lrow)
 #undef UP
-    // opt in to the full 160 KiB of LDS (the role of cudaFuncSetAttribute at kernel.cu:351,411)
-    const int lds = (int)ell_lds_bytes(H);
+    // opt in to the full 160 KiB of LDS (the role of cudaFuncSetAttribute at kernel.cu:351,411).  The
+    // attribute belongs to the kernel, not to a plan: it is set to the device maximum, so plans with
+    // windows of different sizes can live side by side in one process.
+    const int lds = EHYB_LDS_MAX_DOUBLES * 8;
 #define LDS_ATTR(K) HIP_TRY(hipFuncSetAttribute((const void*)(K), hipFuncAttributeMaxDynamicSharedMemorySize, lds));
 #define LDS_ATTR_S(T, S)                                   \
     LDS_ATTR((ehyb_ell_kernel<T, false, false, false, S>)) \
@@ -601,6 +603,7 @@ int ehyb_plan_upload(ehyb_plan* P)
     LDS_ATTR_T(512)
     LDS_ATTR_T(1024)
 #undef LDS_ATTR_T
+#undef LDS_ATTR_S
 #undef LDS_ATTR
     P->uploaded = true;
     return EHYB_OK;
@@ -703,7 +706,16 @@ int ehyb_spmv_bench(ehyb_plan* P, const double* x, double* y, void* stream, int 
     if (ms_total) *ms_total = ms;
     if (ms_ell || ms_er) {
         const int n = std::min(iters, 200);
-        std::vector<hipEvent_t> ev((size_t)3 * n);
+        struct Events {  // destroyed on every way out of this block
+            std::vector<hipEvent_t> v;
+            ~Events()
+            {
+                for (hipEvent_t e : v)
+                    if (e) (void)hipEventDestroy(e);
+            }
+        } evs;
+        evs.v.assign((size_t)3 * n, nullptr);
+        std::vector<hipEvent_t>& ev = evs.v;
         for (auto& e : ev) HIP_TRY(hipEventCreate(&e));
         for (int i = 0; i < n; ++i) {
             const bool fused = fuse_residual(P);
@@ -722,7 +734,6 @@ int ehyb_spmv_bench(ehyb_plan* P, const double* x, double* y, void* stream, int 
             se += t1;
             sr += t2;
         }
-        for (auto& e : ev) (void)hipEventDestroy(e);
         if (ms_ell) *ms_ell = se / n;
         if (ms_er) *ms_er = sr / n;
     }
@@ -764,21 +775,20 @@ int ehyb_plan_create(const matrixCOO* m, const ehyb_config* cfg, ehyb_plan** pla
     return rc;
 }
 
-// The drop-in entry point (reference spmv.cu:61-133).
-int spmvGPuEHYB_status(matrixCOO* localMatrix, const double* vectorIn, double* vectorOut, const int MAXIter,
-                       int* realIter)
+// The drop-in entry point (reference spmv.cu:61-133).  cfg == NULL: defaults, storage chosen from
+// the matrix (sym_storage_suits) -- no environment variable takes part.
+int spmvGPuEHYB_cfg(matrixCOO* localMatrix, const double* vectorIn, double* vectorOut, const int MAXIter,
+                    int* realIter, const ehyb_config* cfg_in, double* ms_total)
 {
     clear_error();
     if (!localMatrix || !vectorIn || !vectorOut || MAXIter < 0)
         EHYB_FAIL(EHYB_ERR_ARG, "spmvGPuEHYB: bad arguments");
     ehyb_config cfg;
-    memset(&cfg, 0, sizeof cfg);  // zero = default; the sizes follow from the mode fields set below
-    if (const char* v = getenv("EHYB_SYM_PAIRS")) cfg.sym_pairs = atoi(v);  // 1: symmetric pair storage (caller's matrix is symmetric)
-    if (const char* v = getenv("EHYB_VERBOSE")) cfg.verbose = atoi(v);
-    if (const char* v = getenv("EHYB_LDS_DOUBLES")) cfg.lds_doubles = atoi(v);
-    if (const char* v = getenv("EHYB_THREADS")) cfg.threads = atoi(v);
-    if (const char* v = getenv("EHYB_WINDOW_MODE")) cfg.window_mode = atoi(v);
-    if (const char* v = getenv("EHYB_ITEMS_PER_CU")) cfg.items_per_cu = atoi(v);
+    memset(&cfg, 0, sizeof cfg);  // zero = default; the sizes follow from the mode fields
+    if (cfg_in)
+        cfg = *cfg_in;
+    else if (sym_storage_suits(localMatrix))
+        cfg.sym_pairs = 1;
     ehyb_plan* P = nullptr;
     int rc = ehyb_plan_create(localMatrix, &cfg, &P);  // COO2EHYB + upload (spmv.cu:73-81)
     if (rc != EHYB_OK) return rc;
@@ -811,8 +821,15 @@ int spmvGPuEHYB_status(matrixCOO* localMatrix, const double* vectorIn, double* v
     printf("iter is %d, time is %f ms, GPU Gflops is %f\n ", iters, ms,
            (1e-9 * ((double)localMatrix->totalNum * 2) * 1000 * iters) / ms);  // spmv.cu:121-122
     if (realIter) *realIter = iters;
+    if (ms_total) *ms_total = ms;
     fail(EHYB_OK);
     return EHYB_OK;
+}
+
+int spmvGPuEHYB_status(matrixCOO* localMatrix, const double* vectorIn, double* vectorOut, const int MAXIter,
+                       int* realIter)
+{
+    return spmvGPuEHYB_cfg(localMatrix, vectorIn, vectorOut, MAXIter, realIter, nullptr, nullptr);
 }
 
 void spmvGPuEHYB(matrixCOO* localMatrix, const double* vectorIn, double* vectorOut, const int MAXIter,

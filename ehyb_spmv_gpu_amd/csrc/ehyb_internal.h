@@ -43,6 +43,7 @@ struct Config {
     int cap_split;
     int hub_rule;
     int sym_pairs;
+    int part_boundary_cap;  // ints the caller's partBoundary holds; 0 = m->nParts + 1, never more
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -105,6 +106,7 @@ struct HostLayout {
 };
 
 int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* out);
+bool sym_storage_suits(const matrixCOO* m);  // spmvGPuEHYB's own choice of the storage (plan.cpp)
 
 // ---------------------------------------------------------------- partitioner
 int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vwgt, int nparts,
@@ -119,6 +121,16 @@ int mtmetis_partition(int n, const int64_t* xadj, const int* adjncy, int nparts,
 // ---------------------------------------------------------------- misc
 double wall_seconds();
 int default_host_threads();  // OpenMP threads when cfg.host_threads is 0: capped by affinity and cgroup quota
+// The library's OpenMP regions run on cfg.host_threads (or the default above) threads; the caller's
+// own OpenMP setting (the calling thread's nthreads-var) is put back when the entry point returns.
+struct OmpScope {
+    int saved;
+    explicit OmpScope(int want);
+    explicit OmpScope(const ehyb_config* cfg) : OmpScope(cfg ? cfg->host_threads : 0) {}
+    ~OmpScope();
+    OmpScope(const OmpScope&) = delete;
+    OmpScope& operator=(const OmpScope&) = delete;
+};
 inline uint64_t splitmix64(uint64_t& s)
 {
     uint64_t z = (s += 0x9E3779B97F4A7C15ull);

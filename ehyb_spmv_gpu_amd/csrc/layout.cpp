@@ -163,7 +163,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         EHYB_FAIL(EHYB_ERR_ARG, "build_layout: rowIdx[0]=%d rowIdx[n]=%d totalNum=%d", rp[0], rp[n], m->totalNum);
     for (int i = 0; i < n; ++i)
         if (rp[i + 1] < rp[i]) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: rowIdx not monotone at row %d", i);
-    if (cfg.host_threads > 0) omp_set_num_threads(cfg.host_threads);
+    OmpScope omp_scope(cfg.host_threads);
 
     // Window capacity: two doubles of the LDS budget hold the slab counter of the ELL kernel, so a
     // 10,240-double budget is exactly 80 KiB and two workgroups still fit one CU's 160 KiB.
@@ -777,9 +777,11 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     st.er_inline = L->inline_er ? er_inline_pairs * 2 * kSlabRows : 0;
     // values 8 B/element, shared column words 4 B, per slab a 16-byte record + 64-byte lane map;
     // the residual either as inline pairs (their columns are part of col_words) or as CSR segments
-    st.bytes_format = 8 * size_ell + 4 * col_words + 80 * nslabs + 32 * st.n_items + 32 * (int64_t)(L->segs.size() / 8) + 8 * st.window_loads +
-                      4 * halo_item_loads + 8 * (int64_t)nrows +
-                      (L->inline_er ? 8 * st.er_inline + 8 * nnz_er : 12 * nnz_er + 12 * nseg + 16 * nseg);
+    st.bytes_format_ell = 8 * size_ell + 4 * col_words + 80 * nslabs + 32 * st.n_items + 32 * (int64_t)(L->segs.size() / 8) + 8 * st.window_loads +
+                          4 * halo_item_loads + 8 * (int64_t)nrows + (L->inline_er ? 8 * st.er_inline + 8 * nnz_er : 0);
+    // residual launch: (column, value) streamed, one 8-byte gather of x per entry (at least: a random
+    // gather moves a whole sector), per segment its pointer, row and block share, and y read + written
+    st.bytes_format = st.bytes_format_ell + (L->inline_er ? 0 : 12 * nnz_er + 8 * nnz_er + 12 * nseg + 16 * nseg);
     if (nnz_ell + nnz_er != nnz) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: %lld + %lld != %lld", (long long)nnz_ell, (long long)nnz_er, (long long)nnz);
     if (sym) {
         int64_t gone = 0;

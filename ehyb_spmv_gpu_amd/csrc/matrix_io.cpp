@@ -83,6 +83,7 @@ extern "C" {
 int ehyb_mm_read(const char* path, const ehyb_config* cfg, matrixCOO* out, int* is_symmetric)
 {
     clear_error();
+    OmpScope omp_scope(cfg);
     if (!path || !out) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_mm_read: null argument");
     // The whole file in memory, plain or gzip (zlib reads both; "<path>.gz" is tried when <path>
     // does not exist, so `-m audikw_1` also finds ./read/audikw_1.mtx.gz).  The reference parses
@@ -276,6 +277,7 @@ int ehyb_matrix_from_csr(int n, const int64_t* rowptr, const int* cols, const do
                          const ehyb_config* cfg, matrixCOO* out)
 {
     clear_error();
+    OmpScope omp_scope(cfg);
     if (!out || n <= 0 || !rowptr || rowptr[0] != 0 || rowptr[n] < 0 || (rowptr[n] > 0 && (!cols || !vals)))
         EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_from_csr: bad arguments");
     int rc = alloc_matrix(n, rowptr[n], out);
@@ -307,6 +309,7 @@ int ehyb_matrix_from_csr(int n, const int64_t* rowptr, const int* cols, const do
 int ehyb_gen_banded(int n, int band, int block, const ehyb_config* cfg, matrixCOO* out)
 {
     clear_error();
+    OmpScope omp_scope(cfg);
     if (!out || n <= 0 || band <= 0 || block <= 0 || band > block || n % block != 0)
         EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_banded: need n %% block == 0 and band <= block");
     int rc = alloc_matrix(n, (int64_t)n * band, out);
@@ -348,7 +351,7 @@ int ehyb_gen_fem3d_block(int n, int dof, int nx, int ny, int extra_ppm, int scra
         EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_fem3d: need n %% dof == 0 and positive grid sizes");
     if (n_blocks < 1 || block < 0 || block >= n_blocks || (int64_t)n * n_blocks > 0x7FFFFFFFll)
         EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_fem3d_block: block %d of %d, %d rows each", block, n_blocks, n);
-    omp_set_num_threads(cfg && cfg->host_threads > 0 ? cfg->host_threads : default_host_threads());
+    OmpScope omp_scope(cfg);
     const int N = n / dof;
     const int64_t layer = (int64_t)nx * ny;
     const int nz = (int)((N + layer - 1) / layer);
@@ -440,6 +443,7 @@ int ehyb_gen_fem3d_block(int n, int dof, int nx, int ny, int extra_ppm, int scra
 int ehyb_gen_rmat(int scale, int64_t edges, uint64_t seed, const ehyb_config* cfg, matrixCOO* out)
 {
     clear_error();
+    OmpScope omp_scope(cfg);
     if (!out || scale < 1 || scale > 30 || edges < 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_rmat: bad arguments");
     const int n = 1 << scale;
     std::vector<int> ei((size_t)edges), ej((size_t)edges);
@@ -505,6 +509,7 @@ int ehyb_gen_stencil2d(int nx, int ny, int points, int extra, uint64_t seed, con
                        matrixCOO* out)
 {
     clear_error();
+    OmpScope omp_scope(cfg);
     if (!out || nx <= 0 || ny <= 0 || (points != 5 && points != 9) || extra < 0)
         EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_stencil2d: bad arguments");
     const int n = nx * ny;
@@ -557,6 +562,7 @@ int ehyb_gen_stencil2d(int nx, int ny, int points, int extra, uint64_t seed, con
 int ehyb_gen_kkt3d(int nx, const ehyb_config* cfg, matrixCOO* out)
 {
     clear_error();
+    OmpScope omp_scope(cfg);
     if (!out || nx < 2 || (int64_t)nx * nx * nx * 2 > 0x7FFFFFF0ll) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_kkt3d: bad size");
     const int n1 = nx * nx * nx, n = 2 * n1;
     auto id = [&](int x, int y, int z) { return (z * nx + y) * nx + x; };
@@ -622,6 +628,7 @@ int ehyb_gen_kkt3d(int nx, const ehyb_config* cfg, matrixCOO* out)
 int ehyb_matrix_append_ghosts(matrixCOO* m, int n_ghost, int64_t nnz_g, const int* gi, const int* gj, const double* gv)
 {
     clear_error();
+    OmpScope omp_scope(0);
     if (!m || !m->rowIdx || n_ghost < 0 || nnz_g < 0 || (nnz_g > 0 && (!gi || !gj || !gv)))
         EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_append_ghosts: bad arguments");
     const int n0 = m->dimension;

@@ -579,10 +579,10 @@ int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vw
     fine.ew = nullptr;
     fine.vw = vwgt;
 
-    if (cfg.partitioner == EHYB_PART_CONTIGUOUS) {
-        // contiguous blocks of the given numbering.  Unit weights: equal chunks rounded up to whole
-        // 64-row slabs (so block-structured inputs keep their alignment: config 3's 1024-row blocks
-        // stay inside one window); weighted: equal-weight blocks.
+    // contiguous blocks of the given numbering.  Unit weights: equal chunks rounded up to whole
+    // 64-row slabs (so block-structured inputs keep their alignment: config 3's 1024-row blocks
+    // stay inside one window); weighted: equal-weight blocks.
+    auto contiguous = [&]() -> int {
         if (!vwgt) {
             // fill every block to the cap (rounded down to whole slabs): block-structured inputs whose
             // block size divides the cap keep whole blocks inside one window
@@ -612,7 +612,8 @@ int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vw
         }
         if (edgecut) *edgecut = edge_cut(fine, part);
         return EHYB_OK;
-    }
+    };
+    if (cfg.partitioner == EHYB_PART_CONTIGUOUS) return contiguous();
 
     // ---- coarsening
     const double t0 = wall_seconds();
@@ -626,6 +627,14 @@ int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vw
         std::vector<int> cmap;
         coarsen_once(cur, max_vw, rng, &cg, &cmap);
         if (cg.n > cur.n * 0.93) {  // matching stalled
+            // EHYB_PART_AUTO: a graph that stops coarsening while it is still far from the target has
+            // no locality for a k-way partitioner to find (R-MAT 2^24: 124 M of 133 M edges cut after
+            // 110 s, most of them in the initial partition of a 15 M-vertex "coarsest" graph).
+            // Contiguous blocks cost nothing and cut about as much.
+            if (cfg.partitioner == EHYB_PART_AUTO && cg.n > 8 * (int64_t)coarse_target) {
+                if (cfg.verbose) printf("partition: matching stalled at %d of %d vertices: contiguous blocks\n", cg.n, n);
+                return contiguous();
+            }
             if (cg.n < cur.n) {
                 levels.push_back(std::move(cg));
                 cmaps.push_back(std::move(cmap));
@@ -690,5 +699,6 @@ extern "C" int ehyb_partition_graph(int n, const int64_t* xadj, const int* adjnc
                                     int64_t* edgecut)
 {
     ehyb::Config c = ehyb::resolve_config(cfg);
+    ehyb::OmpScope omp_scope(c.host_threads);
     return ehyb::partition_graph(n, xadj, adjncy, vwgt, nparts, max_part_rows, c, part, edgecut);
 }

@@ -1,9 +1,58 @@
 // Host half of the plan object: layout construction and read-only views (no HIP calls).
 #include "ehyb_internal.h"
 
+#include <algorithm>
 #include <new>
 
 using namespace ehyb;
+
+namespace ehyb {
+
+// What spmvGPuEHYB does when nobody tells it the storage (cfg == NULL): symmetric pair storage iff
+//   * the matrix has at least EHYB_SYM_MIN_ROWS rows (below that plain storage is faster),
+//   * it arrives with partitions, enough of them to fill the chip with one workgroup each, and every
+//     partition leaves room in the symmetric window for its x image AND its y accumulators -- which is
+//     how matrixReorder (symmetric files only, solver_test.c:369-370) sizes them,
+//   * a sample of its off-diagonal entries has bitwise equal mirror images (a_ij == a_ji).
+// The result never depends on the answer (entries without a partner are stored as they are); only
+// the speed does.
+bool sym_storage_suits(const matrixCOO* m)
+{
+    const int n = m->dimension;
+    if (n < EHYB_SYM_MIN_ROWS || !m->partBoundary || !m->rowIdx || !m->J || !m->V) return false;
+    const int np = m->nParts;
+    if (np < kNumCU / 2 || m->partBoundary[0] != 0 || m->partBoundary[np] != n) return false;
+    ehyb_config zs;
+    memset(&zs, 0, sizeof zs);
+    zs.sym_pairs = 1;
+    const Config cs = resolve_config(&zs);
+    int max_rows = 0;
+    for (int p = 0; p < np; ++p) {
+        if (m->partBoundary[p + 1] < m->partBoundary[p]) return false;
+        max_rows = std::max(max_rows, m->partBoundary[p + 1] - m->partBoundary[p]);
+    }
+    if (2 * (max_rows + 1) > cs.lds_doubles - 2) return false;
+    // symmetry probe: up to 4096 entries, evenly spread
+    const int64_t nnz = m->totalNum;
+    if (nnz <= 0) return false;
+    const int64_t step = std::max<int64_t>(1, nnz / 4096);
+    int64_t seen = 0, paired = 0;
+    int row = 0;
+    for (int64_t k = 0; k < nnz; k += step) {
+        while (row + 1 < n && m->rowIdx[row + 1] <= k) ++row;
+        const int j = m->J[k];
+        if (j == row || (unsigned)j >= (unsigned)n) continue;
+        ++seen;
+        for (int q = m->rowIdx[j]; q < m->rowIdx[j + 1]; ++q)
+            if (m->J[q] == row && m->V[q] == m->V[k]) {
+                ++paired;
+                break;
+            }
+    }
+    return seen > 0 && paired * 10 >= seen * 9;
+}
+
+}  // namespace ehyb
 
 extern "C" {
 

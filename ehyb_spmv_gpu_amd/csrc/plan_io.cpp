@@ -17,7 +17,7 @@ using namespace ehyb;
 
 namespace {
 
-const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '4'};
+const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '5'};
 const char kEnd[8] = {'E', 'H', 'Y', 'B', 'E', 'N', 'D', '4'};
 
 struct FileCloser {

@@ -104,18 +104,19 @@ static void build_adjacency(const matrixCOO* m, bool symmetric_pattern, std::vec
 
 using namespace ehyb;
 
-// First partition of every top-level block of the most recent two-level reorder on this thread
-// (read back through ehyb_top_boundary).
-static thread_local std::vector<int> g_block_first;
-
 extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const ehyb_config* cfg)
+{
+    return ehyb_matrix_reorder_blocks(m, symmetric_pattern, cfg, nullptr);
+}
+
+extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, const ehyb_config* cfg, int* block_first)
 {
     clear_error();
     if (!m || m->dimension <= 0 || m->totalNum < 0 || !m->I || !m->J || !m->V || !m->rowIdx ||
         !m->numInRow || !m->numInRow2 || !m->partBoundary || !m->reorderList)
         EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_reorder: incomplete matrixCOO");
     Config c = resolve_config(cfg);
-    if (c.host_threads > 0) omp_set_num_threads(c.host_threads);
+    OmpScope omp_scope(c.host_threads);
     const int n = m->dimension;
     const int64_t nnz = m->totalNum;
     int nparts = m->nParts;
@@ -135,6 +136,13 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
         EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_reorder: entry %lld (%d,%d) is outside the %d x %d matrix or not in the row rowIdx places it in",
                   (long long)bad_entry, m->I[bad_entry], m->J[bad_entry], n, n);
     if (c.verbose) printf("nParts is %d\n", nparts);
+
+    // boundaries the caller's partBoundary can take (ehyb.h, part_boundary_cap): without a stated
+    // capacity the partition count is never raised above the caller's nParts
+    const int64_t pb_cap = c.part_boundary_cap > 0 ? c.part_boundary_cap : (int64_t)nparts + 1;
+    if (pb_cap < (int64_t)nparts + 1)
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_reorder: partBoundary holds %lld ints, nParts = %d needs %d", (long long)pb_cap, nparts, nparts + 1);
+    std::vector<int> top_first;  // n_top > 1: first partition of every top-level block
 
     int cache = m->vectorCacheSize > 0 ? (int)m->vectorCacheSize : c.part_rows;
     int cap = std::max<int64_t>(cache, ((int64_t)n + nparts - 1) / nparts);
@@ -171,7 +179,7 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
             std::vector<int64_t> sx;
             std::vector<int> sa, spart;
             int offset = 0;
-            g_block_first.assign(c.n_top + 1, 0);
+            top_first.assign(c.n_top + 1, 0);
             for (int b = 0; b < c.n_top; ++b) {
                 verts.clear();
                 for (int i = 0; i < n; ++i)
@@ -196,10 +204,13 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
                     if (rc != EHYB_OK) return rc;
                 }
                 for (int q = 0; q < nb; ++q) part[verts[q]] = offset + spart[q];
-                g_block_first[b] = offset;
+                top_first[b] = offset;
                 offset += kb;
+                if ((int64_t)offset + 1 > pb_cap)
+                    EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_reorder: the two-level partition needs more than the %lld partBoundary entries "
+                                            "the caller holds (set cfg.part_boundary_cap)", (long long)pb_cap);
             }
-            g_block_first[c.n_top] = offset;
+            top_first[c.n_top] = offset;
             nparts = offset;
             m->nParts = nparts;
         } else {
@@ -244,6 +255,9 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
                     for (int p = 0; p < nparts; ++p)
                         if (demand[p] > c.lds_doubles - 2 && demand[p] <= c.lds_doubles * 3 / 2 && (int)members[p].size() >= 4 * kSlabRows)
                             offenders.push_back(p);
+                    // every split adds a partition: no more of them than the caller's partBoundary can take
+                    if ((int64_t)nparts + 1 + (int64_t)offenders.size() > pb_cap)
+                        offenders.resize((size_t)std::max<int64_t>(0, pb_cap - nparts - 1));
                     if (offenders.empty()) break;
                     if (c.verbose) printf("capacity split round %d: %zu of %d partitions overflow the window\n", round, offenders.size(), nparts);
                     // bisect the offenders side by side (each on its own induced subgraph), then renumber
@@ -426,6 +440,12 @@ extern "C" int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const eh
     m->V = nV;
     m->maxCol = maxcol;
     if (c.verbose) printf("permute time is %ld us\n", (long)((wall_seconds() - t_perm) * 1e6));
+    if (block_first) {
+        if (c.n_top > 1)
+            std::copy(top_first.begin(), top_first.end(), block_first);
+        else
+            block_first[0] = 0, block_first[1] = nparts;
+    }
     return EHYB_OK;
 }
 
@@ -434,12 +454,8 @@ extern "C" int ehyb_top_boundary(const matrixCOO* m, const ehyb_config* cfg, int
     if (!m || !part_of_block || n_top < 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_top_boundary: bad arguments");
     (void)cfg;
     const int np = m->nParts;
-    // the blocks of a two-level reorder done by this thread on this matrix
-    if ((int)g_block_first.size() == n_top + 1 && g_block_first[n_top] == np) {
-        for (int b = 0; b <= n_top; ++b) part_of_block[b] = g_block_first[b];
-        return EHYB_OK;
-    }
-    // otherwise: runs of whole partitions with (nearly) equal entry counts
+    if (!m->partBoundary || !m->rowIdx || np < 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_top_boundary: matrix not reordered");
+    // runs of whole partitions with (nearly) equal entry counts
     std::vector<int64_t> w(np + 1, 0);
     for (int p = 0; p < np; ++p)
         w[p + 1] = w[p] + (m->rowIdx[m->partBoundary[p + 1]] - m->rowIdx[m->partBoundary[p]]);

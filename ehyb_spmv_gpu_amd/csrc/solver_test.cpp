@@ -212,6 +212,7 @@ int main(int argc, char* argv[])
     // --------------------------------- reorder (solver_test.c:369-376)
     if (!plan) {
         gettimeofday(&t0, NULL);
+        cfg.part_boundary_cap = n + 1;  // the library's readers and generators allocate dimension + 1 boundaries
         rc = ehyb_matrix_reorder(&A, symmetric, &cfg);
         gettimeofday(&t1, NULL);
         if (rc != EHYB_OK) {
@@ -226,13 +227,7 @@ int main(int argc, char* argv[])
     // --------------------------------- the hot path (solver_test.c:382-383)
     int realIter = 0;
     if (cache.empty()) {
-        if (cfg.verbose) setenv("EHYB_VERBOSE", "1", 1);
-        char buf[32];
-        snprintf(buf, sizeof buf, "%d", cfg.lds_doubles), setenv("EHYB_LDS_DOUBLES", buf, 1);
-        snprintf(buf, sizeof buf, "%d", cfg.threads), setenv("EHYB_THREADS", buf, 1);
-        snprintf(buf, sizeof buf, "%d", cfg.window_mode), setenv("EHYB_WINDOW_MODE", buf, 1);
-        snprintf(buf, sizeof buf, "%d", cfg.sym_pairs), setenv("EHYB_SYM_PAIRS", buf, 1);
-        rc = spmvGPuEHYB_status(&A, xReorder, yReorder, MAXIter, &realIter);
+        rc = spmvGPuEHYB_cfg(&A, xReorder, yReorder, MAXIter, &realIter, &cfg, nullptr);  // spmvGPuEHYB with this run's knobs
         if (rc != EHYB_OK) {
             printf("spmvGPuEHYB failed (%d): %s\n", rc, ehyb_last_error());
             return 1;

@@ -21,12 +21,30 @@ from . import host as H
 
 
 def row_cuts(matrix, cfg, world):
-    """First row of every rank's block, world+1 entries (whole partitions per rank)."""
-    blocks = (C.c_int * (world + 1))()
-    H._check(H._lib.load().ehyb_top_boundary(C.byref(matrix.c), C.byref(cfg) if cfg else None, world, blocks),
-             "ehyb_top_boundary")
+    """First row of every rank's block, world+1 entries (whole partitions per rank): the top-level
+    blocks of the two-level reorder (Matrix.reorder with cfg.n_top == world) when the matrix carries
+    them, else runs of whole partitions with equal entry counts (ehyb_top_boundary)."""
+    blocks = getattr(matrix, "block_first", None)
+    if blocks is None or len(blocks) != world + 1 or blocks[-1] != matrix.c.nParts:
+        blocks = (C.c_int * (world + 1))()
+        H._check(H._lib.load().ehyb_top_boundary(C.byref(matrix.c), C.byref(cfg) if cfg else None, world, blocks),
+                 "ehyb_top_boundary")
     pb = matrix.part_boundary
     return [int(pb[blocks[b]]) for b in range(world + 1)]
+
+
+def balanced_row_cuts(rowptr, world):
+    """Row blocks of (nearly) equal entry counts, one per GPU: world+1 first rows.  The top level of the
+    two-level partition of SURVEY 8e for callers that shard the rows themselves (every GPU streams the
+    same number of bytes)."""
+    rowptr = np.asarray(rowptr, dtype=np.int64)
+    n = len(rowptr) - 1
+    cuts = [0]
+    for b in range(1, world):
+        c = int(np.searchsorted(rowptr, rowptr[n] * b // world, side="left"))
+        cuts.append(min(max(c, cuts[-1] + 1), n - (world - b)))
+    cuts.append(n)
+    return cuts
 
 
 def exchange_segments(x_full, cuts, rank, group=None):
@@ -123,9 +141,14 @@ def _copy_cfg(cfg, **kw):
 
 
 class RankLocalMatrix:
-    def __init__(self, I, J, V, cuts, rank, cfg=None, symmetric=False, group=None):
+    def __init__(self, I, J, V, cuts, rank, cfg=None, symmetric=False, group=None, exchange="halo"):
         """I, J, V: this rank's rows in global labels, row-grouped (I ascending).  cuts: first row of
-        every rank, world+1 entries.  Collective: every rank of `group` must call it."""
+        every rank, world+1 entries.  Collective: every rank of `group` must call it.
+        exchange = "halo": one ghost slot per distinct remote column, filled by an all_to_all of exactly
+        those entries (HaloSpmv).  exchange = "allgather": the ghost columns are the places of the remote
+        entries inside the buffer an all-gather of the (padded) x segments fills (GatherSpmv):
+        x = [own segment, padded to seg_len | segment of rank 0 | ... | segment of rank world-1], every
+        segment in its owner's plan order, so nothing has to be unpacked after the collective."""
         world = len(cuts) - 1
         self.rank, self.world, self.cuts, self.group = rank, world, [int(c) for c in cuts], group
         r0, r1 = self.cuts[rank], self.cuts[rank + 1]
@@ -166,9 +189,29 @@ class RankLocalMatrix:
             if len(a) and (a.min() < r0 or a.max() >= r1):
                 raise ValueError("RankLocalMatrix: a peer asked for a column this rank does not own")
         self.send_counts = np.array([len(a) for a in asked], dtype=np.int64)
-        self.send_idx = np.concatenate([self.perm[a - r0] for a in asked]).astype(np.int64) if world > 1 else np.zeros(0, np.int64)
-        # the coupling entries, rows in plan numbering, columns = ghost slots
-        self.m.append_ghosts(self.n_ghost, self.perm[I[off] - r0], np.searchsorted(gcols, Jg), V[off])
+        places = [self.perm[a - r0].astype(np.int64) for a in asked]   # where, in my plan order, what each peer wants sits
+        self.send_idx = np.concatenate(places) if world > 1 else np.zeros(0, np.int64)
+        self.exchange = exchange
+        self.seg_len = max(self.cuts[b + 1] - self.cuts[b] for b in range(world))
+        if exchange == "allgather" and world > 1:
+            import torch.distributed as dist
+
+            told = [None] * world
+            dist.all_gather_object(told, places, group=group)
+            # ghost column of remote entry k of owner p: behind my padded segment, inside p's segment of the gathered buffer
+            slot = np.empty(self.n_ghost, dtype=np.int64)
+            at = 0
+            for p in range(world):
+                pl = np.asarray(told[p][rank], dtype=np.int64)
+                slot[at:at + len(pl)] = (self.seg_len - self.n_loc) + p * self.seg_len + pl
+                at += len(pl)
+            assert at == self.n_ghost
+            self.n_ext = (self.seg_len - self.n_loc) + world * self.seg_len
+            self.m.append_ghosts(self.n_ext, self.perm[I[off] - r0], slot[np.searchsorted(gcols, Jg)], V[off])
+        else:
+            # the coupling entries, rows in plan numbering, columns = ghost slots
+            self.n_ext = self.n_ghost
+            self.m.append_ghosts(self.n_ghost, self.perm[I[off] - r0], np.searchsorted(gcols, Jg), V[off])
         self.nnz = len(V)
         self.cfg_plan = _copy_cfg(cfg, n_top=2 if world > 1 else 1)
 
@@ -274,6 +317,87 @@ class HaloSpmv:
     def y_local(self):
         """This rank's y segment in global label order (host array)."""
         return self.L.y_from_plan(self.y.cpu().numpy())
+
+    def time_local(self, iters):
+        return _time_local(self, iters)
+
+
+def _time_local(sh, iters):
+    """Mean milliseconds of this rank's multiply alone (both phases back to back, no exchange)."""
+    torch = sh.torch
+    cur = torch.cuda.current_stream()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    xp, yp = sh.x.data_ptr(), sh.y.data_ptr()
+    for _ in range(3):
+        sh.plan.spmv(xp, yp, cur.cuda_stream)
+    a.record(cur)
+    for _ in range(iters):
+        sh.plan.spmv(xp, yp, cur.cuda_stream)
+    b.record(cur)
+    b.synchronize()
+    return a.elapsed_time(b) / iters
+
+
+class GatherSpmv:
+    """One rank's multiply of a RankLocalMatrix(exchange="allgather") on its GPU: per step ONE
+    all_gather_into_tensor of the padded x segments (RCCL over xGMI: the all-gatherv of north_star with
+    equal counts) straight into the part of x the residual phase reads, overlapped with the ELL phase,
+    which needs local columns only.  No pack or unpack kernel on either side."""
+
+    def __init__(self, local, device, overlap=True, stage_on_cpu=False):
+        import torch
+        import torch.distributed as dist
+
+        assert local.exchange == "allgather" or local.world == 1
+        self.torch, self.dist = torch, dist
+        self.L = local
+        self.plan = local.plan()
+        self.seg_len = local.seg_len
+        self.x = torch.zeros(local.n_loc + local.n_ext, dtype=torch.float64, device=device)
+        self.y = torch.zeros(local.n_loc, dtype=torch.float64, device=device)
+        self.mine = self.x[:self.seg_len]                                   # own segment, zero padded
+        self.gathered = self.x[self.seg_len:] if local.world > 1 else None  # world x seg_len
+        self.overlap = overlap and local.world > 1
+        self.comm_stream = torch.cuda.Stream(device=device) if self.overlap else None
+        self.stage = stage_on_cpu and device.type != "cpu"                  # gloo cannot move GPU tensors
+
+    def set_x_local(self, x_local):
+        self.x[:self.L.n_loc].copy_(self.torch.from_numpy(self.L.x_to_plan(x_local)))
+
+    def exchange(self):
+        if self.L.world == 1:
+            return
+        if not self.stage:
+            self.dist.all_gather_into_tensor(self.gathered, self.mine, group=self.L.group)
+            return
+        mine = self.mine.cpu()
+        parts = [self.torch.empty_like(mine) for _ in range(self.L.world)]
+        self.dist.all_gather(parts, mine, group=self.L.group)
+        self.gathered.copy_(self.torch.cat(parts))
+
+    def step(self):
+        torch = self.torch
+        cur = torch.cuda.current_stream()
+        xp, yp = self.x.data_ptr(), self.y.data_ptr()
+        if self.L.world == 1:
+            self.plan.spmv(xp, yp, cur.cuda_stream)
+            return
+        if not self.overlap:
+            self.exchange()
+            self.plan.spmv(xp, yp, cur.cuda_stream)
+            return
+        self.comm_stream.wait_stream(cur)
+        with torch.cuda.stream(self.comm_stream):
+            self.exchange()
+        self.plan.spmv(xp, yp, cur.cuda_stream, phase=1)  # local columns only
+        cur.wait_stream(self.comm_stream)
+        self.plan.spmv(xp, yp, cur.cuda_stream, phase=2)  # columns inside the gathered segments
+
+    def y_local(self):
+        return self.L.y_from_plan(self.y.cpu().numpy())
+
+    def time_local(self, iters):
+        return _time_local(self, iters)
 
 
 class HaloCG:

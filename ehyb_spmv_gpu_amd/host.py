@@ -194,10 +194,24 @@ class Matrix:
 
     # ---- the pre-step (solver_test.c:369-376)
     def reorder(self, cfg=None, symmetric=None):
-        """matrixReorder / matrixReorder_unsym (reordering.c:231-378 / 41-228), in place."""
+        """matrixReorder / matrixReorder_unsym (reordering.c:231-378 / 41-228), in place.
+        With cfg.n_top > 1 the first partition of every top-level block is kept in self.block_first."""
         sym = self.symmetric if symmetric is None else symmetric
-        _check(self.lib.ehyb_matrix_reorder(C.byref(self.c), 1 if sym else 0, C.byref(cfg) if cfg else None),
+        c = Config.from_buffer_copy(cfg) if cfg is not None else Config()
+        c.part_boundary_cap = self.n + 1  # what ehyb_mm_read / ehyb_gen_* / ehyb_matrix_from_csr allocate
+        n_top = max(1, int(c.n_top))
+        blocks = (C.c_int * (n_top + 1))()
+        _check(self.lib.ehyb_matrix_reorder_blocks(C.byref(self.c), 1 if sym else 0, C.byref(c), blocks),
                "ehyb_matrix_reorder")
+        self.block_first = [int(b) for b in blocks]
+        return self
+
+    def reorder_dropin(self):
+        """matrixReorder(m) / matrixReorder_unsym(m) exactly as the reference's driver calls them
+        (solver_test.c:369-374; the C++-linkage symbols of include/reordering.h): no configuration,
+        nParts / vectorCacheSize as the caller left them are only hints."""
+        name = "_Z13matrixReorderP10_matrixCOO" if self.symmetric else "_Z19matrixReorder_unsymP10_matrixCOO"
+        getattr(self.lib, name)(C.byref(self.c))
         return self
 
     def key(self):
@@ -364,15 +378,18 @@ class Plan:
             pass
 
 
-def spmv_gpu_ehyb(matrix, vector_in, max_iter):
-    """spmvGPuEHYB (spmv.cu:61-133): y = A_perm * x on the GPU, 10 warm-ups + max_iter runs."""
+def spmv_gpu_ehyb(matrix, vector_in, max_iter, cfg=None, timing=False):
+    """spmvGPuEHYB (spmv.cu:61-133): y = A_perm * x on the GPU, 10 warm-ups + max_iter runs.
+    cfg None = what the drop-in symbol does by itself (storage chosen from the matrix).
+    timing=True also returns the milliseconds of the max_iter timed multiplies."""
     lib = _lib.load()
     x = np.ascontiguousarray(vector_in, dtype=np.float64)
     y = np.zeros(matrix.n, dtype=np.float64)
     it = C.c_int(0)
-    _check(lib.spmvGPuEHYB_status(C.byref(matrix.c), _ptr(x, C.c_double), _ptr(y, C.c_double), max_iter, C.byref(it)),
-           "spmvGPuEHYB")
-    return y, it.value
+    ms = C.c_double(0)
+    _check(lib.spmvGPuEHYB_cfg(C.byref(matrix.c), _ptr(x, C.c_double), _ptr(y, C.c_double), max_iter, C.byref(it),
+                               C.byref(cfg) if cfg is not None else None, C.byref(ms)), "spmvGPuEHYB")
+    return (y, it.value, ms.value) if timing else (y, it.value)
 
 
 def host_threads():

@@ -111,7 +111,16 @@ typedef struct ehyb_config {
                               of the LDS adds varies from run to run (last-bit differences).
                               1 = on -- what solver_test and bench.py choose for symmetric inputs of at
                               least EHYB_SYM_MIN_ROWS rows; 0/2 = off */
-    int32_t reserved[6];
+    int32_t part_boundary_cap; /* ints the caller's matrixCOO.partBoundary can hold.  ehyb_matrix_reorder may end
+                              with MORE partitions than m->nParts asked for (partitions whose halo overflows the
+                              window are bisected, cap_split; two-level partitions, n_top > 1) and writes
+                              nParts+1 boundaries.  0 = unknown: exactly the m->nParts+1 entries of the reference
+                              contract (spmv.h:31) -- then the partition count is never raised (no capacity
+                              split; n_top > 1 fails with EHYB_ERR_ARG if it would need more).  Matrices
+                              allocated by this library (ehyb_mm_read, ehyb_gen_*, ehyb_matrix_from_csr) hold
+                              dimension+1 entries; the reference harness callocs `dimension`
+                              (solver_test.c:42,146), which is what matrixReorder[_unsym] assume.          */
+    int32_t reserved[5];
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);
@@ -157,13 +166,18 @@ int ehyb_partition_graph(int n, const int64_t* xadj, const int* adjncy, const in
  * >= dimension entries (the reference harness callocs `dimension` ints for both).
  */
 int ehyb_matrix_reorder(matrixCOO* m, int symmetric_pattern, const ehyb_config* cfg);
+/* The same with cfg.n_top > 1 row blocks (one per GPU): block_first[b] = first partition of block b,
+ * block_first[n_top] = nParts (n_top+1 ints, caller-allocated; NULL: not wanted). */
+int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, const ehyb_config* cfg, int* block_first);
 
 /* v_rodr[list[i]] = v_in[i]  (reordering.c:380-384) */
 void ehyb_vector_reorder(int dimension, const double* v_in, double* v_rodr, const int* list);
 /* v[i] = v_rodr[list[i]]     (reordering.c:386-391) */
 void ehyb_vector_recover(int dimension, const double* v_rodr, double* v, const int* list);
 
-/* With n_top > 1: first partition of every top-level block, n_top+1 entries. */
+/* Cuts a reordered matrix into n_top runs of whole partitions with (nearly) equal entry counts:
+ * part_of_block[b] = first partition of run b, n_top+1 entries.  A pure function of m (for matrices
+ * whose two-level block boundaries were not kept; ehyb_matrix_reorder_blocks returns the real ones). */
 int ehyb_top_boundary(const matrixCOO* m, const ehyb_config* cfg, int n_top, int* part_of_block);
 
 /* ------------------------------------------------------------------- plan */
@@ -222,7 +236,9 @@ typedef struct ehyb_stats {
                                the ELL launch (ehyb_spmv is one launch), see EHYB_ARR_SLAB_META */
     int64_t sym_pairs;      /* stored entries that stand for a symmetric pair (cfg.sym_pairs): nnz_ell counts
                                both entries of such a pair, size_block_ell one                          */
-    int64_t reserved[2];
+    int64_t bytes_format_ell; /* the part of bytes_format the ELL launch moves (an inline residual included);
+                               the rest belongs to the residual launch                                   */
+    int64_t reserved[1];
 } ehyb_stats;
 int ehyb_plan_stats(const ehyb_plan* plan, ehyb_stats* out);
 
@@ -290,6 +306,17 @@ int ehyb_spmv_phase(ehyb_plan* plan, const double* x_dev, double* y_dev, void* s
  */
 int ehyb_spmv_bench(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream,
                     int warmup, int iters, double* ms_total, double* ms_ell, double* ms_er);
+
+/*
+ * spmvGPuEHYB (spmv.h) with an explicit configuration and a status code; *ms_total (may be NULL)
+ * receives the time of the MAXIter timed multiplies.  cfg == NULL is what spmvGPuEHYB itself does:
+ * every knob at its default and the storage chosen from the matrix it is handed -- symmetric pair
+ * storage iff the matrix has at least EHYB_SYM_MIN_ROWS rows, its partitions leave room for the y
+ * accumulators (they do when matrixReorder made them) and a sample of its entries has bitwise equal
+ * mirror images; no environment variable takes part.
+ */
+int spmvGPuEHYB_cfg(matrixCOO* localMatrix, const double* vectorIn, double* vectorOut, const int MAXIter,
+                    int* realIter, const ehyb_config* cfg, double* ms_total);
 
 /* Convenience: host vectors in, host vector out (H2D, `iters` multiplies, D2H). */
 int ehyb_spmv_host(ehyb_plan* plan, const double* x_host, double* y_host, int iters);

@@ -42,6 +42,22 @@ def check_rank(tag, I, J, V, cuts, rank, world, cfg, symmetric):
     assert written[:L.n_loc].min() == 1 and written.sum() == L.n_loc
     y = L.y_from_plan(y_plan[:L.n_loc])
     bad, worst = O.check_tolerance(y, y_ref, scale)
+    # the same rows with the all-gather layout: ghost columns = places inside the gathered segments
+    G = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, symmetric=symmetric, exchange="allgather")
+    seg = G.seg_len
+    assert seg == max(cuts[b + 1] - cuts[b] for b in range(world)) and G.n_ghost == L.n_ghost
+    if world > 1:
+        assert G.m.n == seg * (world + 1)
+        xg = torch.zeros(seg * (world + 1), dtype=torch.float64)
+        xg[:G.n_loc] = torch.from_numpy(G.x_to_plan(x[r0:r1]))
+        dist.all_gather_into_tensor(xg[seg:], xg[:seg].clone())
+        gplan = G.plan(upload=False)
+        ghc = gplan.array("halo_cols")
+        assert len(ghc) == 0 or ghc.max() < G.n_loc
+        yg, wg = O.walk_plan(gplan, xg.numpy())
+        assert wg[:G.n_loc].min() == 1 and wg.sum() == G.n_loc
+        bad_g, _ = O.check_tolerance(G.y_from_plan(yg[:G.n_loc]), y_ref, scale)
+        bad += bad_g
     tot = torch.tensor([float(L.n_ghost), float(len(V)), float(bad)], dtype=torch.float64)
     dist.all_reduce(tot)
     if rank == 0:

@@ -21,28 +21,57 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _bench(world, extra):
+def _bench(world, extra, workload="small", launcher=True):
+    """launcher=True: as the driver starts it (torch.distributed.run); False: `python bench.py --gpus N`
+    invoked plainly, which must start its ranks itself as a child process."""
     env = dict(os.environ, EHYB_BENCH_ONE_DEVICE="1", EHYB_BENCH_BACKEND="gloo")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
-           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"),
-           "--gpus", str(world), "--steps", "10", "--warmup", "2", "--workload", "small"] + extra
+    env.pop("WORLD_SIZE", None)
+    tail = [os.path.join(ROOT, "bench.py"), "--gpus", str(world), "--steps", "10", "--warmup", "2", "--workload", workload] + extra
+    if launcher:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(_free_port())] + tail
+    else:
+        cmd = [sys.executable] + tail
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=env, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    return json.loads(p.stdout.strip().splitlines()[-1])
+    lines = [ln for ln in p.stdout.strip().splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, p.stdout[-2000:]
+    return json.loads(lines[0])
 
 
 def test_weak_halo_exchange_two_ranks(gpu):
-    out = _bench(2, [])
+    out = _bench(2, ["--scaling", "weak"])
     assert out["n_gpus"] == 2 and out["scaling"] == "weak"
     assert out["parity"]["rows_over_1e-12"] == 0
     cfgd = out["config"]
     assert cfgd["rows"] == 2 * cfgd["rows_per_gpu"] and 0 < cfgd["ghost_slots_per_gpu_max"] < cfgd["rows_per_gpu"] // 10
 
 
+def test_strong_halo_rmat_two_ranks_self_launched(gpu):
+    """The default N > 1 mode (strong scaling of one R-MAT, halo exchange) started plainly as
+    `python bench.py --gpus 2`: the bench spawns its own ranks before touching the GPU."""
+    out = _bench(2, [], workload="rmat-18", launcher=False)
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["parity"]["rows_over_1e-12"] == 0
+    c = out["config"]
+    assert "all_to_all" in c["exchange"] and 0 < c["ghost_columns_per_gpu_max"] < c["rows"]
+    assert out["local_multiply_ms_max_over_ranks"] > 0
+
+
 def test_strong_allgather_three_ranks(gpu):
-    out = _bench(3, ["--scaling", "strong"])
+    """--exchange allgather: the padded x segments through one all-gather per step, read in place by
+    the residual phase (fem3d matrix sharded by rows, symmetric pair storage inside every block)."""
+    out = _bench(3, ["--exchange", "allgather"])
     assert out["n_gpus"] == 3 and out["scaling"] == "strong"
     assert out["parity"]["rows_over_1e-12"] == 0
+    assert "all_gather_into_tensor" in out["config"]["exchange"]
+
+
+def test_world_size_mismatch_is_refused(gpu):
+    env = dict(os.environ, WORLD_SIZE="2", RANK="0", LOCAL_RANK="0")
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "2"], capture_output=True, text=True,
+                       timeout=120, env=env, cwd=ROOT)
+    assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
 
 
 @pytest.mark.parametrize("world", [1, 2])

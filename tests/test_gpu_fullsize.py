@@ -1,5 +1,5 @@
-"""GPU parity at BASELINE.json's sizes (configs 2 and 3 in full; 4 and 5 as scaled stand-ins,
-see DESIGN.md section 7), through the plan C-ABI.  The C oracle handles 10^8 entries in about a
+"""GPU parity at BASELINE.json's sizes (configs 2-5 in full -- 4 as the 16 M-row KKT stand-in for
+nlpkkt200, 5 as R-MAT 2^24 on one GPU -- plus scaled versions of 4 and 5), through the plan C-ABI.  The C oracle handles 10^8 entries in about a
 second, so the full y is compared against it; size-independent properties (exact scaling,
 column-sum checksum, phase split) are checked as well."""
 import numpy as np
@@ -98,3 +98,55 @@ def test_config5_rmat_heavy_residual(E, O, gpu):
     mask = np.ones(c.n, dtype=bool)
     mask[split_rows] = False
     assert np.array_equal(y[mask], y_b[mask])
+
+
+def _check_scaled_and_checksum(c, plan, y_perm):
+    """The size-independent properties that need no second copy of a 16 M-row problem on the host:
+    exact power-of-two scaling and the checksum of checksums (column sums against x)."""
+    y2 = plan.spmv_host(2.0 * c.xp)
+    assert np.array_equal(y2, 2.0 * y_perm)
+    del y2
+    colsum = np.bincount(c.m.J, weights=c.m.V, minlength=c.n)
+    lhs, rhs = float(y_perm.sum()), float(colsum @ c.xp)
+    assert abs(lhs - rhs) <= 1e-11 * float(np.abs(c.m.V).sum())
+
+
+@pytest.mark.parametrize("sym", [1, 0], ids=["symmetric_pairs", "every_entry"])
+def test_config4_kkt3d_200_full(E, O, gpu, sym):
+    """BASELINE config 4 at its size: nlpkkt200 has 16.24 M rows / 448 M entries; the KKT stand-in on a
+    200^3 grid has 16.0 M rows / 365 M entries (no .mtx offline).  Full y against the C oracle.
+      symmetric_pairs  the path bench.py takes: multilevel partitioner, symmetric pair storage, every
+                       entry ends up in the LDS-fed part;
+      every_entry      plain storage on CONTIGUOUS partitions: the two halves of the saddle-point
+                       system [H A^T; A 0] are 8 M rows apart and a grid neighbour 40,000 rows away, so
+                       most couplings miss the window -- the residual-heavy shape config 4 is listed
+                       for ("wavefront-reduce stress")."""
+    cfg = E.make_config(sym_pairs=sym, partitioner=E.EHYB_PART_AUTO if sym else E.EHYB_PART_CONTIGUOUS)
+    c = Case(E, O, "kkt3d", (200,), cfg)
+    assert c.n == 16_000_000 and c.nnz > 360_000_000
+    plan = E.Plan(c.m, cfg)
+    st = plan.stats
+    assert (st["sym_pairs"] > 0) == bool(sym)
+    if not sym:
+        assert st["nnz_er"] > 0.2 * st["nnz"]
+    y = plan.spmv_host(c.xp)
+    bad, worst = c.check(y)
+    assert bad == 0, f"worst {worst:.3e}"
+    _check_scaled_and_checksum(c, plan, y)
+
+
+def test_config5_rmat24_one_gpu(E, O, gpu):
+    """BASELINE config 5's matrix on one GPU: R-MAT 2^24 rows, 2^27 edge samples (132.7 M entries after
+    merging duplicates), hub rows of > 100,000 entries split into atomically combined segments, four
+    fifths of the entries in the residual.  A graph partitioner finds nothing to cut in R-MAT (124 M of
+    133 M edges cut after two minutes): contiguous partitions, as bench.py uses for this workload."""
+    cfg = E.make_config(partitioner=E.EHYB_PART_CONTIGUOUS)
+    c = Case(E, O, "rmat", (24, 1 << 27, 1), cfg)
+    assert c.n == 1 << 24 and 1.2e8 < c.nnz < 1.35e8
+    plan = E.Plan(c.m, cfg)
+    st = plan.stats
+    assert st["nnz_er"] > st["nnz_ell"] and st["max_row"] > 100_000
+    y = plan.spmv_host(c.xp)
+    bad, worst = c.check(y)
+    assert bad == 0, f"worst {worst:.3e}"
+    _check_scaled_and_checksum(c, plan, y)

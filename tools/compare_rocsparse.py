@@ -24,6 +24,37 @@ def build():
                         "-Wl,-rpath,/opt/rocm/lib", "-o", LIB], check=True)
 
 
+def rocsparse_arm(E, O, np, gen, gargs, x, y_ref, scale, iters=100, algs=(("default", 0), ("adaptive", 2), ("lrb", 7))):
+    """rocSPARSE CSR SpMV (generic API) on the same matrix, same GPU, same timing protocol; every
+    result checked against the CPU oracle.  -> {"best": {...}, name: {...}} (bench.py --vendor-baseline)."""
+    build()
+    lib = C.CDLL(LIB)
+    m = E.Matrix.generate(gen, *gargs)
+    n, nnz = m.n, m.nnz
+    rp, J, V = m.row_idx.copy(), m.J.copy(), m.V.copy()
+    m.free()
+    dp, ip = C.POINTER(C.c_double), C.POINTER(C.c_int)
+    out = {}
+    for name, alg in algs:
+        y = np.zeros(n)
+        ms, pre = C.c_double(), C.c_double()
+        rc = lib.rocsparse_csr_spmv_bench(n, C.c_int64(nnz), rp.ctypes.data_as(ip), J.ctypes.data_as(ip),
+                                          V.ctypes.data_as(dp), np.ascontiguousarray(x).ctypes.data_as(dp), y.ctypes.data_as(dp), alg, 10,
+                                          iters, C.byref(ms), C.byref(pre))
+        if rc != 0:
+            out[name] = {"error": rc}
+            continue
+        bad, worst = O.check_tolerance(y, y_ref, scale)
+        out[name] = {"ms_per_spmv": round(ms.value, 5), "GFLOP/s": round(2.0 * nnz / ms.value / 1e6, 2),
+                     "preprocess_ms": round(pre.value, 3), "rows_over_1e-12": bad}
+    ok = {k: v for k, v in out.items() if "ms_per_spmv" in v and v["rows_over_1e-12"] == 0}
+    if ok:
+        b = min(ok, key=lambda k: ok[k]["ms_per_spmv"])
+        out["best"] = dict(ok[b], algorithm=b)
+    out["library"] = "rocSPARSE rocsparse_spmv, CSR, fp64 (tools/rocsparse_baseline.cpp); not part of the product path"
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="audikw_1-like")

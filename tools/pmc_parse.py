@@ -1,7 +1,10 @@
 #!/usr/bin/env python3
-"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) into profiles/pmc_latest.json.
+"""Turn the two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE) of tools/pmc_run.py into a JSON summary
+and, with --table, merge it into profiles/pmc_traffic.json -- the table bench.py reads
+`roofline.traffic` from, keyed by workload | storage | kernel so that a measurement is only ever
+quoted for the case it was taken on.
 
-usage: python tools/pmc_parse.py <fetch_dir> <write_dir> <out.json>
+usage: python tools/pmc_parse.py <fetch_dir> <write_dir> <out.json> [--workload W --storage sym|plain --round rNN_x --table profiles/pmc_traffic.json]
 
 Units and corrections as MI355X_MICROARCH.md (HBM / rocprofv3) prescribes: the counters are in
 KiB; on gfx950 FETCH_SIZE reports exactly half of a wide coalesced streaming read, so it is
@@ -29,6 +32,7 @@ def per_kernel(dirpath, counter):
 
 def main():
     fetch_dir, write_dir, out_path = sys.argv[1:4]
+    opts = dict(zip(sys.argv[4::2], sys.argv[5::2]))
     fetch = per_kernel(fetch_dir, "FETCH_SIZE")
     write = per_kernel(write_dir, "WRITE_SIZE")
     res = {"units": "bytes per launch; counters are KiB", "kernels": {}}
@@ -55,7 +59,21 @@ def main():
             res["ehyb_ell_kernel_hbm_bytes_per_launch"] = k["hbm_bytes_per_launch"]
         if "ehyb_er_kernel" in name and k["hbm_bytes_per_launch"]:
             res["ehyb_er_kernel_hbm_bytes_per_launch"] = k["hbm_bytes_per_launch"]
+    res["workload"], res["storage"] = opts.get("--workload"), opts.get("--storage")
     json.dump(res, open(out_path, "w"), indent=1)
+    if "--table" in opts and res["workload"] and res["storage"]:
+        try:
+            tab = json.load(open(opts["--table"]))
+        except (OSError, ValueError):
+            tab = {"units": "HBM bytes per launch = FETCH_SIZE x calibrated factor + WRITE_SIZE (separate --pmc passes)", "entries": {}}
+        for name, k in res["kernels"].items():
+            base = "ehyb_ell_kernel" if "ehyb_ell_kernel" in name else ("ehyb_er_kernel" if "ehyb_er_kernel" in name else None)
+            if base and k["hbm_bytes_per_launch"]:
+                tab["entries"][f"{res['workload']}|{res['storage']}|{base}"] = {
+                    "hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "fetch_bytes_corrected": k["fetch_bytes_corrected"],
+                    "write_bytes": k["WRITE_SIZE_bytes"], "fetch_factor": factor, "instantiation": name,
+                    "launches": k["launches"], "evidence": opts.get("--round")}
+        json.dump(tab, open(opts["--table"], "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1))
 
 

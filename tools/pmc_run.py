@@ -28,7 +28,8 @@ def main():
     bw = C.c_double()
     lib.ehyb_measure_read_bw(1 << 30, 5, C.byref(bw))  # 8 launches of ehyb_read_kernel over 1 GiB
     gen, gargs, _ = B.WORKLOADS[args.workload]
-    cfg = E.make_config(sym_pairs=1 if (gen in B.SYMMETRIC_GENERATORS and not args.plain) else 0)  # as bench.py does
+    sym = B.symmetric_storage_pays(gen, gargs) and not args.plain  # as bench.py does
+    cfg = E.make_config(sym_pairs=1 if sym else 0, partitioner=B.partitioner_for(E, gen))
     m = E.Matrix.generate(gen, *gargs, cfg=cfg)
     x = E.x_glibc(m.n)
     m.reorder(cfg)
@@ -39,7 +40,7 @@ def main():
         plan.spmv(dx.ptr, dy.ptr)
     lib.ehyb_dev_sync()
     st = plan.stats
-    print("PMC_RUN", {k: st[k] for k in ("nnz", "nnz_ell", "nnz_er", "size_block_ell", "bytes_format", "bytes_alg", "n_items", "window_loads")})
+    print("PMC_RUN", args.workload, "sym" if st["sym_pairs"] else "plain", {k: st[k] for k in ("nnz", "nnz_ell", "nnz_er", "size_block_ell", "bytes_format", "bytes_alg", "n_items", "window_loads")})
 
 
 if __name__ == "__main__":
