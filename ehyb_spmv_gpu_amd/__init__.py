@@ -7,6 +7,7 @@ raises if it has not been built.
 from . import host  # noqa: F401
 from .host import (  # noqa: F401
     ARRAYS,
+    EHYB_PART_AUTO,
     EHYB_PART_CONTIGUOUS,
     EHYB_PART_MTMETIS,
     EHYB_PART_MULTILEVEL,

@@ -56,7 +56,10 @@ class Config(C.Structure):
         ("hub_rule", C.c_int32),
         ("sym_pairs", C.c_int32),
         ("part_boundary_cap", C.c_int32),
-        ("reserved", C.c_int32 * 5),
+        ("er_mode", C.c_int32),
+        ("er_panel_cols", C.c_int32),
+        ("er_block_rows", C.c_int32),
+        ("reserved", C.c_int32 * 2),
     ]
 
 
@@ -64,12 +67,12 @@ _STAT_NAMES = [
     "nnz", "nnz_ell", "nnz_er", "ell_padding", "size_block_ell", "size_er", "rows_er",
     "er_segments", "n_rows", "n_cols", "n_parts", "n_slabs", "n_items", "halo_cols",
     "window_loads", "bytes_format", "bytes_alg", "max_row", "lds_bytes", "col_words",
-    "er_inline", "sym_pairs", "bytes_format_ell",
+    "er_inline", "sym_pairs", "bytes_format_ell", "er_partials",
 ]
 
 
 class Stats(C.Structure):
-    _fields_ = [(n, C.c_int64) for n in _STAT_NAMES] + [("reserved", C.c_int64 * 1)]
+    _fields_ = [(n, C.c_int64) for n in _STAT_NAMES]
 
     def as_dict(self):
         return {n: int(getattr(self, n)) for n in _STAT_NAMES}

@@ -114,6 +114,9 @@ Config resolve_config(const ehyb_config* in)
     c.cap_split = z.cap_split == 2 ? 2 : 1;
     c.hub_rule = z.hub_rule == 2 ? 2 : 1;
     c.part_boundary_cap = z.part_boundary_cap > 0 ? z.part_boundary_cap : 0;
+    c.er_mode = (z.er_mode == 1 || z.er_mode == 2) ? z.er_mode : 0;
+    c.er_panel_cols = z.er_panel_cols > 0 ? std::min(16384, std::max(256, round_down(z.er_panel_cols, 64))) : 8192;
+    c.er_block_rows = z.er_block_rows > 0 ? std::min(16384, std::max(64, z.er_block_rows)) : 8192;
     // symmetric pairs: whole rows may not leave the ELL part (a residual row cannot scatter): no hub rule
     if (c.sym_pairs == 1) {
         c.part_rows = std::max(kSlabRows, std::min(c.part_rows, round_down(c.lds_doubles * 3 / 10, kSlabRows)));
@@ -160,6 +163,9 @@ void ehyb_config_resolve(const ehyb_config* in, ehyb_config* out)
     r.hub_rule = c.hub_rule;
     r.sym_pairs = c.sym_pairs;
     r.part_boundary_cap = c.part_boundary_cap;
+    r.er_mode = c.er_mode;
+    r.er_panel_cols = c.er_panel_cols;
+    r.er_block_rows = c.er_block_rows;
     *out = r;
 }
 

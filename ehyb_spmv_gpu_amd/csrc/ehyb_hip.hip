@@ -326,6 +326,105 @@ __global__ __launch_bounds__(THREADS) void ehyb_er_kernel(const int4* __restrict
         er_bin<4, THREADS>(b.x, b.y, seg_ptr, seg_row, col, val, x, y);
 }
 
+// ------------------------------------------------------------------ panel residual (er_panel.cpp)
+// Segmented sum over the lanes of a wave: lanes that are neighbours and hold the same key form a run;
+// afterwards the FIRST lane of every run holds the run's sum.  (Runs are contiguous, so "key of lane
+// l + d equals mine" implies every lane in between does too.)
+template <class K>
+__device__ __forceinline__ double run_sum(double v, K key, int lane)
+{
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const double t = __shfl_down(v, d, 64);
+        const K k = __shfl_down(key, d, 64);
+        if (lane + d < 64 && k == key) v += t;
+    }
+    return v;
+}
+
+// Pass 1: one workgroup per unit {first column, columns, first entry, end entry}.  The unit's panel of
+// x is staged in LDS; (value, 16-bit local column, slot) are streamed, four 64-entry chunks per wave
+// and step (twelve independent loads in flight), the products of one row that sit next to each other
+// in a chunk are summed across the lanes and the first lane of each such piece stores the partial.
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __restrict__ units,
+                                                                const double* __restrict__ val,
+                                                                const uint16_t* __restrict__ col,
+                                                                const uint32_t* __restrict__ dst,
+                                                                const double* __restrict__ x,
+                                                                double* __restrict__ partial)
+{
+    extern __shared__ __attribute__((aligned(16))) double win[];
+    constexpr int WAVES = THREADS / 64;
+    const int4 u = units[blockIdx.x];
+    const double* __restrict__ xp = x + u.x;
+    for (int i = threadIdx.x; i < u.y; i += THREADS) win[i] = xp[i];
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c0 = u.z >> 6, c1 = u.w >> 6;  // chunks of 64 entries
+    for (int c = c0 + 4 * wave; c < c1; c += 4 * WAVES) {
+        double v[4];
+        uint32_t cc[4], d[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const bool in = c + j < c1;
+            const size_t pos = (size_t)(in ? c + j : c) * 64 + lane;
+            v[j] = val[pos];
+            cc[j] = col[pos];
+            d[j] = in ? dst[pos] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double prod = v[j] * win[cc[j]];
+            const double sum = run_sum(prod, d[j], lane);
+            const uint32_t before = __shfl_up(d[j], 1, 64);
+            if ((lane == 0 || before != d[j]) && d[j] != 0xFFFFFFFFu) partial[d[j]] = sum;
+        }
+    }
+}
+
+// Pass 2: one workgroup per unit {first partial, end partial, first row, rows}.  The row block's
+// accumulators live in LDS; (partial, 16-bit local row) are streamed, equal neighbouring rows summed
+// across lanes first, then one ds_add_f64 per run; finally y[row] += accumulator for the rows that
+// received something (the ELL launch has written y before).
+template <int THREADS>
+__global__ __launch_bounds__(THREADS) void ehyb_pb_reduce_kernel(const int4* __restrict__ units,
+                                                                 const double* __restrict__ partial,
+                                                                 const uint16_t* __restrict__ row,
+                                                                 double* __restrict__ y)
+{
+    extern __shared__ __attribute__((aligned(16))) double yacc[];
+    const int4 u = units[blockIdx.x];
+    for (int i = threadIdx.x; i < u.w; i += THREADS) yacc[i] = 0.0;
+    __syncthreads();
+    const int lane = threadIdx.x & 63;
+    // every wave runs the same number of steps (the shuffles need all 64 lanes)
+    for (int base = u.x; base < u.y; base += 4 * THREADS) {
+        double v[4];
+        uint32_t r[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const int i = base + j * THREADS + (int)threadIdx.x;
+            const bool in = i < u.y;
+            v[j] = in ? partial[i] : 0.0;
+            r[j] = in ? (uint32_t)row[i] : 0xFFFFFFFFu;
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const double sum = run_sum(v[j], r[j], lane);
+            const uint32_t before = __shfl_up(r[j], 1, 64);
+            if ((lane == 0 || before != r[j]) && r[j] != 0xFFFFFFFFu) unsafeAtomicAdd(&yacc[r[j]], sum);  // ds_add_f64
+        }
+    }
+    __syncthreads();
+    double* __restrict__ yp = y + u.z;
+    for (int i = threadIdx.x; i < u.w; i += THREADS) {
+        const double a = yacc[i];
+        if (a != 0.0) yp[i] += a;
+    }
+}
+
 // streaming-read probe for the on-box bandwidth ceiling
 __global__ __launch_bounds__(256) void ehyb_read_kernel(const double2* __restrict__ src, size_t n2, double* sink)
 {
@@ -413,6 +512,15 @@ static int launch_er(ehyb_plan* P, const double* x, double* y, hipStream_t st)
 {
     const HostLayout& H = P->host;
     if (H.er_bins[3] == 0) return EHYB_OK;
+    if (H.er_panel) {  // panel form: scale (x panels in LDS) then reduce (y blocks in LDS)
+        const int u1 = (int)(H.pb_units1.size() / 4), u2 = (int)(H.pb_units2.size() / 4);
+        hipLaunchKernelGGL(ehyb_pb_scale_kernel<512>, dim3(u1), dim3(512), (size_t)H.pb_panel_cols * 8, st, (const int4*)P->d_pb_units1,
+                           P->d_pb_val, P->d_pb_col, P->d_pb_dst, x, P->d_pb_partial);
+        hipLaunchKernelGGL(ehyb_pb_reduce_kernel<512>, dim3(u2), dim3(512), (size_t)H.pb_rows_max * 8, st, (const int4*)P->d_pb_units2,
+                           P->d_pb_partial, P->d_pb_row, y);
+        HIP_TRY(hipGetLastError());
+        return EHYB_OK;
+    }
     const int n_blocks = (int)(H.er_blocks.size() / 4);
     if (P->cfg.er_threads != 256) EHYB_FAIL(EHYB_ERR_ARG, "residual workgroup size %d not built (256)", P->cfg.er_threads);
     hipLaunchKernelGGL(ehyb_er_kernel<256>, dim3(n_blocks), dim3(256), 0, st, (const int4*)P->d_er_blocks,
@@ -444,7 +552,8 @@ static void free_device(ehyb_plan* P)
     void** ptrs[] = {(void**)&P->d_halo_cols,  (void**)&P->d_ell_val,   (void**)&P->d_ell_col,    (void**)&P->d_lane_group,
                      (void**)&P->d_slab_meta,  (void**)&P->d_items,     (void**)&P->d_segs,       (void**)&P->d_er_seg_ptr,
                      (void**)&P->d_er_seg_row, (void**)&P->d_er_col,    (void**)&P->d_er_val,     (void**)&P->d_er_blocks,
-                     (void**)&P->d_slab_lrow};
+                     (void**)&P->d_slab_lrow,  (void**)&P->d_pb_val,    (void**)&P->d_pb_col,     (void**)&P->d_pb_dst,
+                     (void**)&P->d_pb_units1,  (void**)&P->d_pb_row,    (void**)&P->d_pb_units2,  (void**)&P->d_pb_partial};
     for (void** q : ptrs) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
@@ -579,12 +688,26 @@ int ehyb_plan_upload(ehyb_plan* P)
     UP(d_slab_meta, slab_meta)
     UP(d_items, items)
     UP(d_segs, segs)
-    UP(d_er_seg_ptr, er_seg_ptr)
-    UP(d_er_seg_row, er_seg_row)
-    UP(d_er_col, er_col)
-    UP(d_er_val, er_val)
-    UP(d_er_blocks, er_blocks)
     UP(d_slab_lrow, slab_lrow)
+    if (H.er_panel) {
+        // the residual launch runs the panel form: the CSR segments stay on the host
+        UP(d_pb_val, pb_val)
+        UP(d_pb_col, pb_col)
+        UP(d_pb_dst, pb_dst)
+        UP(d_pb_units1, pb_units1)
+        UP(d_pb_row, pb_row)
+        UP(d_pb_units2, pb_units2)
+        if (hipMalloc((void**)&P->d_pb_partial, (size_t)std::max<int64_t>(H.pb_partials, 1) * 8) != hipSuccess) {
+            free_device(P);
+            EHYB_FAIL(EHYB_ERR_HIP, "ehyb_plan_upload: no device memory for %lld partial sums", (long long)H.pb_partials);
+        }
+    } else {
+        UP(d_er_seg_ptr, er_seg_ptr)
+        UP(d_er_seg_row, er_seg_row)
+        UP(d_er_col, er_col)
+        UP(d_er_val, er_val)
+        UP(d_er_blocks, er_blocks)
+    }
 #undef UP
     // opt in to the full 160 KiB of LDS (the role of cudaFuncSetAttribute at kernel.cu:351,411).  The
     // attribute belongs to the kernel, not to a plan: it is set to the device maximum, so plans with
@@ -602,6 +725,8 @@ int ehyb_plan_upload(ehyb_plan* P)
     LDS_ATTR_T(256)
     LDS_ATTR_T(512)
     LDS_ATTR_T(1024)
+    LDS_ATTR(ehyb_pb_scale_kernel<512>)
+    LDS_ATTR(ehyb_pb_reduce_kernel<512>)
 #undef LDS_ATTR_T
 #undef LDS_ATTR_S
 #undef LDS_ATTR

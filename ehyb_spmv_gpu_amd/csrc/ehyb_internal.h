@@ -44,6 +44,9 @@ struct Config {
     int hub_rule;
     int sym_pairs;
     int part_boundary_cap;  // ints the caller's partBoundary holds; 0 = m->nParts + 1, never more
+    int er_mode;            // 0 automatic, 1 CSR segments, 2 panel form
+    int er_panel_cols;
+    int er_block_rows;
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -102,10 +105,24 @@ struct HostLayout {
     int yacc_doubles = 0;
     std::vector<uint16_t> slab_lrow;  // [n_slabs*64] sym only: image-local row of every lane (0xFFFF: none)
 
+    // panel form of a large residual (er_panel.cpp): two streaming passes instead of gathers from global memory
+    bool er_panel = false;
+    int pb_panel_cols = 0;            // columns per x panel (LDS of pass 1)
+    int pb_rows_max = 0;              // rows of the largest row block (LDS of pass 2)
+    int64_t pb_partials = 0;
+    int64_t pb_bytes = 0;             // bytes both passes move per multiply
+    std::vector<double> pb_val;       // pass-1 order, panels padded to multiples of 64 entries
+    std::vector<uint16_t> pb_col;     // column - panel start
+    std::vector<uint32_t> pb_dst;     // partial slot; 0xFFFFFFFF = padding
+    std::vector<int32_t> pb_units1;   // {first column, columns, first entry, end entry}
+    std::vector<uint16_t> pb_row;     // per partial: row - first row of its block
+    std::vector<int32_t> pb_units2;   // {first partial, end partial, first row, rows}
+
     ehyb_stats stats{};
 };
 
 int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* out);
+int build_panel_residual(const Config& cfg, HostLayout* L);  // er_panel.cpp; reads the CSR residual of *L
 bool sym_storage_suits(const matrixCOO* m);  // spmvGPuEHYB's own choice of the storage (plan.cpp)
 
 // ---------------------------------------------------------------- partitioner
@@ -168,4 +185,11 @@ struct ehyb_plan {
     double* d_er_val = nullptr;
     int32_t* d_er_blocks = nullptr;
     uint16_t* d_slab_lrow = nullptr;
+    double* d_pb_val = nullptr;
+    uint16_t* d_pb_col = nullptr;
+    uint32_t* d_pb_dst = nullptr;
+    int32_t* d_pb_units1 = nullptr;
+    uint16_t* d_pb_row = nullptr;
+    int32_t* d_pb_units2 = nullptr;
+    double* d_pb_partial = nullptr;  // [pb_partials] written by pass 1, read by pass 2: one multiply at a time per plan
 };

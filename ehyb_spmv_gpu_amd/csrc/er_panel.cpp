@@ -1,0 +1,207 @@
+// Panel form of a LARGE residual: the random gather of x is traded for two streaming passes.
+//
+// The reference multiplies its residual ("ER") rows straight from global memory: value and column
+// streamed, x[column] gathered wherever it lies (kernel.cu:169-194).  On a matrix without locality
+// (R-MAT) nearly every such gather misses the 4 MiB L2 of its XCD and moves a whole sector over the
+// fabric for 8 useful bytes: the CSR residual kernel of this library (ehyb_er_kernel) spends 243 us on
+// the 23 M residual entries of R-MAT 2^22 -- about 64 B of fabric traffic per entry besides the 12 B it
+// streams.  The explicit cache of the ELL part (x window in LDS) removes exactly that cost, but only
+// for columns near the row's own partition.  This form extends the idea to ALL columns:
+//
+//   pass 1 "scale"   entries grouped by COLUMN PANEL (pb_panel_cols consecutive columns).  A workgroup
+//                    stages its panel of x in LDS (coalesced) and streams (value, 16-bit local column,
+//                    slot): product = value * x_lds[column]; products of one row that sit next to
+//                    each other inside a 64-entry chunk are summed across lanes and ONE partial per
+//                    such piece is written to partial[slot] -- a hub row of 50,000 entries leaves a
+//                    few hundred partials.
+//   pass 2 "reduce"  partials grouped by ROW BLOCK (consecutive rows holding about equally many
+//                    partials, at most pb_rows_max rows).  A workgroup keeps the block's y
+//                    accumulators in LDS, streams (partial, 16-bit local row), adds (ds_add_f64; equal
+//                    neighbouring rows summed across lanes first) and finally y[row] += accumulator.
+//
+// Inside a panel the entries are ordered by row, and the partial slots are numbered by (row block,
+// panel, row): a pass-1 workgroup writes runs of consecutive slots, a pass-2 workgroup reads ONE
+// contiguous range.  Every byte of both passes is streamed: 14 B read + <= 8 B written + <= 10 B read
+// per entry instead of 12 B + a sector.  Rows of any length and any skew are fine; no global atomics.
+#include "ehyb_internal.h"
+
+#include <omp.h>
+
+#include <algorithm>
+#include <numeric>
+
+namespace ehyb {
+
+int build_panel_residual(const Config& cfg, HostLayout* L)
+{
+    const int64_t nnz_er = (int64_t)L->er_col.size();
+    const int64_t nseg = (int64_t)L->er_seg_row.size();
+    const int n_cols = L->n_cols;
+    const int W = cfg.er_panel_cols;
+    const int rows_max = cfg.er_block_rows;
+    L->er_panel = false;
+    if (nnz_er == 0) return EHYB_OK;
+    if (nnz_er + 64 * ((int64_t)n_cols / W + 2) >= 0x7FFFFF00ll)
+        EHYB_FAIL(EHYB_ERR_ARG, "build_panel_residual: residual of %lld entries too large for 32-bit offsets", (long long)nnz_er);
+
+    // ---- (row, column, value) of every residual entry, from the CSR segments
+    std::vector<int32_t> erow((size_t)nnz_er);
+#pragma omp parallel for schedule(static, 1024)
+    for (int64_t s = 0; s < nseg; ++s) {
+        const int32_t r = L->er_seg_row[s] & 0x7FFFFFFF;
+        for (int64_t k = L->er_seg_ptr[s]; k < L->er_seg_ptr[s + 1]; ++k) erow[(size_t)k] = r;
+    }
+    const int32_t* ecol = L->er_col.data();
+    const double* evalv = L->er_val.data();
+
+    // ---- row blocks: consecutive rows with about `target` entries each, at most rows_max rows
+    const int row_begin = L->row_begin, nrows = L->row_end - L->row_begin;
+    std::vector<int32_t> cnt_row((size_t)nrows, 0);
+    for (int64_t k = 0; k < nnz_er; ++k) {
+        const int r = erow[(size_t)k] - row_begin;
+        if ((unsigned)r >= (unsigned)nrows) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_panel_residual: residual row outside the plan's rows");
+        ++cnt_row[r];
+    }
+    const int64_t target = std::min<int64_t>(std::max<int64_t>(nnz_er / 2048, 4096), 1 << 20);
+    std::vector<int32_t> rb_first;  // first row (plan numbering) of every block, + end
+    std::vector<int32_t> rb_of_row((size_t)nrows);
+    {
+        int64_t acc = 0;
+        int first = 0;
+        rb_first.push_back(row_begin);
+        for (int r = 0; r < nrows; ++r) {
+            // close the block in front of this row if taking it would overshoot
+            if (r > first && (acc + cnt_row[r] > target || r - first >= rows_max)) {
+                rb_first.push_back(row_begin + r);
+                first = r;
+                acc = 0;
+            }
+            rb_of_row[r] = (int32_t)rb_first.size() - 1;
+            acc += cnt_row[r];
+        }
+        rb_first.push_back(row_begin + nrows);
+    }
+    const int n_rb = (int)rb_first.size() - 1;
+
+    // ---- pass-1 order: by panel (counting sort), inside a panel by (row, column)
+    const int n_panels = (n_cols + W - 1) / W;
+    std::vector<int64_t> pcount((size_t)n_panels + 1, 0);
+    for (int64_t k = 0; k < nnz_er; ++k) {
+        if ((unsigned)ecol[k] >= (unsigned)n_cols) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_panel_residual: column outside the matrix");
+        ++pcount[(size_t)(ecol[k] / W) + 1];
+    }
+    for (int p = 0; p < n_panels; ++p) pcount[p + 1] += pcount[p];
+    std::vector<uint32_t> order((size_t)nnz_er);
+    {
+        std::vector<int64_t> fill(pcount.begin(), pcount.end() - 1);
+        for (int64_t k = 0; k < nnz_er; ++k) order[(size_t)fill[ecol[k] / W]++] = (uint32_t)k;
+    }
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int p = 0; p < n_panels; ++p)
+        std::sort(order.begin() + pcount[p], order.begin() + pcount[p + 1], [&](uint32_t a, uint32_t b) {
+            return erow[a] != erow[b] ? erow[a] < erow[b] : (ecol[a] != ecol[b] ? ecol[a] < ecol[b] : a < b);
+        });
+
+    // ---- padded positions: every panel starts on a multiple of 64 entries
+    std::vector<int64_t> pstart((size_t)n_panels + 1, 0);
+    for (int p = 0; p < n_panels; ++p) pstart[p + 1] = pstart[p] + (pcount[p + 1] - pcount[p] + 63) / 64 * 64;
+    const int64_t padded = pstart[n_panels];
+    L->pb_val.assign((size_t)padded, 0.0);
+    L->pb_col.assign((size_t)padded, 0);
+    L->pb_dst.assign((size_t)padded, 0xFFFFFFFFu);
+
+    // ---- pieces: runs of one row inside a 64-entry chunk of a panel, numbered in pass-1 order
+    // piece_of[pos] (temporarily in pb_dst), and per piece its row
+    std::vector<int32_t> piece_row;
+    std::vector<int64_t> panel_piece0((size_t)n_panels + 1, 0);
+    {
+        // count first (parallel), then fill
+        std::vector<int64_t> pieces_in((size_t)n_panels, 0);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int p = 0; p < n_panels; ++p) {
+            int64_t c = 0;
+            const int64_t b = pcount[p], e = pcount[p + 1];
+            for (int64_t k = b; k < e; ++k)
+                if (k == b || ((k - b) & 63) == 0 || erow[order[(size_t)k]] != erow[order[(size_t)k - 1]]) ++c;
+            pieces_in[p] = c;
+        }
+        for (int p = 0; p < n_panels; ++p) panel_piece0[p + 1] = panel_piece0[p] + pieces_in[p];
+        const int64_t n_pieces = panel_piece0[n_panels];
+        if (n_pieces >= 0x7FFFFF00ll) EHYB_FAIL(EHYB_ERR_ARG, "build_panel_residual: too many partial sums");
+        piece_row.resize((size_t)n_pieces);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (int p = 0; p < n_panels; ++p) {
+            int64_t piece = panel_piece0[p] - 1;
+            const int64_t b = pcount[p], e = pcount[p + 1];
+            for (int64_t k = b; k < e; ++k) {
+                const uint32_t src = order[(size_t)k];
+                if (k == b || ((k - b) & 63) == 0 || erow[src] != erow[order[(size_t)k - 1]]) piece_row[(size_t)++piece] = erow[src];
+                const int64_t pos = pstart[p] + (k - b);
+                L->pb_val[(size_t)pos] = evalv[src];
+                L->pb_col[(size_t)pos] = (uint16_t)(ecol[src] - p * W);
+                L->pb_dst[(size_t)pos] = (uint32_t)piece;
+            }
+        }
+    }
+    const int64_t n_pieces = (int64_t)piece_row.size();
+
+    // ---- slots: pieces in (row block, panel, pass-1 order) = stable counting sort by row block
+    std::vector<int64_t> rb_count((size_t)n_rb + 1, 0);
+    for (int64_t j = 0; j < n_pieces; ++j) ++rb_count[(size_t)rb_of_row[piece_row[(size_t)j] - row_begin] + 1];
+    for (int b = 0; b < n_rb; ++b) rb_count[b + 1] += rb_count[b];
+    std::vector<uint32_t> slot_of_piece((size_t)n_pieces);
+    L->pb_row.assign((size_t)n_pieces, 0);
+    {
+        std::vector<int64_t> fill(rb_count.begin(), rb_count.end() - 1);
+        for (int64_t j = 0; j < n_pieces; ++j) {
+            const int r = piece_row[(size_t)j];
+            const int b = rb_of_row[r - row_begin];
+            const int64_t s = fill[b]++;
+            slot_of_piece[(size_t)j] = (uint32_t)s;
+            L->pb_row[(size_t)s] = (uint16_t)(r - rb_first[b]);
+        }
+    }
+#pragma omp parallel for schedule(static, 65536)
+    for (int64_t pos = 0; pos < padded; ++pos)
+        if (L->pb_dst[(size_t)pos] != 0xFFFFFFFFu) L->pb_dst[(size_t)pos] = slot_of_piece[L->pb_dst[(size_t)pos]];
+
+    // ---- work units
+    // pass 1: {first column, columns, first entry, end entry} -- chunks of a panel, multiples of 64 entries
+    const int64_t c1 = std::min<int64_t>(std::max<int64_t>((padded / 2048 + 63) / 64 * 64, 8192), 65536);
+    L->pb_units1.clear();
+    int64_t staged = 0;
+    for (int p = 0; p < n_panels; ++p)
+        for (int64_t b = pstart[p]; b < pstart[p + 1]; b += c1) {
+            const int32_t u[4] = {p * W, std::min(W, n_cols - p * W), (int32_t)b, (int32_t)std::min(b + c1, pstart[p + 1])};
+            L->pb_units1.insert(L->pb_units1.end(), u, u + 4);
+            staged += u[1];
+        }
+    // pass 2: {first slot, end slot, first row, rows}; blocks without partials are skipped
+    L->pb_units2.clear();
+    int max_rows = 0;
+    int64_t rows_touched = 0;
+    for (int b = 0; b < n_rb; ++b) {
+        if (rb_count[b + 1] == rb_count[b]) continue;
+        const int32_t u[4] = {(int32_t)rb_count[b], (int32_t)rb_count[b + 1], rb_first[b], rb_first[b + 1] - rb_first[b]};
+        L->pb_units2.insert(L->pb_units2.end(), u, u + 4);
+        max_rows = std::max(max_rows, u[3]);
+        rows_touched += u[3];
+    }
+    L->pb_panel_cols = W;
+    L->pb_rows_max = max_rows;
+    L->pb_partials = n_pieces;
+    L->er_panel = true;
+    // bytes the two launches move: entries (value, column, slot) + the staged panels + partials out;
+    // partials (value, row) in + the touched y rows read and written
+    L->pb_bytes = 14 * padded + 8 * staged + 8 * n_pieces + 10 * n_pieces + 16 * L->stats.rows_er +
+                  16 * (int64_t)(L->pb_units1.size() / 4 + L->pb_units2.size() / 4);
+    if (cfg.verbose)
+        printf("panel residual: %lld entries (%lld with padding) in %d panels of %d columns -> %lld partials, %zu + %zu work units, "
+               "row blocks <= %d rows\n",
+               (long long)nnz_er, (long long)padded, n_panels, W, (long long)n_pieces, L->pb_units1.size() / 4, L->pb_units2.size() / 4,
+               max_rows);
+    (void)rows_touched;
+    return EHYB_OK;
+}
+
+}  // namespace ehyb

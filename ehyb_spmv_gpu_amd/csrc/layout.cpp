@@ -749,8 +749,15 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             }
         }
     }
-    // ---- statistics (convert.c:140,310; spmv.cu:82)
+    // ---- a large residual also gets its panel form (er_panel.cpp): what the residual launch then runs
     ehyb_stats& st = L->stats;
+    st.rows_er = rows_er;
+    L->er_panel = false;
+    if (!L->inline_er && nnz_er > 0 && (cfg.er_mode == 2 || (cfg.er_mode == 0 && nnz_er >= (1 << 21)))) {
+        const int rc_pb = build_panel_residual(cfg, L);
+        if (rc_pb != EHYB_OK) return rc_pb;
+    }
+    // ---- statistics (convert.c:140,310; spmv.cu:82)
     st.nnz = nnz;
     st.nnz_ell = nnz_ell;
     st.nnz_er = nnz_er;
@@ -781,7 +788,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                           4 * halo_item_loads + 8 * (int64_t)nrows + (L->inline_er ? 8 * st.er_inline + 8 * nnz_er : 0);
     // residual launch: (column, value) streamed, one 8-byte gather of x per entry (at least: a random
     // gather moves a whole sector), per segment its pointer, row and block share, and y read + written
-    st.bytes_format = st.bytes_format_ell + (L->inline_er ? 0 : 12 * nnz_er + 8 * nnz_er + 12 * nseg + 16 * nseg);
+    st.bytes_format = st.bytes_format_ell + (L->inline_er ? 0 : (L->er_panel ? L->pb_bytes : 12 * nnz_er + 8 * nnz_er + 12 * nseg + 16 * nseg));
+    st.er_partials = L->er_panel ? L->pb_partials : 0;
     if (nnz_ell + nnz_er != nnz) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: %lld + %lld != %lld", (long long)nnz_ell, (long long)nnz_er, (long long)nnz);
     if (sym) {
         int64_t gone = 0;

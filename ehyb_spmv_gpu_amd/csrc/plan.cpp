@@ -117,6 +117,12 @@ int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int
         case EHYB_ARR_SEGS: VIEW(H.segs);
         case EHYB_ARR_PERM: VIEW(plan->perm);
         case EHYB_ARR_SLAB_LROW: VIEW(H.slab_lrow);
+        case EHYB_ARR_PB_VAL: VIEW(H.pb_val);
+        case EHYB_ARR_PB_COL: VIEW(H.pb_col);
+        case EHYB_ARR_PB_DST: VIEW(H.pb_dst);
+        case EHYB_ARR_PB_UNITS1: VIEW(H.pb_units1);
+        case EHYB_ARR_PB_ROW: VIEW(H.pb_row);
+        case EHYB_ARR_PB_UNITS2: VIEW(H.pb_units2);
         case EHYB_ARR_ER_BINS:
             *ptr = (const void*)H.er_bins;
             *count = 8;

@@ -17,7 +17,7 @@ using namespace ehyb;
 
 namespace {
 
-const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '5'};
+const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '6'};
 const char kEnd[8] = {'E', 'H', 'Y', 'B', 'E', 'N', 'D', '4'};
 
 struct FileCloser {
@@ -61,14 +61,41 @@ bool each_array(HostLayout& H, F&& io)
     return io(H.part_boundary) && io(H.win_len) && io(H.halo_ptr) && io(H.halo_cols) && io(H.slab_pair_ptr) &&
            io(H.slab_row) && io(H.slab_part) && io(H.ell_val) && io(H.ell_col) && io(H.slab_col_ptr) && io(H.lane_group) &&
            io(H.slab_meta) && io(H.items) && io(H.segs) && io(H.er_seg_ptr) && io(H.er_seg_row) && io(H.er_col) &&
-           io(H.er_val) && io(H.er_blocks) && io(H.slab_lrow);
+           io(H.er_val) && io(H.er_blocks) && io(H.slab_lrow) && io(H.pb_val) && io(H.pb_col) && io(H.pb_dst) &&
+           io(H.pb_units1) && io(H.pb_row) && io(H.pb_units2);
 }
 
 struct Scalars {
     int32_t n_cols, row_begin, row_end, n_parts, lds_doubles, inline_er;
     int32_t er_bins[8];
     int32_t sym, yacc_doubles;
+    int32_t er_panel, pb_panel_cols, pb_rows_max, pad_;
+    int64_t pb_partials, pb_bytes;
 };
+
+// The panel residual's arrays must fit together as the two kernels index them.
+bool panel_consistent(const HostLayout& H)
+{
+    if (!H.er_panel)
+        return H.pb_val.empty() && H.pb_col.empty() && H.pb_dst.empty() && H.pb_units1.empty() && H.pb_row.empty() && H.pb_units2.empty();
+    const size_t ne = H.pb_val.size();
+    if (H.pb_col.size() != ne || H.pb_dst.size() != ne || ne % 64 != 0 || H.pb_units1.size() % 4 || H.pb_units2.size() % 4) return false;
+    if (H.pb_partials < 0 || H.pb_row.size() != (size_t)H.pb_partials) return false;
+    if (H.pb_panel_cols < 64 || H.pb_panel_cols > 16384 || H.pb_rows_max < 1 || H.pb_rows_max > 16384) return false;
+    for (size_t u = 0; u < H.pb_units1.size(); u += 4) {
+        const int32_t* q = &H.pb_units1[u];
+        if (q[0] < 0 || q[1] < 1 || q[1] > H.pb_panel_cols || (int64_t)q[0] + q[1] > H.n_cols || q[2] < 0 || q[3] < q[2] || (size_t)q[3] > ne ||
+            q[2] % 64 || q[3] % 64)
+            return false;
+    }
+    for (size_t u = 0; u < H.pb_units2.size(); u += 4) {
+        const int32_t* q = &H.pb_units2[u];
+        if (q[0] < 0 || q[1] < q[0] || q[1] > H.pb_partials || q[2] < H.row_begin || q[3] < 1 || q[3] > H.pb_rows_max || q[2] + q[3] > H.row_end) return false;
+    }
+    for (uint32_t d : H.pb_dst)
+        if (d != 0xFFFFFFFFu && d >= (uint64_t)H.pb_partials) return false;
+    return true;
+}
 
 }  // namespace
 
@@ -104,7 +131,8 @@ int ehyb_plan_save(const ehyb_plan* plan, const int* reorder_list, uint64_t matr
     HostLayout& H = const_cast<HostLayout&>(plan->host);  // each_array takes non-const; nothing is modified
     File f(fopen(path, "wb"));
     if (!f) EHYB_FAIL(EHYB_ERR_IO, "ehyb_plan_save: cannot create %s", path);
-    Scalars s{H.n_cols, H.row_begin, H.row_end, H.n_parts, H.lds_doubles, H.inline_er ? 1 : 0, {0}, H.sym ? 1 : 0, H.yacc_doubles};
+    Scalars s{H.n_cols, H.row_begin, H.row_end, H.n_parts, H.lds_doubles, H.inline_er ? 1 : 0, {0}, H.sym ? 1 : 0, H.yacc_doubles,
+              H.er_panel ? 1 : 0, H.pb_panel_cols, H.pb_rows_max, 0, H.pb_partials, H.pb_bytes};
     memcpy(s.er_bins, H.er_bins, sizeof s.er_bins);
     std::vector<int32_t> perm;
     if (reorder_list) perm.assign(reorder_list, reorder_list + H.n_cols);
@@ -152,6 +180,8 @@ int ehyb_plan_load(const char* path, uint64_t expect_key, ehyb_plan** plan, int*
     H.n_cols = s.n_cols, H.row_begin = s.row_begin, H.row_end = s.row_end, H.n_parts = s.n_parts;
     H.lds_doubles = s.lds_doubles, H.inline_er = s.inline_er != 0;
     H.sym = s.sym != 0, H.yacc_doubles = s.yacc_doubles;
+    H.er_panel = s.er_panel != 0, H.pb_panel_cols = s.pb_panel_cols, H.pb_rows_max = s.pb_rows_max;
+    H.pb_partials = s.pb_partials, H.pb_bytes = s.pb_bytes;
     memcpy(H.er_bins, s.er_bins, sizeof s.er_bins);
     // the sizes the kernels rely on must fit together -- a damaged file must not reach the GPU
     const size_t nslab = H.slab_row.size(), nseg = H.er_seg_row.size();
@@ -164,7 +194,8 @@ int ehyb_plan_load(const char* path, uint64_t expect_key, ehyb_plan** plan, int*
         H.ell_val.size() == (size_t)H.slab_pair_ptr.back() * 2 * kSlabRows && H.ell_col.size() == (size_t)H.slab_col_ptr.back() &&
         H.items.size() % 8 == 0 && H.segs.size() % 8 == 0 && H.er_seg_ptr.size() == nseg + 1 &&
         H.er_col.size() == (size_t)H.er_seg_ptr.back() && H.er_val.size() == H.er_col.size() && H.er_blocks.size() % 4 == 0 && (H.sym ? H.slab_lrow.size() == nslab * kSlabRows : H.slab_lrow.empty()) &&
-        H.lds_doubles > 0 && H.lds_doubles <= EHYB_LDS_MAX_DOUBLES && (perm.empty() || perm.size() == (size_t)H.n_cols);
+        H.lds_doubles > 0 && H.lds_doubles <= EHYB_LDS_MAX_DOUBLES && (perm.empty() || perm.size() == (size_t)H.n_cols) &&
+        panel_consistent(H);
     if (!consistent) EHYB_FAIL(EHYB_ERR_FORMAT, "ehyb_plan_load: %s holds inconsistent array sizes", path);
     if (reorder_list) {
         if (perm.empty()) EHYB_FAIL(EHYB_ERR_FORMAT, "ehyb_plan_load: %s holds no permutation", path);

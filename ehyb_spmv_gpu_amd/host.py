@@ -24,6 +24,8 @@ ARRAYS = {
     "er_col": (12, np.int32), "er_val": (13, np.float64), "er_bins": (14, np.int32),
     "slab_col_ptr": (15, np.uint32), "lane_group": (16, np.uint8), "slab_meta": (17, np.uint32),
     "segs": (18, np.int32), "perm": (19, np.int32), "slab_lrow": (20, np.uint16),
+    "pb_val": (21, np.float64), "pb_col": (22, np.uint16), "pb_dst": (23, np.uint32), "pb_units1": (24, np.int32),
+    "pb_row": (25, np.uint16), "pb_units2": (26, np.int32),
 }
 
 

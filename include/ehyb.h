@@ -120,7 +120,12 @@ typedef struct ehyb_config {
                               allocated by this library (ehyb_mm_read, ehyb_gen_*, ehyb_matrix_from_csr) hold
                               dimension+1 entries; the reference harness callocs `dimension`
                               (solver_test.c:42,146), which is what matrixReorder[_unsym] assume.          */
-    int32_t reserved[5];
+    int32_t er_mode;       /* form of a residual too large to ride inside the ELL launch: 0 = automatic (panel form from
+                              2^21 residual entries up), 1 = CSR segments (ehyb_er_kernel: x gathered from global
+                              memory), 2 = panel form (two streaming passes, x panels and y blocks in LDS: er_panel.cpp) */
+    int32_t er_panel_cols; /* panel form: columns per x panel staged in LDS (<= 16384, default 8192 = 64 KiB)          */
+    int32_t er_block_rows; /* panel form: most rows of a y block accumulated in LDS (<= 16384, default 8192)          */
+    int32_t reserved[2];
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);
@@ -238,7 +243,8 @@ typedef struct ehyb_stats {
                                both entries of such a pair, size_block_ell one                          */
     int64_t bytes_format_ell; /* the part of bytes_format the ELL launch moves (an inline residual included);
                                the rest belongs to the residual launch                                   */
-    int64_t reserved[1];
+    int64_t er_partials;    /* > 0: the residual is stored in panel form; partial sums written by its first pass
+                               and read by its second, per multiply                                    */
 } ehyb_stats;
 int ehyb_plan_stats(const ehyb_plan* plan, ehyb_stats* out);
 
@@ -274,9 +280,19 @@ enum {
                                    end row, win_len, halo_begin}: one LDS window staging each       */
     EHYB_ARR_PERM          = 19,/* int32  [n_cols]     reorderList stored with a plan that came from
                                    ehyb_plan_load (empty for plans built in this process)          */
-    EHYB_ARR_SLAB_LROW     = 20 /* uint16 [n_slabs*64] symmetric pair storage only: the row every lane works on, as
+    EHYB_ARR_SLAB_LROW     = 20,/* uint16 [n_slabs*64] symmetric pair storage only: the row every lane works on, as
                                    its place in the partition's LDS image (row - even(partition start));
                                    0xFFFF = no row.  The rows of a partition sit in its slabs longest first. */
+    /* panel form of the residual (stats.er_partials > 0; the CSR arrays 10-13 describe the same entries) */
+    EHYB_ARR_PB_VAL        = 21,/* double [entries, every panel padded to a multiple of 64]  pass-1 order: by column
+                                   panel, inside a panel by (row, column); padding = 0.0                   */
+    EHYB_ARR_PB_COL        = 22,/* uint16 same length: column - first column of the panel                  */
+    EHYB_ARR_PB_DST        = 23,/* uint32 same length: partial sum the entry belongs to (entries of one row that are
+                                   neighbours inside a 64-entry chunk share one); 0xFFFFFFFF = padding     */
+    EHYB_ARR_PB_UNITS1     = 24,/* int32  [4*u1] pass-1 work units {first column, columns, first entry, end entry}  */
+    EHYB_ARR_PB_ROW        = 25,/* uint16 [er_partials] row of the partial - first row of its row block; partials are
+                                   numbered by (row block, panel, row)                                     */
+    EHYB_ARR_PB_UNITS2     = 26 /* int32  [4*u2] pass-2 work units {first partial, end partial, first row, rows}    */
 };
 int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int64_t* count);
 

@@ -272,9 +272,64 @@ def walk_plan(plan, x):
         # one workgroup holds a partition's accumulators: every item is exactly one partition
         assert np.all(items[:, 1] - items[:, 0] == 1)
         assert np.all(segs[:, 1] == np.searchsorted(slab_part, segs[:, 0])) and np.all(segs[:, 2] == np.searchsorted(slab_part, segs[:, 0], side="right"))
+    y_csr = np.zeros(n)
     if len(seg_row):
         prod = er_val * x[er_col]
         sums = np.add.reduceat(prod, seg_ptr[:-1]) if len(prod) else np.zeros(0)
         rows = seg_row & 0x7FFFFFFF
-        np.add.at(y, rows, sums)
+        np.add.at(y_csr, rows, sums)
+    if plan.stats["er_partials"] > 0:
+        # panel form of the residual, walked as ehyb_pb_scale_kernel / ehyb_pb_reduce_kernel index it
+        y_pb = walk_panel_residual(plan, x)
+        tol = 1e-12 * (np.abs(er_val * x[er_col]).sum() / max(1, len(seg_row)) + np.abs(y_csr).max() + 1e-300)
+        assert np.allclose(y_pb, y_csr, rtol=0, atol=tol), "panel form and CSR segments of the residual disagree"
+        y += y_pb
+    else:
+        y += y_csr
     return y, written
+
+
+def walk_panel_residual(plan, x):
+    """y contribution of the residual in panel form (include/ehyb.h EHYB_ARR_PB_*): pass 1 per unit
+    {first column, columns, first entry, end entry} multiplies with the unit's x panel and sums the
+    entries of every slot; pass 2 per unit {first partial, end partial, first row, rows} adds the
+    partials into the rows of its block.  Checks the invariants the kernels rely on."""
+    n = plan.n
+    val, col, dst = plan.array("pb_val"), plan.array("pb_col").astype(np.int64), plan.array("pb_dst").astype(np.int64)
+    u1 = plan.array("pb_units1").reshape(-1, 4)
+    u2 = plan.array("pb_units2").reshape(-1, 4)
+    prow = plan.array("pb_row").astype(np.int64)
+    P = plan.stats["er_partials"]
+    assert len(val) == len(col) == len(dst) and len(val) % 64 == 0 and len(prow) == P
+    pad = dst == 0xFFFFFFFF
+    assert not val[pad].any() and dst[~pad].max() < P and plan.stats["nnz_er"] == int((~pad).sum())
+    # an entry's slot is shared only with neighbours inside its own 64-entry chunk (what the lane sums assume)
+    live = np.flatnonzero(~pad)
+    first = np.full(P, -1, dtype=np.int64)
+    last = np.full(P, -1, dtype=np.int64)
+    first[dst[live][::-1]] = live[::-1]
+    last[dst[live]] = live
+    assert first.min() >= 0, "a partial no entry writes"
+    cnt = np.bincount(dst[live], minlength=P)
+    assert np.all(last - first + 1 == cnt) and np.all(first // 64 == last // 64), "slot pieces must be contiguous inside a chunk"
+    partial = np.zeros(P)
+    covered = np.zeros(len(val), dtype=np.int32)
+    for c0, nc, b, e in u1:
+        assert b % 64 == 0 and e % 64 == 0 and e > b and 0 <= c0 and c0 + nc <= n
+        win = x[c0:c0 + nc]
+        k = np.arange(b, e)[~pad[b:e]]
+        assert len(k) == 0 or col[k].max() < nc, "local column outside the staged panel"
+        np.add.at(partial, dst[k], val[k] * win[col[k]])
+        covered[b:e] += 1
+    assert np.all(covered == 1), "every entry belongs to exactly one pass-1 unit"
+    y = np.zeros(n)
+    seen = np.zeros(P, dtype=np.int32)
+    rows_seen = np.zeros(n, dtype=np.int32)
+    for pb, pe, r0, nr in u2:
+        assert pe > pb and prow[pb:pe].max() < nr
+        np.add.at(y, r0 + prow[pb:pe], partial[pb:pe])
+        seen[pb:pe] += 1
+        rows_seen[r0:r0 + nr] += 1
+    assert np.all(seen == 1), "every partial belongs to exactly one pass-2 unit"
+    assert rows_seen.max() <= 1, "row blocks of pass 2 must not overlap (their write-back is not atomic)"
+    return y

@@ -1,0 +1,88 @@
+"""Panel form of a large residual (csrc/er_panel.cpp; kernels ehyb_pb_scale_kernel / ehyb_pb_reduce_kernel):
+the host builder checked without a GPU by the oracle's walk of the arrays (oracle.walk_panel_residual
+indexes them as the kernels do and checks the invariants they rely on), against the CSR segments of
+the same residual and against the reference CPU product."""
+import numpy as np
+import pytest
+
+from util import Case
+
+CASES = [
+    ("rmat_s14", "rmat", (14, 1 << 17, 1), dict(lds_doubles=512, er_panel_cols=512, er_block_rows=300)),
+    ("rmat_s12_dense", "rmat", (12, 1 << 18, 5), dict(lds_doubles=256, er_panel_cols=256, er_block_rows=64)),
+    ("kkt_contiguous", "kkt3d", (12,), dict(lds_doubles=512, partitioner=1)),
+    ("rmat_s16_defaults", "rmat", (16, 1 << 19, 3), dict()),
+    ("fem_reference_window", "fem3d", (30000, 3, 22, 22, 13500, 1, 1), dict(window_mode=1, lds_doubles=1024, er_panel_cols=1024)),
+    ("rmat_sym_storage", "rmat", (14, 1 << 17, 4), dict(lds_doubles=512, sym_pairs=1, er_panel_cols=256)),
+]
+
+
+@pytest.mark.parametrize("name,kind,args,kw", CASES, ids=[c[0] for c in CASES])
+def test_panel_form_walks_to_the_reference_product(E, O, name, kind, args, kw):
+    cfg = E.make_config(er_mode=2, fuse_er=2, **kw)
+    c = Case(E, O, kind, args, cfg)
+    plan = E.Plan(c.m, cfg, upload=False)
+    st = plan.stats
+    assert st["nnz_er"] > 0 and 0 < st["er_partials"] <= st["nnz_er"]
+    y, written = O.walk_plan(plan, c.xp)          # asserts panel form == CSR segments inside
+    assert written[:c.n].min() == 1
+    bad, worst = c.check(y)
+    assert bad == 0, f"worst {worst:.3e}"
+    # pass-1 units stay inside one panel, pass-2 row blocks inside the limit
+    u1 = plan.array("pb_units1").reshape(-1, 4)
+    u2 = plan.array("pb_units2").reshape(-1, 4)
+    assert np.all(u1[:, 1] <= cfg.er_panel_cols) and np.all(u1[:, 0] % cfg.er_panel_cols == 0)
+    assert np.all(u2[:, 3] <= cfg.er_block_rows)
+    # bytes: both passes streamed -- entries at 14 B, partials at 18 B, plus panels and y
+    assert st["bytes_format"] - st["bytes_format_ell"] >= 14 * st["nnz_er"] + 18 * st["er_partials"]
+
+
+def test_mode_selection(E, O):
+    """er_mode 1 = CSR segments, 2 = panel form, 0 = panel form from 2^21 residual entries up; a tiny
+    residual rides inside the ELL launch whatever er_mode says."""
+    cfg1 = E.make_config(er_mode=1, lds_doubles=512)
+    c = Case(E, O, "rmat", (14, 1 << 17, 1), cfg1)
+    assert E.Plan(c.m, cfg1, upload=False).stats["er_partials"] == 0
+    assert E.Plan(c.m, E.make_config(er_mode=0, lds_doubles=512), upload=False).stats["er_partials"] == 0   # 64 k entries: CSR
+    assert E.Plan(c.m, E.make_config(er_mode=2, lds_doubles=512), upload=False).stats["er_partials"] > 0
+    cfg = E.make_config(er_mode=2)
+    f = Case(E, O, "fem3d", (30000, 3, 22, 22, 13500, 1, 1), cfg)
+    st = E.Plan(f.m, cfg, upload=False).stats
+    assert st["er_partials"] == 0 and (st["nnz_er"] == 0 or st["er_inline"] > 0)
+
+
+def test_hub_row_collapses_to_few_partials(E, O):
+    """A row with tens of thousands of residual entries leaves at most one partial per 64-entry chunk it
+    touches -- far fewer than its entries (what keeps the second pass balanced on power-law inputs)."""
+    cfg = E.make_config(er_mode=2, lds_doubles=256, er_panel_cols=4096)
+    c = Case(E, O, "rmat", (15, 1 << 20, 7), cfg)
+    plan = E.Plan(c.m, cfg, upload=False)
+    st = plan.stats
+    assert st["max_row"] > 4000 and st["er_partials"] < 0.5 * st["nnz_er"]
+    y, _ = O.walk_plan(plan, c.xp)
+    assert c.check(y)[0] == 0
+
+
+def test_plan_cache_round_trip_with_panel_form(E, O, tmp_path):
+    cfg = E.make_config(er_mode=2, lds_doubles=512, er_panel_cols=512)
+    c = Case(E, O, "rmat", (13, 1 << 16, 2), cfg)
+    plan = E.Plan(c.m, cfg, upload=False)
+    path = tmp_path / "p.ehyb"
+    plan.save(path, c.perm, key=7)
+    loaded, perm = E.Plan.load(path, key=7, upload=False)
+    assert loaded.stats == plan.stats and np.array_equal(perm, c.perm)
+    for name in ("pb_val", "pb_col", "pb_dst", "pb_units1", "pb_row", "pb_units2"):
+        assert np.array_equal(loaded.array(name), plan.array(name)), name
+    y, _ = O.walk_plan(loaded, c.xp)
+    assert c.check(y)[0] == 0
+    # a slot beyond the partial buffer must not reach the GPU
+    data = bytearray(path.read_bytes())
+    dst = plan.array("pb_dst")
+    needle = dst[:8].tobytes()
+    off = bytes(data).rindex(needle)
+    data[off:off + 4] = (plan.stats["er_partials"] + 5).to_bytes(4, "little")
+    bad = tmp_path / "bad.ehyb"
+    bad.write_bytes(bytes(data))
+    with pytest.raises(E.EhybError) as e:
+        E.Plan.load(bad, upload=False)
+    assert e.value.code == 6
