@@ -59,7 +59,8 @@ class Config(C.Structure):
         ("er_mode", C.c_int32),
         ("er_panel_cols", C.c_int32),
         ("er_block_rows", C.c_int32),
-        ("reserved", C.c_int32 * 2),
+        ("direct", C.c_int32),
+        ("reserved", C.c_int32 * 1),
     ]
 
 

@@ -117,6 +117,12 @@ Config resolve_config(const ehyb_config* in)
     c.er_mode = (z.er_mode == 1 || z.er_mode == 2) ? z.er_mode : 0;
     c.er_panel_cols = z.er_panel_cols > 0 ? std::min(16384, std::max(256, round_down(z.er_panel_cols, 64))) : 8192;
     c.er_block_rows = z.er_block_rows > 0 ? std::min(16384, std::max(64, z.er_block_rows)) : 8192;
+    c.direct = (z.direct == 1 || z.direct == 2) ? z.direct : 0;
+    // the automatic choice of the direct shape is for callers that left the window sizing alone: a caller
+    // that names a window (lds_doubles / part_rows other than the defaults) gets that window
+    if (c.direct == 0 && (c.lds_doubles != EHYB_LDS_MAX_DOUBLES || c.part_rows != round_down(EHYB_LDS_MAX_DOUBLES * 11 / 20, kSlabRows) ||
+                          c.window_mode == EHYB_WINDOW_REFERENCE || c.sym_pairs == 1))
+        c.direct = 2;
     // symmetric pairs: whole rows may not leave the ELL part (a residual row cannot scatter): no hub rule
     if (c.sym_pairs == 1) {
         c.part_rows = std::max(kSlabRows, std::min(c.part_rows, round_down(c.lds_doubles * 3 / 10, kSlabRows)));
@@ -166,6 +172,7 @@ void ehyb_config_resolve(const ehyb_config* in, ehyb_config* out)
     r.er_mode = c.er_mode;
     r.er_panel_cols = c.er_panel_cols;
     r.er_block_rows = c.er_block_rows;
+    r.direct = c.direct;
     *out = r;
 }
 

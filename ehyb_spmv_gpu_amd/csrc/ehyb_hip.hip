@@ -58,7 +58,13 @@ using namespace ehyb;
 // memory, shuffle reduction, then y[row] += sum -- plain for rows with one segment (rows are
 // unique, kernel.cu:69-77), one fp64 atomic per segment for split rows (the working form of
 // kernel.cu:43-67).  Called from ehyb_er_kernel, which runs behind the ELL launch.
-template <int G, int THREADS>
+// ASSIGN (direct shape, small matrices): y[row] = sum -- every row has exactly one segment.
+// Most residual rows are short (R-MAT 2^22: 22 entries on average), so a lane has one to four entries
+// and the time goes into the CHAIN of dependent loads, not into bandwidth: segment bounds -> (column,
+// value) -> x[column] -> y.  Everything that does not depend on the products is therefore requested up
+// front (row number and the old y with the bounds), and a lane's column/value loads are issued four at
+// a time before the first gather of x (measured on R-MAT 2^22: DESIGN.md 3.2).
+template <int G, int THREADS, bool ASSIGN>
 __device__ __forceinline__ void er_bin(int lo, int hi, const int64_t* __restrict__ seg_ptr,
                                        const int* __restrict__ seg_row, const int* __restrict__ col,
                                        const double* __restrict__ val, const double* __restrict__ x,
@@ -69,26 +75,41 @@ __device__ __forceinline__ void er_bin(int lo, int hi, const int64_t* __restrict
     for (int base = lo; base < hi; base += SEGS) {  // uniform trip count: every lane reaches the shuffles
         const int seg = base + threadIdx.x / G;
         double acc0 = 0.0, acc1 = 0.0;
+        int r = 0;
+        double y_old = 0.0;
         if (seg < hi) {
             const int64_t b = seg_ptr[seg], e = seg_ptr[seg + 1];
+            r = seg_row[seg];
+            if (!ASSIGN && sub == 0 && r >= 0) y_old = y[r];  // in flight while the products are formed
             int64_t k = b + sub;
-            for (; k + G < e; k += 2 * G) {
-                const int ca = col[k], cb = col[k + G];
-                const double va = val[k], vb = val[k + G];
-                acc0 = fma(va, x[ca], acc0);
-                acc1 = fma(vb, x[cb], acc1);
+            for (; k + 3 * G < e; k += 4 * G) {
+                const int c0 = col[k], c1 = col[k + G], c2 = col[k + 2 * G], c3 = col[k + 3 * G];
+                const double v0 = val[k], v1 = val[k + G], v2 = val[k + 2 * G], v3 = val[k + 3 * G];
+                const double x0 = x[c0], x1 = x[c1], x2 = x[c2], x3 = x[c3];
+                acc0 = fma(v0, x0, acc0);
+                acc1 = fma(v1, x1, acc1);
+                acc0 = fma(v2, x2, acc0);
+                acc1 = fma(v3, x3, acc1);
             }
-            if (k < e) acc0 = fma(val[k], x[col[k]], acc0);
+            // up to three more, again all requested before the first use
+            const bool h0 = k < e, h1 = k + G < e, h2 = k + 2 * G < e;
+            const int c0 = h0 ? col[k] : 0, c1 = h1 ? col[k + G] : 0, c2 = h2 ? col[k + 2 * G] : 0;
+            const double v0 = h0 ? val[k] : 0.0, v1 = h1 ? val[k + G] : 0.0, v2 = h2 ? val[k + 2 * G] : 0.0;
+            const double x0 = h0 ? x[c0] : 0.0, x1 = h1 ? x[c1] : 0.0, x2 = h2 ? x[c2] : 0.0;
+            acc0 = fma(v0, x0, acc0);
+            acc1 = fma(v1, x1, acc1);
+            acc0 = fma(v2, x2, acc0);
         }
         double acc = acc0 + acc1;
 #pragma unroll
         for (int off = G / 2; off > 0; off >>= 1) acc += __shfl_down(acc, off, G);
         if (sub == 0 && seg < hi) {
-            const int r = seg_row[seg];
-            if (r < 0)
+            if (ASSIGN)
+                y[r] = acc;
+            else if (r < 0)
                 unsafeAtomicAdd(&y[r & 0x7fffffff], acc);
             else
-                y[r] += acc;
+                y[r] = y_old + acc;
         }
     }
 }
@@ -309,7 +330,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(SYM ? 4
 // ------------------------------------------------------------------ residual kernel
 // Two-launch form (multi-GPU phase 2, or a residual too large to ride in the ELL launch): one
 // block per descriptor {seg_lo, seg_hi, lanes per segment}, a single pass of same-bin segments.
-template <int THREADS>
+template <int THREADS, bool ASSIGN>
 __global__ __launch_bounds__(THREADS) void ehyb_er_kernel(const int4* __restrict__ blocks,
                                                           const int64_t* __restrict__ seg_ptr,
                                                           const int* __restrict__ seg_row,
@@ -319,11 +340,11 @@ __global__ __launch_bounds__(THREADS) void ehyb_er_kernel(const int4* __restrict
 {
     const int4 b = blocks[blockIdx.x];  // (the XCD map of the ELL kernel was tried here: no difference on R-MAT)
     if (b.z == 64)
-        er_bin<64, THREADS>(b.x, b.y, seg_ptr, seg_row, col, val, x, y);
+        er_bin<64, THREADS, ASSIGN>(b.x, b.y, seg_ptr, seg_row, col, val, x, y);
     else if (b.z == 16)
-        er_bin<16, THREADS>(b.x, b.y, seg_ptr, seg_row, col, val, x, y);
+        er_bin<16, THREADS, ASSIGN>(b.x, b.y, seg_ptr, seg_row, col, val, x, y);
     else
-        er_bin<4, THREADS>(b.x, b.y, seg_ptr, seg_row, col, val, x, y);
+        er_bin<4, THREADS, ASSIGN>(b.x, b.y, seg_ptr, seg_row, col, val, x, y);
 }
 
 // ------------------------------------------------------------------ panel residual (er_panel.cpp)
@@ -412,9 +433,14 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_reduce_kernel(const int4* __r
         }
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            const double sum = run_sum(v[j], r[j], lane);
+            // a row may come back later in the same wave (next panel): runs are told apart by their
+            // number -- how many run heads sit at or below the lane -- not by the row
             const uint32_t before = __shfl_up(r[j], 1, 64);
-            if ((lane == 0 || before != r[j]) && r[j] != 0xFFFFFFFFu) unsafeAtomicAdd(&yacc[r[j]], sum);  // ds_add_f64
+            const bool head = lane == 0 || before != r[j];
+            const unsigned long long heads = __ballot(head);
+            const uint32_t run = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull));
+            const double sum = run_sum(v[j], run, lane);
+            if (head && r[j] != 0xFFFFFFFFu) unsafeAtomicAdd(&yacc[r[j]], sum);  // ds_add_f64
         }
     }
     __syncthreads();
@@ -469,7 +495,7 @@ static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t
 {
     const HostLayout& H = P->host;
     const int n_items = (int)(H.items.size() / 8);
-    if (n_items == 0) return EHYB_OK;
+    if (n_items == 0 || H.direct) return EHYB_OK;  // direct shape: the row-segment kernel does everything
     const size_t lds = ell_lds_bytes(H);
     const bool dyn = P->cfg.ell_variant != 3;
     const EllArgs A = ell_args(P, x, y, stamps);
@@ -523,8 +549,12 @@ static int launch_er(ehyb_plan* P, const double* x, double* y, hipStream_t st)
     }
     const int n_blocks = (int)(H.er_blocks.size() / 4);
     if (P->cfg.er_threads != 256) EHYB_FAIL(EHYB_ERR_ARG, "residual workgroup size %d not built (256)", P->cfg.er_threads);
-    hipLaunchKernelGGL(ehyb_er_kernel<256>, dim3(n_blocks), dim3(256), 0, st, (const int4*)P->d_er_blocks,
-                       P->d_er_seg_ptr, P->d_er_seg_row, P->d_er_col, P->d_er_val, x, y);
+    if (H.direct)
+        hipLaunchKernelGGL((ehyb_er_kernel<256, true>), dim3(n_blocks), dim3(256), 0, st, (const int4*)P->d_er_blocks,
+                           P->d_er_seg_ptr, P->d_er_seg_row, P->d_er_col, P->d_er_val, x, y);
+    else
+        hipLaunchKernelGGL((ehyb_er_kernel<256, false>), dim3(n_blocks), dim3(256), 0, st, (const int4*)P->d_er_blocks,
+                           P->d_er_seg_ptr, P->d_er_seg_row, P->d_er_col, P->d_er_val, x, y);
     HIP_TRY(hipGetLastError());
     return EHYB_OK;
 }
@@ -748,6 +778,7 @@ int ehyb_spmv_phase(ehyb_plan* P, const double* x, double* y, void* stream, int 
     hipStream_t st = (hipStream_t)stream;
     int rc = EHYB_OK;
     if (phase == 0 && fuse_residual(P)) return launch_ell(P, x, y, st, true);  // one launch
+    if (P->host.direct && phase != 0) EHYB_FAIL(EHYB_ERR_STATE, "ehyb_spmv_phase: a plan in the direct shape (small matrix) has no phases");
     if (phase == 0 || phase == 1) rc = launch_ell(P, x, y, st, false);
     if (rc == EHYB_OK && (phase == 0 || phase == 2)) rc = launch_er(P, x, y, st);
     return rc;

@@ -47,6 +47,7 @@ struct Config {
     int er_mode;            // 0 automatic, 1 CSR segments, 2 panel form
     int er_panel_cols;
     int er_block_rows;
+    int direct;             // 0 automatic, 1 on, 2 off
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -104,6 +105,9 @@ struct HostLayout {
     bool sym = false;
     int yacc_doubles = 0;
     std::vector<uint16_t> slab_lrow;  // [n_slabs*64] sym only: image-local row of every lane (0xFFFF: none)
+
+    // direct shape (small matrices): every row in the residual, the residual kernel ASSIGNS y, no ELL launch
+    bool direct = false;
 
     // panel form of a large residual (er_panel.cpp): two streaming passes instead of gathers from global memory
     bool er_panel = false;

@@ -170,6 +170,12 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     const int lds = std::max(kSlabRows, cfg.lds_doubles - 2);
     const bool halo_mode = cfg.window_mode == EHYB_WINDOW_HALO;
     const bool sym = cfg.sym_pairs == 1 && halo_mode;  // symmetric pair storage (in-partition pairs; remote columns are untouched)
+    // Direct shape for small matrices (cfg.direct): no window, every row goes to the row-segment kernel,
+    // which then assigns y.  bcsstk17's size (11 k rows, 0.4 M entries, 5 MB) is about 170 slabs: a
+    // handful of 1024-thread workgroups with 160 KiB windows cannot be spread over 256 CUs, and x is in L2.
+    const bool direct = !sym && cfg.n_top <= 1 && row_begin == 0 && row_end == n &&
+                        (cfg.direct == 1 || (cfg.direct == 0 && n <= EHYB_DIRECT_MAX_ROWS && cfg.window_mode != EHYB_WINDOW_REFERENCE && cfg.fuse_er != 1));
+    L->direct = direct;
 
     // ---- partitions: the caller's, cut down to the window capacity where needed
     std::vector<int32_t>& pb = L->part_boundary;
@@ -328,7 +334,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 // workgroup needs for everything else (R-MAT: a 5-slab item of 131 pairs each ended
                 // at 116 us of a 120 us launch).  Such rows go to the residual whole, where 64 lanes
                 // share a row.
-                if (cfg.hub_rule != 2 && c > kWideRow) {
+                if ((cfg.hub_rule != 2 && c > kWideRow) || direct) {
                     row_to_er[r - row_begin] = 1;
                     c = 0;
                 }
@@ -425,7 +431,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     // column -> x) at the end of the slab cost 7 % of the launch when tried; with the slice every
     // address follows from the slab record and only the x gather waits for a load.
     // The CSR segments are built as well, so the two-phase call of the same plan still works.
-    L->inline_er = cfg.n_top <= 1 && nnz_er > 0 && (cfg.fuse_er == 1 || (cfg.fuse_er != 2 && nnz_er * 500 < nnz));
+    L->inline_er = !direct && cfg.n_top <= 1 && nnz_er > 0 && (cfg.fuse_er == 1 || (cfg.fuse_er != 2 && nnz_er * 500 < nnz));
     if (L->inline_er) {
         // every lane of a slab gets as many residual pairs as the slab's longest residual row: fine
         // for a handful of rows (hub rows moved out of the ELL part whole), not for many long ones
@@ -688,10 +694,12 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         for (int r = pb[p]; r < pb[p + 1]; ++r) {
             const int rr = r - row_begin;
             int64_t len = er_rp[rr + 1] - er_rp[rr];
-            if (len == 0) continue;
-            ++rows_er;
+            // direct shape: the kernel assigns y, so every row has exactly one segment -- an empty one
+            // for an empty row (y = 0), an unsplit one for a long row (no atomics on an unzeroed y)
+            if (len == 0 && !direct) continue;
+            rows_er += len > 0;
             const int32_t item = item_of_slab[slab_base[p] + slot_of[r - row_begin] / kSlabRows];
-            int pieces = (int)((len + cfg.er_seg_len - 1) / cfg.er_seg_len);
+            int pieces = direct ? 1 : (int)((len + cfg.er_seg_len - 1) / cfg.er_seg_len);
             for (int q = 0; q < pieces; ++q) {
                 int64_t b = er_rp[rr] + len * q / pieces, e2 = er_rp[rr] + len * (q + 1) / pieces;
                 int32_t row = r | (pieces > 1 ? (int32_t)0x80000000 : 0);
@@ -753,7 +761,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     ehyb_stats& st = L->stats;
     st.rows_er = rows_er;
     L->er_panel = false;
-    if (!L->inline_er && nnz_er > 0 && (cfg.er_mode == 2 || (cfg.er_mode == 0 && nnz_er >= (1 << 21)))) {
+    if (!L->inline_er && !direct && nnz_er > 0 && (cfg.er_mode == 2 || (cfg.er_mode == 0 && nnz_er >= (1 << 21)))) {
         const int rc_pb = build_panel_residual(cfg, L);
         if (rc_pb != EHYB_OK) return rc_pb;
     }

@@ -17,7 +17,7 @@ using namespace ehyb;
 
 namespace {
 
-const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '6'};
+const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '7'};
 const char kEnd[8] = {'E', 'H', 'Y', 'B', 'E', 'N', 'D', '4'};
 
 struct FileCloser {
@@ -69,7 +69,7 @@ struct Scalars {
     int32_t n_cols, row_begin, row_end, n_parts, lds_doubles, inline_er;
     int32_t er_bins[8];
     int32_t sym, yacc_doubles;
-    int32_t er_panel, pb_panel_cols, pb_rows_max, pad_;
+    int32_t er_panel, pb_panel_cols, pb_rows_max, direct;
     int64_t pb_partials, pb_bytes;
 };
 
@@ -132,7 +132,7 @@ int ehyb_plan_save(const ehyb_plan* plan, const int* reorder_list, uint64_t matr
     File f(fopen(path, "wb"));
     if (!f) EHYB_FAIL(EHYB_ERR_IO, "ehyb_plan_save: cannot create %s", path);
     Scalars s{H.n_cols, H.row_begin, H.row_end, H.n_parts, H.lds_doubles, H.inline_er ? 1 : 0, {0}, H.sym ? 1 : 0, H.yacc_doubles,
-              H.er_panel ? 1 : 0, H.pb_panel_cols, H.pb_rows_max, 0, H.pb_partials, H.pb_bytes};
+              H.er_panel ? 1 : 0, H.pb_panel_cols, H.pb_rows_max, H.direct ? 1 : 0, H.pb_partials, H.pb_bytes};
     memcpy(s.er_bins, H.er_bins, sizeof s.er_bins);
     std::vector<int32_t> perm;
     if (reorder_list) perm.assign(reorder_list, reorder_list + H.n_cols);
@@ -180,7 +180,7 @@ int ehyb_plan_load(const char* path, uint64_t expect_key, ehyb_plan** plan, int*
     H.n_cols = s.n_cols, H.row_begin = s.row_begin, H.row_end = s.row_end, H.n_parts = s.n_parts;
     H.lds_doubles = s.lds_doubles, H.inline_er = s.inline_er != 0;
     H.sym = s.sym != 0, H.yacc_doubles = s.yacc_doubles;
-    H.er_panel = s.er_panel != 0, H.pb_panel_cols = s.pb_panel_cols, H.pb_rows_max = s.pb_rows_max;
+    H.er_panel = s.er_panel != 0, H.pb_panel_cols = s.pb_panel_cols, H.pb_rows_max = s.pb_rows_max, H.direct = s.direct != 0;
     H.pb_partials = s.pb_partials, H.pb_bytes = s.pb_bytes;
     memcpy(H.er_bins, s.er_bins, sizeof s.er_bins);
     // the sizes the kernels rely on must fit together -- a damaged file must not reach the GPU

@@ -68,6 +68,8 @@ enum { EHYB_PART_AUTO = 0, EHYB_PART_CONTIGUOUS = 1, EHYB_PART_MULTILEVEL = 2, E
  * 3 unknowns per node: 21,000 rows 9.7 vs 7.3 us, 42,000 rows 9.9 vs 11.0 us, 84,000 rows 13.6 vs 16.8 us).
  * Callers that pick the storage from the matrix's symmetry (solver_test, bench.py) use this line. */
 #define EHYB_SYM_MIN_ROWS 32768
+/* Plans of at most this many rows run in the direct (window-less, one small launch) shape: cfg.direct. */
+#define EHYB_DIRECT_MAX_ROWS 24576
 
 /* OpenMP threads the host builder uses when cfg.host_threads is 0: what OpenMP would take, capped by
  * the CPUs the process may really use (affinity mask, cgroup CPU quota). */
@@ -125,7 +127,14 @@ typedef struct ehyb_config {
                               memory), 2 = panel form (two streaming passes, x panels and y blocks in LDS: er_panel.cpp) */
     int32_t er_panel_cols; /* panel form: columns per x panel staged in LDS (<= 16384, default 8192 = 64 KiB)          */
     int32_t er_block_rows; /* panel form: most rows of a y block accumulated in LDS (<= 16384, default 8192)          */
-    int32_t reserved[2];
+    int32_t direct;        /* small matrices: 0 = automatic (plans of at most EHYB_DIRECT_MAX_ROWS rows, single GPU,
+                              plain storage, window sizing left at its defaults), 1 = on, 2 = off.  On: no LDS window at all -- every row is multiplied by
+                              the row-segment kernel straight from global x (which sits in L2 at this size), one
+                              launch of 256-thread workgroups, y assigned, not accumulated.  A 160 KiB window per
+                              1024-thread workgroup is the wrong shape when the whole matrix is a few MB: the
+                              reference has a small-matrix branch for the same reason (kernel.cu:197-284,
+                              solver_test.c:56-69).                                                           */
+    int32_t reserved[1];
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);

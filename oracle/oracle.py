@@ -191,7 +191,7 @@ def walk_plan(plan, x):
         if e1 > e0:
             lens = np.diff(seg_ptr[e0:e1 + 1])
             assert np.all(lens[:e64 - e0] >= 128) and np.all((lens[e64 - e0:e16 - e0] > 16) & (lens[e64 - e0:e16 - e0] < 128))
-            assert np.all(lens[e16 - e0:] <= 16) and np.all(lens >= 1)
+            assert np.all(lens[e16 - e0:] <= 16) and np.all(lens >= 0)
             rows = seg_row[e0:e1] & 0x7FFFFFFF
             last_p = segs[g1 - 1, 0]
             assert rows.min() >= slab_row[is0] and rows.max() < min(int(slab_row[is1 - 1]) + 64, int(pb[last_p + 1]))
@@ -265,7 +265,7 @@ def walk_plan(plan, x):
     if inline:
         # inline form (tiny residual): the pairs behind the slabs hold the same entries as the CSR segments
         y_seg = np.zeros(n)
-        np.add.at(y_seg, seg_row & 0x7FFFFFFF, np.add.reduceat(er_val * x[er_col], seg_ptr[:-1]))
+        np.add.at(y_seg, np.repeat(seg_row & 0x7FFFFFFF, np.diff(seg_ptr)), er_val * x[er_col])
         assert np.allclose(y_inl, y_seg, rtol=0, atol=1e-12 * (np.abs(y_seg).max() + 1e-300))
     y += y_mirror
     if sym:
@@ -274,10 +274,8 @@ def walk_plan(plan, x):
         assert np.all(segs[:, 1] == np.searchsorted(slab_part, segs[:, 0])) and np.all(segs[:, 2] == np.searchsorted(slab_part, segs[:, 0], side="right"))
     y_csr = np.zeros(n)
     if len(seg_row):
-        prod = er_val * x[er_col]
-        sums = np.add.reduceat(prod, seg_ptr[:-1]) if len(prod) else np.zeros(0)
-        rows = seg_row & 0x7FFFFFFF
-        np.add.at(y_csr, rows, sums)
+        # (segments may be empty in the direct shape: one per row, y assigned)
+        np.add.at(y_csr, np.repeat(seg_row & 0x7FFFFFFF, np.diff(seg_ptr)), er_val * x[er_col])
     if plan.stats["er_partials"] > 0:
         # panel form of the residual, walked as ehyb_pb_scale_kernel / ehyb_pb_reduce_kernel index it
         y_pb = walk_panel_residual(plan, x)

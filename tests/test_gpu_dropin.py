@@ -36,7 +36,10 @@ def test_reference_driver_end_to_end(E, gpu, tmp_path, kind):
     assert p.returncode == 0, out[-1500:] + p.stderr[-1500:]
     assert ("read symmetric matrix" if kind == "symmetric" else "unsymmetric reordering") in out
     assert "sizeER is" in out and "iter is 50, time is" in out                      # spmv.cu:82,121
-    assert "large difference" not in out                                              # solver_test.c:18-21 (1 % per row)
+    # solver_test.c:15-21 flags rows that differ by more than 1 % of min(|y|, |yResult|): with a different
+    # summation order that trips on rows whose terms cancel to rounding level (both print as +-0.000000)
+    for a, b in re.findall(r"large difference at \d+\s*: realy (-?[0-9.]+) vs yResult (-?[0-9.]+)", out):
+        assert abs(float(a)) < 1e-6 and abs(float(b)) < 1e-6, (a, b)
     diff = float(re.search(r"diff is ([0-9.eE+-]+)", out).group(1))                   # solver_test.c:28: sum |dy|
     total = float(np.abs(m.V).sum()) * 0.1
     assert diff <= 1e-12 * total, (diff, total)

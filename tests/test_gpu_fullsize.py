@@ -83,7 +83,7 @@ def test_config4_kkt_like(E, O, gpu):
 def test_config5_rmat_heavy_residual(E, O, gpu):
     """R-MAT 2^21 rows / 2^24 samples: power-law rows, most entries in the residual, hub rows split
     into atomically combined segments."""
-    cfg = E.make_config(er_seg_len=2048)
+    cfg = E.make_config(er_seg_len=2048, er_mode=1)     # CSR segments: the form that splits long rows
     c = Case(E, O, "rmat", (21, 1 << 24, 1), cfg)
     plan = E.Plan(c.m, cfg)
     st = plan.stats
@@ -104,7 +104,12 @@ def _check_scaled_and_checksum(c, plan, y_perm):
     """The size-independent properties that need no second copy of a 16 M-row problem on the host:
     exact power-of-two scaling and the checksum of checksums (column sums against x)."""
     y2 = plan.spmv_host(2.0 * c.xp)
-    assert np.array_equal(y2, 2.0 * y_perm)
+    if plan.stats["sym_pairs"] == 0 and plan.stats["er_partials"] == 0:
+        assert np.array_equal(y2, 2.0 * y_perm)
+    else:
+        # LDS adds (mirror products / row-block accumulators) land in a different order from run to run:
+        # the last bits may differ, the scaling law holds to tolerance
+        assert c.check(0.5 * y2)[0] == 0
     del y2
     colsum = np.bincount(c.m.J, weights=c.m.V, minlength=c.n)
     lhs, rhs = float(y_perm.sum()), float(colsum @ c.xp)

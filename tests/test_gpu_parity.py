@@ -150,3 +150,33 @@ def test_panel_form_of_the_residual(E, O, gpu, name, kind, args, kw):
     # deterministic: no global atomics in either pass; LDS adds of one row block may reorder
     y_b = plan.spmv_host(c.xp)
     assert c.check(y_b)[0] == 0
+
+
+DIRECT_CASES = [
+    ("bcsstk17_like", "fem3d", (10974, 3, 62, 59, 250000, 1, 17)),
+    ("rmat_s13_hubs", "rmat", (13, 1 << 18, 3)),
+    ("stencil5", "stencil2d", (120, 100, 5, 500, 2)),
+    ("kkt3d_12", "kkt3d", (12,)),
+    ("banded_16k", "banded", (1 << 14, 32, 1024)),
+]
+
+
+@pytest.mark.parametrize("name,kind,args", DIRECT_CASES, ids=[c[0] for c in DIRECT_CASES])
+def test_direct_shape(E, O, gpu, name, kind, args):
+    """Small matrices with default sizing: one launch of the row-segment kernel, y assigned (whatever it
+    held before), empty rows zeroed, long rows unsplit; also through the drop-in symbol."""
+    cfg = E.make_config()
+    c = Case(E, O, kind, args, cfg)
+    plan = E.Plan(c.m, cfg)
+    assert plan.stats["nnz_ell"] == 0 and plan.stats["nnz_er"] == c.nnz
+    dx, dy = E.DeviceBuffer(c.n).upload(c.xp), E.DeviceBuffer(c.n).upload(np.full(c.n, 1e300))
+    plan.spmv(dx.ptr, dy.ptr)
+    y = dy.download()
+    bad, worst = c.check(y)
+    assert bad == 0, f"{name}: worst {worst:.3e}"
+    plan.spmv(dx.ptr, dy.ptr)
+    assert np.array_equal(dy.download(), y), "assigning kernel without atomics: bit-reproducible"
+    with pytest.raises(E.EhybError):
+        plan.spmv(dx.ptr, dy.ptr, phase=1)
+    y1, it = E.spmv_gpu_ehyb(c.m, c.xp, 3)
+    assert it == 3 and c.check(y1)[0] == 0
