@@ -50,6 +50,9 @@ WORKLOADS = {
     # name: (generator, args, description)
     "audikw_1-like": ("fem3d", (943695, 3, 68, 68, 13500, 1, 1),
                       "synthetic stand-in for audikw_1: 943,695 rows, ~77.7 M entries, 3 dof/node FEM-like, scrambled labels"),
+    "audikw_1-graded": ("fem3d_graded", (943695, 3, 68, 68, 100000, 705000, 1, 1),
+                        "harder stand-in for audikw_1: same size (943,695 rows, 77.65 M entries) on a GRADED mesh -- rows of 15 to 303 entries "
+                        "(mean 82.3, sigma 41; audikw_1: 21 to 345, mean 82.3), scrambled labels"),
     "banded-4M": ("banded", (1 << 22, 32, 1024), "config 3: block-circulant band, 4,194,304 rows x 32 entries, zero residual"),
     "rmat-24": ("rmat", (24, 1 << 27, 1), "config 5: R-MAT 2^24 rows, 2^27 edge samples"),
     "kkt3d-200": ("kkt3d", (200,), "config 4 stand-in: KKT-like saddle point system on a 200^3 grid"),
@@ -64,7 +67,7 @@ WORKLOADS = {
 # drop-in caller hands to matrixReorder / spmvGPuEHYB
 REFERENCE_SIZING = {"audikw_1-like": (164, 6144, 0)}
 
-SYMMETRIC_GENERATORS = ("fem3d", "kkt3d", "stencil2d")  # A == A^T by construction (include/ehyb.h)
+SYMMETRIC_GENERATORS = ("fem3d", "fem3d_graded", "kkt3d", "stencil2d")  # A == A^T by construction (include/ehyb.h)
 SYM_MIN_ROWS = 32768  # EHYB_SYM_MIN_ROWS (include/ehyb.h): below it plain storage is faster
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
@@ -359,6 +362,9 @@ def dropin_case(E, O, np, workload, x, y_cpu, scale, steps, log):
     try:
         y, it, ms = E.spmv_gpu_ehyb(m, E.vector_reorder(x, perm), steps, timing=True)
     finally:
+        import ctypes
+
+        ctypes.CDLL(None).fflush(None)  # the C library's own stdout buffer, before fd 1 is put back
         sys.stdout.flush()
         os.dup2(keep, 1)
         os.close(keep)

@@ -136,6 +136,7 @@ SIGNATURES = {
     "ehyb_x_glibc": (None, [C.c_int, _dp]),
     "ehyb_gen_banded": (C.c_int, [C.c_int, C.c_int, C.c_int, _cfgp, _mp]),
     "ehyb_gen_fem3d": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _cfgp, _mp]),
+    "ehyb_gen_fem3d_graded": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _cfgp, _mp]),
     "ehyb_gen_fem3d_block": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
                                        _cfgp, _mp]),
     "ehyb_matrix_append_ghosts": (C.c_int, [_mp, C.c_int, C.c_int64, _ip, _ip, _dp]),

@@ -378,8 +378,27 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
     extern __shared__ __attribute__((aligned(16))) double win[];
     constexpr int WAVES = THREADS / 64;
     const int4 u = units[blockIdx.x];
-    const double* __restrict__ xp = x + u.x;
-    for (int i = threadIdx.x; i < u.y; i += THREADS) win[i] = xp[i];
+    // stage the panel: all of a thread's loads in flight before the first store (a 64 KiB panel is 16
+    // double2 loads per thread; one load per loop trip would pay the memory latency 16 times)
+    {
+        const double2* __restrict__ xp2 = reinterpret_cast<const double2*>(x + u.x);  // panels start on even columns
+        double2* win2 = reinterpret_cast<double2*>(win);
+        const int n2 = u.y >> 1;
+        for (int i0 = 0; i0 < n2; i0 += 8 * THREADS) {
+            double2 t[8];
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * THREADS + (int)threadIdx.x;
+                t[j] = i < n2 ? xp2[i] : double2{0.0, 0.0};
+            }
+#pragma unroll
+            for (int j = 0; j < 8; ++j) {
+                const int i = i0 + j * THREADS + (int)threadIdx.x;
+                if (i < n2) win2[i] = t[j];
+            }
+        }
+        if ((u.y & 1) && threadIdx.x == 0) win[u.y - 1] = x[u.x + u.y - 1];
+    }
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);

@@ -332,10 +332,29 @@ int ehyb_gen_banded(int n, int band, int block, const ehyb_config* cfg, matrixCO
     return EHYB_OK;
 }
 
+static int gen_fem3d_impl(int n, int dof, int nx, int ny, int extra_ppm, int scramble, uint64_t seed, int block, int n_blocks,
+                          int near_min_ppm, const ehyb_config* cfg, matrixCOO* out);
+
 int ehyb_gen_fem3d(int n, int dof, int nx, int ny, int extra_ppm, int scramble, uint64_t seed,
                    const ehyb_config* cfg, matrixCOO* out)
 {
-    return ehyb_gen_fem3d_block(n, dof, nx, ny, extra_ppm, scramble, seed, 0, 1, cfg, out);
+    return gen_fem3d_impl(n, dof, nx, ny, extra_ppm, scramble, seed, 0, 1, -1, cfg, out);
+}
+
+// Graded mesh: the same grid, but how many couplings a node keeps follows a smooth density field
+// g in [0,1] over the grid (fine and coarse regions of an unstructured mesh): a first-shell coupling
+// is kept with probability near_min + (1 - near_min) * g, a second-shell coupling with probability
+// far_max * g^3, g taken at the sparser end of the coupling (the decision is the same from both
+// ends, so the matrix stays symmetric).  With near_min 0.25 and far_max 0.9 rows run from about 7 to
+// 115 node couplings -- 21 to 345 entries at 3 unknowns per node, audikw_1's range.
+int ehyb_gen_fem3d_graded(int n, int dof, int nx, int ny, int near_min_ppm, int far_max_ppm, int scramble, uint64_t seed,
+                          const ehyb_config* cfg, matrixCOO* out)
+{
+    if (near_min_ppm < 0 || near_min_ppm > 1000000 || far_max_ppm < 0 || far_max_ppm > 1000000) {
+        set_error("ehyb_gen_fem3d_graded: probabilities are parts per million");
+        return EHYB_ERR_ARG;
+    }
+    return gen_fem3d_impl(n, dof, nx, ny, far_max_ppm, scramble, seed, 0, 1, near_min_ppm, cfg, out);
 }
 
 // Rows of block `block` of n_blocks fem3d grids stacked along z: a matrix of dimension
@@ -345,6 +364,12 @@ int ehyb_gen_fem3d(int n, int dof, int nx, int ny, int extra_ppm, int scramble, 
 // a weak-scaling run generates its own rows only; (0, 1) is ehyb_gen_fem3d itself.
 int ehyb_gen_fem3d_block(int n, int dof, int nx, int ny, int extra_ppm, int scramble, uint64_t seed,
                          int block, int n_blocks, const ehyb_config* cfg, matrixCOO* out)
+{
+    return gen_fem3d_impl(n, dof, nx, ny, extra_ppm, scramble, seed, block, n_blocks, -1, cfg, out);
+}
+
+static int gen_fem3d_impl(int n, int dof, int nx, int ny, int extra_ppm, int scramble, uint64_t seed, int block, int n_blocks,
+                          int near_min_ppm, const ehyb_config* cfg, matrixCOO* out)
 {
     clear_error();
     if (!out || n <= 0 || dof <= 0 || nx <= 0 || ny <= 0 || n % dof != 0 || extra_ppm < 0)
@@ -372,6 +397,14 @@ int ehyb_gen_fem3d_block(int n, int dof, int nx, int ny, int extra_ppm, int scra
     }
     const std::vector<int>& perm = perms[1];
     const uint64_t thr = (uint64_t)extra_ppm;
+    const bool graded = near_min_ppm >= 0;
+    if (graded && n_blocks != 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_fem3d_graded: single block only");
+    // density field of the graded mesh, per grid position: a smooth product of three waves
+    auto density = [&](int x, int y, int z) {
+        const double a = std::sin(6.2831853 * 1.5 * (x + 0.5) / nx + 0.7), b = std::sin(6.2831853 * 1.0 * (y + 0.5) / ny + 1.3),
+                     c = std::sin(6.2831853 * 1.25 * (z + 0.5) / nz + 0.4);
+        return 0.5 + 0.5 * a * b * c;
+    };
     const int64_t grid_block = n_blocks > 1 ? (int64_t)nz * layer : 0;  // grid ids per block (last layer may be partial)
     // neighbours of grid node g of this block, including g itself, as global node labels
     auto neighbours = [&](int g, int* nb) {
@@ -389,7 +422,15 @@ int ehyb_gen_fem3d_block(int n, int dof, int nx, int ny, int extra_ppm, int scra
                         int64_t h = (int64_t)z * layer + (int64_t)y * nx + x;
                         if (h >= N) continue;
                         bool near = dx >= -1 && dx <= 1 && dy >= -1 && dy <= 1 && dz >= -1 && dz <= 1;
-                        if (!near) {
+                        if (graded) {
+                            const bool face = std::abs(dx) + std::abs(dy) + std::abs(dz) == 1;  // always kept: no row below 7 node couplings
+                            if (h != g && !face) {
+                                const double gd = std::min(density(ix, iy, iz), density(x, y, z));
+                                const double p = near ? near_min_ppm * 1e-6 + (1.0 - near_min_ppm * 1e-6) * gd : extra_ppm * 1e-6 * gd * gd * gd;
+                                uint64_t lo = std::min<int64_t>(g, h), hi = std::max<int64_t>(g, h);
+                                if ((double)(mix64(lo * 0x100000001B3ull + hi + seed) % 1000000ull) >= p * 1e6) continue;
+                            }
+                        } else if (!near) {
                             if (thr == 0) continue;
                             const int64_t gg = block * grid_block + g, hh = (block + o) * grid_block + h;
                             uint64_t lo = std::min<int64_t>(gg, hh), hi = std::max<int64_t>(gg, hh);

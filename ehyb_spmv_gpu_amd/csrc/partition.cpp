@@ -627,11 +627,11 @@ int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vw
         std::vector<int> cmap;
         coarsen_once(cur, max_vw, rng, &cg, &cmap);
         if (cg.n > cur.n * 0.93) {  // matching stalled
-            // EHYB_PART_AUTO: a graph that stops coarsening while it is still far from the target has
+            // EHYB_PART_AUTO: a graph that stops coarsening before it has even halved, far from the target, has
             // no locality for a k-way partitioner to find (R-MAT 2^24: 124 M of 133 M edges cut after
             // 110 s, most of them in the initial partition of a 15 M-vertex "coarsest" graph).
             // Contiguous blocks cost nothing and cut about as much.
-            if (cfg.partitioner == EHYB_PART_AUTO && cg.n > 8 * (int64_t)coarse_target) {
+            if (cfg.partitioner == EHYB_PART_AUTO && cg.n > 8 * (int64_t)coarse_target && cg.n > n / 2) {
                 if (cfg.verbose) printf("partition: matching stalled at %d of %d vertices: contiguous blocks\n", cg.n, n);
                 return contiguous();
             }

@@ -124,6 +124,10 @@ class Matrix:
             n, dof, nx, ny, ppm, scramble, seed = args
             rc = m.lib.ehyb_gen_fem3d(n, dof, nx, ny, ppm, scramble, seed, cp, C.byref(m.c))
             m.symmetric = True
+        elif kind == "fem3d_graded":
+            n, dof, nx, ny, near_ppm, far_ppm, scramble, seed = args
+            rc = m.lib.ehyb_gen_fem3d_graded(n, dof, nx, ny, near_ppm, far_ppm, scramble, seed, cp, C.byref(m.c))
+            m.symmetric = True
         elif kind == "fem3d_block":
             n, dof, nx, ny, ppm, scramble, seed, block, n_blocks = args
             rc = m.lib.ehyb_gen_fem3d_block(n, dof, nx, ny, ppm, scramble, seed, block, n_blocks, cp, C.byref(m.c))

@@ -425,6 +425,12 @@ int ehyb_gen_banded(int n, int band, int block, const ehyb_config* cfg, matrixCO
  * symmetric values; scramble != 0 applies a random relabelling of the nodes.            */
 int ehyb_gen_fem3d(int n, int dof, int nx, int ny, int extra_ppm, int scramble, uint64_t seed,
                    const ehyb_config* cfg, matrixCOO* out);
+/* audikw_1-like with a graded mesh: a smooth density field over the grid decides how many couplings a node
+ * keeps (first shell: probability near_min + (1 - near_min) * g; second shell: far_max * g^3; g in [0,1] at the
+ * sparser end of the coupling; both in parts per million), so row lengths spread like those of an
+ * unstructured mesh -- (250000, 900000) with 3 unknowns per node: about 21 to 345 entries per row. */
+int ehyb_gen_fem3d_graded(int n, int dof, int nx, int ny, int near_min_ppm, int far_max_ppm, int scramble, uint64_t seed,
+                          const ehyb_config* cfg, matrixCOO* out);
 /* The rows of block `block` of n_blocks such grids stacked along z (weak scaling: one block per
  * GPU, each rank generates only its own rows): dimension n*n_blocks, rows outside
  * [block*n, (block+1)*n) empty, every block labelled (scrambled) on its own, couplings reach two

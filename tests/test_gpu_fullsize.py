@@ -14,7 +14,10 @@ def _properties(E, O, c, plan, y_perm):
     n = c.n
     # exact scaling: A(2x) == 2 (Ax) bit for bit (power-of-two scaling commutes with rounding)
     y2 = plan.spmv_host(2.0 * c.xp)
-    assert np.array_equal(y2, 2.0 * y_perm)
+    if plan.stats["er_partials"] == 0:
+        assert np.array_equal(y2, 2.0 * y_perm)
+    else:
+        assert c.check(0.5 * y2)[0] == 0   # panel residual: LDS adds of a row block may land in another order
     # checksum of checksums: sum_i y_i == sum_j (column sum_j) x_j
     colsum = np.zeros(n)
     np.add.at(colsum, c.m.J, c.m.V)
@@ -25,8 +28,10 @@ def _properties(E, O, c, plan, y_perm):
     plan.spmv(dx.ptr, dy.ptr, phase=1)
     plan.spmv(dx.ptr, dy.ptr, phase=2)
     y_split = dy.download()
-    if plan.stats["er_inline"] == 0:
+    if plan.stats["er_inline"] == 0 and plan.stats["er_partials"] == 0:
         assert np.array_equal(y_split, y_perm)
+    elif plan.stats["er_inline"] == 0:
+        assert c.check(y_split)[0] == 0
     else:
         # a tiny residual rides inside the ELL launch (summed with the ELL entries before y is rounded
         # and stored), so the two-phase result may differ from the one-call result in the last bits
