@@ -223,26 +223,34 @@ __device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restr
     const int lrow = SYM ? (int)A.slab_lrow[(size_t)s * 64 + lane] : row - base;  // place in the LDS image
     const bool has_row = SYM ? lrow != 0xFFFF : row < pe;
     const double xi = (SYM && has_row) ? win[lrow] : 0.0;
+    // bit 7 of the record: the slab's columns are stored relative to the lane's own row (bands and
+    // stencils: rows with equal offsets share their words); lanes without a row read column 0
+    const uint32_t radd = (!SYM && (sm.w & 0x80u)) ? (uint32_t)lrow : 0u;
+    const uint32_t cmask = (SYM || has_row) ? 0xffffu : 0u;
+#define ELL_COL_LO(c) (SYM ? ((c) & 0xffffu) : ((((c) & 0xffffu) + radd) & cmask))
+#define ELL_COL_HI(c) (SYM ? ((c) >> 16) : ((((c) >> 16) + radd) & cmask))
     int k = 0;
     // (an 8-pair step for SYM, 128 VGPRs at 16 waves per CU, measured 1 % slower than this one)
     for (; k + 4 <= np; k += 4) {
         const double2 v0 = v[(k + 0) * 64], v1 = v[(k + 1) * 64], v2 = v[(k + 2) * 64], v3 = v[(k + 3) * 64];
         const uint32_t c0 = c[(k + 0) * G], c1 = c[(k + 1) * G], c2 = c[(k + 2) * G], c3 = c[(k + 3) * G];
-        ell_entry<SYM>(v0.x, c0 & 0xffffu, win, yacc, xi, code, acc0);
-        ell_entry<SYM>(v0.y, c0 >> 16, win, yacc, xi, code, acc1);
-        ell_entry<SYM>(v1.x, c1 & 0xffffu, win, yacc, xi, code, acc0);
-        ell_entry<SYM>(v1.y, c1 >> 16, win, yacc, xi, code, acc1);
-        ell_entry<SYM>(v2.x, c2 & 0xffffu, win, yacc, xi, code, acc0);
-        ell_entry<SYM>(v2.y, c2 >> 16, win, yacc, xi, code, acc1);
-        ell_entry<SYM>(v3.x, c3 & 0xffffu, win, yacc, xi, code, acc0);
-        ell_entry<SYM>(v3.y, c3 >> 16, win, yacc, xi, code, acc1);
+        ell_entry<SYM>(v0.x, ELL_COL_LO(c0), win, yacc, xi, code, acc0);
+        ell_entry<SYM>(v0.y, ELL_COL_HI(c0), win, yacc, xi, code, acc1);
+        ell_entry<SYM>(v1.x, ELL_COL_LO(c1), win, yacc, xi, code, acc0);
+        ell_entry<SYM>(v1.y, ELL_COL_HI(c1), win, yacc, xi, code, acc1);
+        ell_entry<SYM>(v2.x, ELL_COL_LO(c2), win, yacc, xi, code, acc0);
+        ell_entry<SYM>(v2.y, ELL_COL_HI(c2), win, yacc, xi, code, acc1);
+        ell_entry<SYM>(v3.x, ELL_COL_LO(c3), win, yacc, xi, code, acc0);
+        ell_entry<SYM>(v3.y, ELL_COL_HI(c3), win, yacc, xi, code, acc1);
     }
     for (; k < np; ++k) {
         const double2 v0 = v[k * 64];
         const uint32_t c0 = c[k * G];
-        ell_entry<SYM>(v0.x, c0 & 0xffffu, win, yacc, xi, code, acc0);
-        ell_entry<SYM>(v0.y, c0 >> 16, win, yacc, xi, code, acc1);
+        ell_entry<SYM>(v0.x, ELL_COL_LO(c0), win, yacc, xi, code, acc0);
+        ell_entry<SYM>(v0.y, ELL_COL_HI(c0), win, yacc, xi, code, acc1);
     }
+#undef ELL_COL_LO
+#undef ELL_COL_HI
     if (has_row) {
         if (SYM)
             unsafeAtomicAdd(&yacc[lrow], acc0 + acc1);  // other lanes scatter into the same accumulator
@@ -403,11 +411,12 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c0 = u.z >> 6, c1 = u.w >> 6;  // chunks of 64 entries
-    for (int c = c0 + 4 * wave; c < c1; c += 4 * WAVES) {
-        double v[4];
-        uint32_t cc[4], d[4];
+    constexpr int K = 8;  // chunks per wave and step: 24 independent loads in flight per lane
+    for (int c = c0 + K * wave; c < c1; c += K * WAVES) {
+        double v[K];
+        uint32_t cc[K], d[K];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < K; ++j) {
             const bool in = c + j < c1;
             const size_t pos = (size_t)(in ? c + j : c) * 64 + lane;
             v[j] = val[pos];
@@ -415,11 +424,13 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
             d[j] = in ? dst[pos] : 0xFFFFFFFFu;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            const double prod = v[j] * win[cc[j]];
-            const double sum = run_sum(prod, d[j], lane);
+        for (int j = 0; j < K; ++j) {
+            double sum = v[j] * win[cc[j]];
             const uint32_t before = __shfl_up(d[j], 1, 64);
-            if ((lane == 0 || before != d[j]) && d[j] != 0xFFFFFFFFu) partial[d[j]] = sum;
+            const bool head = lane == 0 || before != d[j];
+            // most chunks hold 64 different rows (every lane a head): the lane sums are only for the others
+            if (__ballot(!head) != 0ull) sum = run_sum(sum, d[j], lane);
+            if (head && d[j] != 0xFFFFFFFFu) partial[d[j]] = sum;
         }
     }
 }
@@ -439,34 +450,53 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_reduce_kernel(const int4* __r
     for (int i = threadIdx.x; i < u.w; i += THREADS) yacc[i] = 0.0;
     __syncthreads();
     const int lane = threadIdx.x & 63;
+    constexpr int K = 8;  // partials per thread and step: 16 independent loads in flight
     // every wave runs the same number of steps (the shuffles need all 64 lanes)
-    for (int base = u.x; base < u.y; base += 4 * THREADS) {
-        double v[4];
-        uint32_t r[4];
+    for (int base = u.x; base < u.y; base += K * THREADS) {
+        double v[K];
+        uint32_t r[K];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < K; ++j) {
             const int i = base + j * THREADS + (int)threadIdx.x;
             const bool in = i < u.y;
             v[j] = in ? partial[i] : 0.0;
             r[j] = in ? (uint32_t)row[i] : 0xFFFFFFFFu;
         }
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < K; ++j) {
             // a row may come back later in the same wave (next panel): runs are told apart by their
             // number -- how many run heads sit at or below the lane -- not by the row
             const uint32_t before = __shfl_up(r[j], 1, 64);
             const bool head = lane == 0 || before != r[j];
             const unsigned long long heads = __ballot(head);
-            const uint32_t run = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull));
-            const double sum = run_sum(v[j], run, lane);
+            double sum = v[j];
+            if (heads != ~0ull) {
+                const uint32_t run = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull));
+                sum = run_sum(sum, run, lane);
+            }
             if (head && r[j] != 0xFFFFFFFFu) unsafeAtomicAdd(&yacc[r[j]], sum);  // ds_add_f64
         }
     }
     __syncthreads();
+    // y[row] += accumulator for the rows that received something: the loads of a batch first, then the stores
     double* __restrict__ yp = y + u.z;
-    for (int i = threadIdx.x; i < u.w; i += THREADS) {
-        const double a = yacc[i];
-        if (a != 0.0) yp[i] += a;
+    for (int i0 = 0; i0 < u.w; i0 += K * THREADS) {
+        double a[K], yo[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int i = i0 + j * THREADS + (int)threadIdx.x;
+            a[j] = i < u.w ? yacc[i] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int i = i0 + j * THREADS + (int)threadIdx.x;
+            yo[j] = a[j] != 0.0 ? yp[i] : 0.0;
+        }
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int i = i0 + j * THREADS + (int)threadIdx.x;
+            if (a[j] != 0.0) yp[i] = yo[j] + a[j];
+        }
     }
 }
 
@@ -503,7 +533,7 @@ static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long 
     A.stamps = stamps;
     // on by default: plain storage 143 -> 134 us on the audikw_1-like matrix; EHYB_XCD_MAP=0 for the A/B
     static const int xcd_env = [] { const char* e = getenv("EHYB_XCD_MAP"); return e ? atoi(e) : 1; }();
-    A.xcd_map = xcd_env;
+    A.xcd_map = P->host.sym ? 0 : xcd_env;  // symmetric pairs: items are sorted heaviest first, dispatched in that order
     return A;
 }
 

@@ -35,6 +35,7 @@ struct PartScratch {
     std::vector<uint32_t> slab_w2;   // pairs per slab
     std::vector<uint32_t> slab_g;    // column-list groups per slab
     std::vector<uint32_t> slab_ner;  // residual pairs per slab (inline form only)
+    std::vector<uint8_t> slab_rel;   // 1: the slab stores its columns relative to the lane's own row
 };
 
 constexpr int kWideRow = 128;  // ELL entries per row above which the row is multiplied by the residual kernel
@@ -254,6 +255,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     std::vector<PartScratch> ps(np);
     std::vector<int32_t> cnt_ell(nrows, 0);
     std::vector<uint8_t> lead_row(nrows, 1);
+    std::vector<uint8_t> lead_rel(nrows, 1);  // the same for column lists taken RELATIVE to the row (bands, stencils)
     std::vector<uint8_t> row_to_er(nrows, 0);  // whole row in the residual (hub rows)
     // lane order inside a partition: slot t (slab t / 64, lane t % 64) holds row row_at[first + t]
     std::vector<int32_t> row_at(nrows), slot_of(nrows);
@@ -391,20 +393,53 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             // Column-list sharing: a row whose column sequence equals that of the row above it
             // (same slab) joins that row's group and stores no column indices of its own.
             // Finite-element matrices with d unknowns per node give groups of d rows.
+            // Relative form: a banded or stencil matrix in its natural order has no two rows with the same
+            // columns, but row after row with the same OFFSETS from its own diagonal position.  Stored as
+            // (column - own row) such rows share their words too; a slab takes whichever form needs fewer
+            // groups (bit 7 of its record word 3 says which).  Only for rows whose ELL entries all lie in the
+            // partition's own contiguous window (a halo column's place in LDS says nothing about its offset),
+            // plain storage.
             S.slab_g.assign(nslab, 0);
+            S.slab_rel.assign(nslab, 0);
+            std::vector<uint32_t> g_rel(nslab, 0);
+            auto own_window_only = [&](int r) {
+                for (int k = rp[r]; k < rp[r + 1]; ++k)
+                    if (m->J[k] < s || m->J[k] >= s + wlen) return false;
+                return true;
+            };
+            bool prev_inwin = false;
             for (int t = 0; t < own; ++t) {
                 const int r = rows_p[t], rprev = t > 0 ? rows_p[t - 1] : r;  // the row in the lane before
-                bool lead = true;
+                bool lead = true, leadr = true;
+                const bool inwin = share && !sym && !row_to_er[r - row_begin] && own_window_only(r);
                 if (share && t % kSlabRows != 0 && !row_to_er[r - row_begin] && !row_to_er[rprev - row_begin]) {
                     const int len = rp[r + 1] - rp[r];
                     lead = len != rp[rprev + 1] - rp[rprev] ||
                            (len > 0 && memcmp(m->J + rp[r], m->J + rp[rprev], sizeof(int) * (size_t)len) != 0);
                     // symmetric pairs: the kept / scatter / dropped pattern must be the same as well
                     if (!lead && sym && len > 0 && memcmp(&state[rp[r] - k0], &state[rp[rprev] - k0], (size_t)len) != 0) lead = true;
+                    if (inwin && prev_inwin && len == rp[rprev + 1] - rp[rprev]) {
+                        leadr = false;
+                        for (int k = 0; k < len && !leadr; ++k) leadr = m->J[rp[r] + k] - r != m->J[rp[rprev] + k] - rprev;
+                    }
                 }
+                prev_inwin = inwin;
                 lead_row[r - row_begin] = lead ? 1 : 0;
+                lead_rel[r - row_begin] = leadr ? 1 : 0;
                 S.slab_g[t / kSlabRows] += lead ? 1 : 0;
+                g_rel[t / kSlabRows] += leadr ? 1 : 0;
             }
+            for (int q = 0; q < nslab; ++q)
+                if (g_rel[q] < S.slab_g[q]) {
+                    // every row of the slab must qualify for the relative form, not only the sharing ones
+                    bool all_in = true;
+                    for (int t = q * kSlabRows; t < std::min(own, (q + 1) * kSlabRows) && all_in; ++t)
+                        all_in = row_to_er[rows_p[t] - row_begin] || own_window_only(rows_p[t]);
+                    if (all_in) {
+                        S.slab_rel[q] = 1;
+                        S.slab_g[q] = g_rel[q];
+                    }
+                }
         }
     }
     if (bad_col) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: column index outside [0,%d)", n);
@@ -492,7 +527,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 L->slab_meta[4 * sidx + 0] = (uint32_t)acc;
                 L->slab_meta[4 * sidx + 1] = (uint32_t)acc_c;
                 L->slab_meta[4 * sidx + 2] = (uint32_t)L->slab_row[sidx];
-                L->slab_meta[4 * sidx + 3] = (w2 << 16) | (ner << 8) | (g - 1);
+                L->slab_meta[4 * sidx + 3] = (w2 << 16) | (ner << 8) | (ps[p].slab_rel[q] ? 0x80u : 0u) | (g - 1);
                 // value stream: w2 ELL pairs then ner residual pairs, 64 lanes x 2 each;
                 // column stream: w2 x g shared words then ner x 128 global columns
                 acc += w2 + ner;
@@ -535,7 +570,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             const uint32_t ner = (L->slab_meta[4 * sidx + 3] >> 8) & 0xFF;
             const uint64_t cp = L->slab_col_ptr[sidx];
             const uint32_t G = (L->slab_meta[4 * sidx + 3] & 0x3F) + 1;
-            const bool lead = lead_row[r - row_begin] != 0;
+            const bool rel = (L->slab_meta[4 * sidx + 3] & 0x80u) != 0;
+            const bool lead = (rel ? lead_rel[r - row_begin] : lead_row[r - row_begin]) != 0;
             gid = lane == 0 ? 0 : gid + (lead ? 1 : 0);
             L->lane_group[(size_t)sidx * kSlabRows + lane] = (uint8_t)gid;
             if (t + 1 == e - s)  // lanes past the last row of the partition read the last group (values 0)
@@ -571,6 +607,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                         }
                         local |= 0x8000;  // bit 15: also add value * x[row] to row `local`
                     }
+                    if (rel) local = (local - (r - (s & ~1))) & 0xFFFF;  // relative to the lane's own place in the LDS image
                     if (lead)  // two 16-bit window-local columns per word, one word per pair and group
                         L->ell_col[(size_t)(cp + (uint64_t)(k_ell / 2) * G + gid)] |= (uint32_t)local << (16 * (k_ell & 1));
                     ++k_ell;
@@ -651,22 +688,36 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             if (c > cuts.back() && c < nslabs) cuts.push_back(c);
         }
         if (nslabs > 0) cuts.push_back(nslabs);
+        // item i = slabs [cut_lo[i], cut_hi[i])
+        std::vector<int64_t> cut_lo(cuts.begin(), cuts.end() - (cuts.empty() ? 0 : 1)), cut_hi(cuts.begin() + (cuts.empty() ? 0 : 1), cuts.end());
         if (sym) {
             // symmetric pairs: the accumulators of a partition's rows live in one workgroup's LDS, so
-            // an item is a whole partition (the reorder step makes them equal: nParts = k x 256)
-            cuts.clear();
-            for (int p = 0; p <= np; ++p)
-                if (cuts.empty() || slab_base[p] > cuts.back()) cuts.push_back(slab_base[p]);
+            // an item is a whole partition (the reorder step makes them equal: nParts = k x 256).
+            // Where they are not equal (entry-balanced partitions of a graded mesh, some of them bisected
+            // to fit the window) there are more items than CUs: heaviest first, so that the workgroups
+            // of the second round are the light ones (workgroups are dispatched in index order).
+            cut_lo.clear();
+            cut_hi.clear();
+            std::vector<int> order;
+            for (int p = 0; p < np; ++p)
+                if (slab_base[p + 1] > slab_base[p]) order.push_back(p);
+            std::stable_sort(order.begin(), order.end(), [&](int a, int b) {
+                return prefix[slab_base[a + 1]] - prefix[slab_base[a]] > prefix[slab_base[b + 1]] - prefix[slab_base[b]];
+            });
+            for (int p : order) {
+                cut_lo.push_back(slab_base[p]);
+                cut_hi.push_back(slab_base[p + 1]);
+            }
         }
         L->items.clear();
         L->segs.clear();
         int64_t window_loads = 0;
-        for (size_t i = 0; i + 1 < cuts.size(); ++i) {
+        for (size_t i = 0; i < cut_lo.size(); ++i) {
             const int32_t item = (int32_t)i;
             const int32_t seg_begin = (int32_t)(L->segs.size() / 8);
-            for (int64_t c = cuts[i]; c < cuts[i + 1];) {
+            for (int64_t c = cut_lo[i]; c < cut_hi[i];) {
                 const int p = L->slab_part[c];
-                const int64_t e = std::min<int64_t>(cuts[i + 1], slab_base[p + 1]);
+                const int64_t e = std::min<int64_t>(cut_hi[i], slab_base[p + 1]);
                 const int32_t hb = L->halo_ptr[p], hn = L->halo_ptr[p + 1] - L->halo_ptr[p];
                 const int32_t seg[8] = {p, (int32_t)c, (int32_t)e, hn, pb[p], pb[p + 1], L->win_len[p], hb};
                 L->segs.insert(L->segs.end(), seg, seg + 8);
@@ -674,7 +725,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 for (int64_t t = c; t < e; ++t) item_of_slab[t] = item;
                 c = e;
             }
-            const int32_t rec[8] = {seg_begin, (int32_t)(L->segs.size() / 8), (int32_t)cuts[i], (int32_t)cuts[i + 1], 0, 0, 0, 0};
+            const int32_t rec[8] = {seg_begin, (int32_t)(L->segs.size() / 8), (int32_t)cut_lo[i], (int32_t)cut_hi[i], 0, 0, 0, 0};
             L->items.insert(L->items.end(), rec, rec + 8);
         }
         L->stats.window_loads = window_loads;

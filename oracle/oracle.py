@@ -182,8 +182,10 @@ def walk_plan(plan, x):
     y_mirror = np.zeros(n)
     next_seg, next_slab = 0, 0
     for g0, g1, is0, is1, e0, e64, e16, e1 in items:
-        # an item = consecutive segments covering the consecutive slabs [is0, is1)
-        assert g0 == next_seg and g1 > g0 and is0 == next_slab and is1 > is0
+        # an item = consecutive segments covering the consecutive slabs [is0, is1); items follow each other
+        # in slab order -- except with symmetric pairs, where an item is a partition and the items are
+        # sorted heaviest first (every slab still belongs to exactly one item: `written` checks it)
+        assert g0 == next_seg and g1 > g0 and is1 > is0 and (sym or is0 == next_slab)
         assert segs[g0, 1] == is0 and segs[g1 - 1, 2] == is1
         next_seg, next_slab = g1, is1
         # the item's residual segments: rows inside the item's slab range, bins by length
@@ -237,6 +239,12 @@ def walk_plan(plan, x):
                     v = ell_val[p0 * 128:p1 * 128].reshape(npairs, 64, 2)
                     words = ell_col[scp[s]:scp[s] + npairs * G].reshape(npairs, G)[:, lane_group[s]]  # [pair][lane]
                     c = np.stack([words & 0xFFFF, words >> 16], axis=2)
+                    if meta[s, 3] & 0x80:
+                        # the slab stores its columns relative to the lane's own place in the LDS image;
+                        # lanes without a row read column 0
+                        assert not sym
+                        lrow_l = np.where(has, rows_l - base, 0)
+                        c = np.where(has[None, :, None], (c + lrow_l[None, :, None]) & 0xFFFF, 0)
                     if sym:
                         # symmetric pair storage: bit 15 = "this entry also stands for its mirror image":
                         # value * x[row of the lane] goes to row `column` of the same partition
