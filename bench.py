@@ -391,7 +391,7 @@ def main():
     ap.add_argument("--threads", type=int, default=0)
     ap.add_argument("--items-per-cu", type=int, default=0)
     ap.add_argument("--window-mode", type=int, default=0)
-    ap.add_argument("--er-mode", type=int, default=0, help="residual form: 0 automatic, 1 CSR segments, 2 panel form (cfg.er_mode)")
+    ap.add_argument("--er-mode", type=int, default=0, help="residual form: 0/1 CSR segments, 2 panel form (cfg.er_mode)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the TIMED CPU legs (the parity check stays)")
     ap.add_argument("--no-overlap", action="store_true", help="N>1: exchange first, then multiply (no stream overlap)")
     ap.add_argument("--no-plain-arm", action="store_true",

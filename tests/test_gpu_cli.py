@@ -75,3 +75,23 @@ def test_cli_item_order_switch(gpu, tmp_path, gen, items):
         p = subprocess.run([BIN, "-i", "5", "-g", gen, "-l", "2048"], cwd=tmp_path, capture_output=True, text=True,
                            timeout=600, env=env)
         assert p.returncode == 0 and "PASSED" in p.stdout, (xcd, p.stdout[-1500:] + p.stderr[-1500:])
+
+
+def test_bench_vendor_baseline_arm(gpu):
+    """bench.py --vendor-baseline: rocSPARSE CSR SpMV (the role of the reference's cuSPARSE baselines,
+    spmv.cu:135-281) on the same matrix and GPU, every algorithm checked against the CPU oracle, reported
+    beside the EHYB number in the same JSON line.  Opt-in: the product path never links rocSPARSE."""
+    import json
+    import sys
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "small", "--steps", "20", "--warmup", "3",
+                        "--vendor-baseline", "--no-cpu-baseline", "--no-plain-arm"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-2500:]
+    lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    out = json.loads(lines[0])
+    v = out["vendor_baseline"]
+    assert v["best"]["rows_over_1e-12"] == 0 and v["best"]["GFLOP/s"] > 0
+    assert out["parity"]["rows_over_1e-12"] == 0 and out["scaling"] == "none"
+    ldd = subprocess.run(["ldd", os.path.join(ROOT, "ehyb_spmv_gpu_amd", "libehyb.so")], capture_output=True, text=True).stdout
+    assert "rocsparse" not in ldd
