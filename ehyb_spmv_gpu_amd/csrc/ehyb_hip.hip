@@ -356,21 +356,6 @@ __global__ __launch_bounds__(THREADS) void ehyb_er_kernel(const int4* __restrict
 }
 
 // ------------------------------------------------------------------ panel residual (er_panel.cpp)
-// Segmented sum over the lanes of a wave: lanes that are neighbours and hold the same key form a run;
-// afterwards the FIRST lane of every run holds the run's sum.  (Runs are contiguous, so "key of lane
-// l + d equals mine" implies every lane in between does too.)
-template <class K>
-__device__ __forceinline__ double run_sum(double v, K key, int lane)
-{
-#pragma unroll
-    for (int d = 1; d < 64; d <<= 1) {
-        const double t = __shfl_down(v, d, 64);
-        const K k = __shfl_down(key, d, 64);
-        if (lane + d < 64 && k == key) v += t;
-    }
-    return v;
-}
-
 // Pass 1: one workgroup per unit {first column, columns, first entry, end entry}.  The unit's panel of
 // x is staged in LDS; (value, 16-bit local column, slot) are streamed, four 64-entry chunks per wave
 // and step (twelve independent loads in flight), the products of one row that sit next to each other
@@ -381,14 +366,16 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
                                                                 const uint16_t* __restrict__ col,
                                                                 const uint32_t* __restrict__ dst,
                                                                 const double* __restrict__ x,
-                                                                double* __restrict__ partial)
+                                                                double* __restrict__ partial, int panel_cols, int probe)
 {
+    // probe (tools/er_ab.py --probe, timing diagnostics only, results wrong): 1 no lane sums, 2 no stores,
+    // 4 no LDS gather, 8 no panel staging
     extern __shared__ __attribute__((aligned(16))) double win[];
     constexpr int WAVES = THREADS / 64;
     const int4 u = units[blockIdx.x];
     // stage the panel: all of a thread's loads in flight before the first store (a 64 KiB panel is 16
     // double2 loads per thread; one load per loop trip would pay the memory latency 16 times)
-    {
+    if (!(probe & 8)) {
         const double2* __restrict__ xp2 = reinterpret_cast<const double2*>(x + u.x);  // panels start on even columns
         double2* win2 = reinterpret_cast<double2*>(win);
         const int n2 = u.y >> 1;
@@ -410,6 +397,8 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* scr = win + panel_cols + 64 * wave;  // this wave's 64 piece accumulators, behind the panel
+    scr[lane] = 0.0;
     const int c0 = u.z >> 6, c1 = u.w >> 6;  // chunks of 64 entries
     constexpr int K = 8;  // chunks per wave and step: 24 independent loads in flight per lane
     for (int c = c0 + K * wave; c < c1; c += K * WAVES) {
@@ -425,12 +414,24 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            double sum = v[j] * win[cc[j]];
-            const uint32_t before = __shfl_up(d[j], 1, 64);
+            const double prod = (probe & 4) ? v[j] * (double)cc[j] : v[j] * win[cc[j]];
+            // head = first lane of a piece (entries of one row that are neighbours in this chunk share a slot)
+            const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)~d[j], (int)d[j], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
             const bool head = lane == 0 || before != d[j];
-            // most chunks hold 64 different rows (every lane a head): the lane sums are only for the others
-            if (__ballot(!head) != 0ull) sum = run_sum(sum, d[j], lane);
-            if (head && d[j] != 0xFFFFFFFFu) partial[d[j]] = sum;
+            const unsigned long long heads = __ballot(head);
+            double sum = prod;
+            if (heads != ~0ull && !(probe & 1)) {
+                // Some lanes share a slot: the piece sums are formed in this wave's 64 LDS words (zero between
+                // uses), one ds_add_f64 per lane, one read + one store of zero per piece.  (Shuffle trees --
+                // six ds_bpermute rounds per chunk -- cost 17 us of a 127 us launch here and 17 of 80 in pass 2.)
+                const int run = (int)__popcll(heads & ((2ull << lane) - 1ull)) - 1;
+                unsafeAtomicAdd(&scr[run], prod);
+                if (head) {
+                    sum = scr[run];
+                    scr[run] = 0.0;
+                }
+            }
+            if (head && d[j] != 0xFFFFFFFFu && (!(probe & 2) || sum == 123.456)) partial[d[j]] = sum;
         }
     }
 }
@@ -443,13 +444,14 @@ template <int THREADS>
 __global__ __launch_bounds__(THREADS) void ehyb_pb_reduce_kernel(const int4* __restrict__ units,
                                                                  const double* __restrict__ partial,
                                                                  const uint16_t* __restrict__ row,
-                                                                 double* __restrict__ y)
+                                                                 double* __restrict__ y, int probe)
 {
+    // probe (timing diagnostics only): 16 no lane sums, 32 no LDS adds, 64 no write-back, 128 no zeroing
     extern __shared__ __attribute__((aligned(16))) double yacc[];
     const int4 u = units[blockIdx.x];
-    for (int i = threadIdx.x; i < u.w; i += THREADS) yacc[i] = 0.0;
+    if (!(probe & 128))
+        for (int i = threadIdx.x; i < u.w; i += THREADS) yacc[i] = 0.0;
     __syncthreads();
-    const int lane = threadIdx.x & 63;
     constexpr int K = 8;  // partials per thread and step: 16 independent loads in flight
     // every wave runs the same number of steps (the shuffles need all 64 lanes)
     for (int base = u.x; base < u.y; base += K * THREADS) {
@@ -464,22 +466,15 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_reduce_kernel(const int4* __r
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            // a row may come back later in the same wave (next panel): runs are told apart by their
-            // number -- how many run heads sit at or below the lane -- not by the row
-            const uint32_t before = __shfl_up(r[j], 1, 64);
-            const bool head = lane == 0 || before != r[j];
-            const unsigned long long heads = __ballot(head);
-            double sum = v[j];
-            if (heads != ~0ull) {
-                const uint32_t run = (uint32_t)__popcll(heads & ((2ull << lane) - 1ull));
-                sum = run_sum(sum, run, lane);
-            }
-            if (head && r[j] != 0xFFFFFFFFu) unsafeAtomicAdd(&yacc[r[j]], sum);  // ds_add_f64
+            // (summing equal neighbouring rows across lanes first was measured: 17 us of an 80 us launch
+            // for nothing -- the LDS adds serialise the few same-row neighbours by themselves)
+            if (r[j] != 0xFFFFFFFFu && (!(probe & 32) || v[j] == 123.456)) unsafeAtomicAdd(&yacc[r[j]], v[j]);  // ds_add_f64
         }
     }
     __syncthreads();
     // y[row] += accumulator for the rows that received something: the loads of a batch first, then the stores
     double* __restrict__ yp = y + u.z;
+    if (probe & 64) return;
     for (int i0 = 0; i0 < u.w; i0 += K * THREADS) {
         double a[K], yo[K];
 #pragma unroll
@@ -588,11 +583,12 @@ static int launch_er(ehyb_plan* P, const double* x, double* y, hipStream_t st)
     const HostLayout& H = P->host;
     if (H.er_bins[3] == 0) return EHYB_OK;
     if (H.er_panel) {  // panel form: scale (x panels in LDS) then reduce (y blocks in LDS)
+        static const int pb_probe = [] { const char* e = getenv("EHYB_PB_PROBE"); return e ? atoi(e) : 0; }();  // timing diagnostics only
         const int u1 = (int)(H.pb_units1.size() / 4), u2 = (int)(H.pb_units2.size() / 4);
-        hipLaunchKernelGGL(ehyb_pb_scale_kernel<512>, dim3(u1), dim3(512), (size_t)H.pb_panel_cols * 8, st, (const int4*)P->d_pb_units1,
-                           P->d_pb_val, P->d_pb_col, P->d_pb_dst, x, P->d_pb_partial);
+        hipLaunchKernelGGL(ehyb_pb_scale_kernel<512>, dim3(u1), dim3(512), (size_t)(H.pb_panel_cols + 512) * 8, st, (const int4*)P->d_pb_units1,
+                           P->d_pb_val, P->d_pb_col, P->d_pb_dst, x, P->d_pb_partial, H.pb_panel_cols, pb_probe);
         hipLaunchKernelGGL(ehyb_pb_reduce_kernel<512>, dim3(u2), dim3(512), (size_t)H.pb_rows_max * 8, st, (const int4*)P->d_pb_units2,
-                           P->d_pb_partial, P->d_pb_row, y);
+                           P->d_pb_partial, P->d_pb_row, y, pb_probe);
         HIP_TRY(hipGetLastError());
         return EHYB_OK;
     }

@@ -812,10 +812,27 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     ehyb_stats& st = L->stats;
     st.rows_er = rows_er;
     L->er_panel = false;
-    // (er_mode 0 = automatic chooses the CSR segments: measured on R-MAT 2^22 the two forms are level --
-    // 204 vs 209 us for the residual -- and on a residual with locality the CSR form is well ahead,
-    // DESIGN.md 3.2; the panel form is there for er_mode = 2)
-    if (!L->inline_er && !direct && nnz_er > 0 && cfg.er_mode == 2) {
+    // er_mode 0 = automatic: the panel form for a LARGE residual WITHOUT locality.  The CSR kernel
+    // gathers x from global memory: where neighbouring rows read neighbouring columns (a structured
+    // residual: kkt3d on contiguous partitions) the gathers of a wave fall into a few cache lines and
+    // the kernel streams at 5.3 TB/s; where they do not (R-MAT) every entry is its own L2 request and the
+    // panel form wins.  Locality is read off the residual itself: distinct 128-byte
+    // lines of x per entry over windows of 1024 consecutive residual entries.
+    bool want_panel = cfg.er_mode == 2;
+    if (cfg.er_mode == 0 && !L->inline_er && !direct && nnz_er >= (1 << 21)) {
+        const int64_t win = 1024, nwin = std::min<int64_t>(64, nnz_er / win);
+        int64_t lines = 0;
+        std::vector<int32_t> tmp((size_t)win);
+        for (int64_t w = 0; w < nwin; ++w) {
+            const int64_t at = (nnz_er - win) * w / std::max<int64_t>(1, nwin - 1);
+            for (int64_t k = 0; k < win; ++k) tmp[(size_t)k] = L->er_col[(size_t)(at + k)] >> 4;
+            std::sort(tmp.begin(), tmp.end());
+            lines += std::unique(tmp.begin(), tmp.end()) - tmp.begin();
+        }
+        want_panel = lines * 2 > nwin * win;  // more than one new line per two entries: no locality to speak of
+        if (cfg.verbose) printf("residual locality: %.3f distinct x lines per entry -> %s form\n", (double)lines / (double)(nwin * win), want_panel ? "panel" : "CSR");
+    }
+    if (!L->inline_er && !direct && nnz_er > 0 && want_panel) {
         const int rc_pb = build_panel_residual(cfg, L);
         if (rc_pb != EHYB_OK) return rc_pb;
     }

@@ -122,12 +122,13 @@ typedef struct ehyb_config {
                               allocated by this library (ehyb_mm_read, ehyb_gen_*, ehyb_matrix_from_csr) hold
                               dimension+1 entries; the reference harness callocs `dimension`
                               (solver_test.c:42,146), which is what matrixReorder[_unsym] assume.          */
-    int32_t er_mode;       /* form of a residual too large to ride inside the ELL launch: 0/1 = CSR segments
+    int32_t er_mode;       /* form of a residual too large to ride inside the ELL launch: 1 = CSR segments
                               (ehyb_er_kernel: x gathered from global memory), 2 = panel form (two streaming passes,
-                              x panels and y blocks in LDS: er_panel.cpp; measured level with the CSR form on
-                              R-MAT and behind it where the residual has locality, so never chosen automatically) */
+                              x panels and y blocks in LDS: er_panel.cpp), 0 = automatic: the panel form from 2^21
+                              residual entries up when the residual shows no locality (more than one distinct
+                              128-byte line of x per two consecutive entries), else CSR segments            */
     int32_t er_panel_cols; /* panel form: columns per x panel staged in LDS (<= 16384, default 8192 = 64 KiB)          */
-    int32_t er_block_rows; /* panel form: most rows of a y block accumulated in LDS (<= 16384, default 8192)          */
+    int32_t er_block_rows; /* panel form: most rows of a y block accumulated in LDS (<= 16384, default 2048)          */
     int32_t direct;        /* small matrices: 0 = automatic (plans of at most EHYB_DIRECT_MAX_ROWS rows, single GPU,
                               plain storage, window sizing left at its defaults), 1 = on, 2 = off.  On: no LDS window at all -- every row is multiplied by
                               the row-segment kernel straight from global x (which sits in L2 at this size), one

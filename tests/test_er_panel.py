@@ -38,8 +38,8 @@ def test_panel_form_walks_to_the_reference_product(E, O, name, kind, args, kw):
 
 
 def test_mode_selection(E, O):
-    """er_mode 0/1 = CSR segments, 2 = panel form; a tiny residual rides inside the ELL launch whatever
-    er_mode says."""
+    """er_mode 1 = CSR segments, 2 = panel form, 0 = panel form only for a large residual (2^21 entries up)
+    without locality; a tiny residual rides inside the ELL launch whatever er_mode says."""
     cfg1 = E.make_config(er_mode=1, lds_doubles=512)
     c = Case(E, O, "rmat", (14, 1 << 17, 1), cfg1)
     assert E.Plan(c.m, cfg1, upload=False).stats["er_partials"] == 0
