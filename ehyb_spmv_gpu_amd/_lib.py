@@ -60,7 +60,7 @@ class Config(C.Structure):
         ("er_panel_cols", C.c_int32),
         ("er_block_rows", C.c_int32),
         ("direct", C.c_int32),
-        ("reserved", C.c_int32 * 1),
+        ("ell_prune", C.c_int32),
     ]
 
 

@@ -431,7 +431,12 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
                     scr[run] = 0.0;
                 }
             }
-            if (head && d[j] != 0xFFFFFFFFu && (!(probe & 2) || sum == 123.456)) partial[d[j]] = sum;
+            if (head && d[j] != 0xFFFFFFFFu && (!(probe & 2) || sum == 123.456)) {
+                if (probe & 256)
+                    __builtin_nontemporal_store(sum, &partial[d[j]]);
+                else
+                    partial[d[j]] = sum;
+            }
         }
     }
 }

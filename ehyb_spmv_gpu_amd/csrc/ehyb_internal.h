@@ -48,6 +48,7 @@ struct Config {
     int er_panel_cols;
     int er_block_rows;
     int direct;             // 0 automatic, 1 on, 2 off
+    int ell_prune;          // 0/1: windows that cost more than the panel residual are given up, 2 = never
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -69,6 +70,7 @@ struct HostLayout {
     std::vector<int32_t> win_len;        // [n_parts] contiguous window length (from part start)
     std::vector<int32_t> halo_ptr;       // [n_parts+1]
     std::vector<int32_t> halo_cols;      // gathered columns (global ids), ascending per part
+    std::vector<int64_t> part_nnz_ell;   // [n_parts] stored ELL entries of the partition without padding (host only)
 
     // per slab (64 rows, one wave)
     std::vector<uint32_t> slab_pair_ptr;  // [n_slabs+1] prefix of (width/2)
@@ -125,9 +127,11 @@ struct HostLayout {
     ehyb_stats stats{};
 };
 
-int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* out);
+int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* out,
+                 const std::vector<uint8_t>* part_to_er = nullptr);
 int build_panel_residual(const Config& cfg, HostLayout* L);  // er_panel.cpp; reads the CSR residual of *L
-bool sym_storage_suits(const matrixCOO* m);  // spmvGPuEHYB's own choice of the storage (plan.cpp)
+bool sym_storage_suits(const matrixCOO* m);
+int windows_that_do_not_pay(const HostLayout& H, std::vector<uint8_t>* to_er, int64_t* entries_moved);  // plan.cpp  // spmvGPuEHYB's own choice of the storage (plan.cpp)
 
 // ---------------------------------------------------------------- partitioner
 int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vwgt, int nparts,

@@ -151,7 +151,10 @@ void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64
 
 }  // namespace
 
-int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* L)
+// part_to_er (may be null): partitions (by their index in the layout's own partition list) whose rows go
+// to the residual whole -- no window, no halo, zero-width slabs (plan.cpp decides, see ell_pays()).
+int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* L,
+                 const std::vector<uint8_t>* part_to_er)
 {
     if (!m || !L) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: null argument");
     const int n = m->dimension;
@@ -272,7 +275,10 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             const int own = e - s;
             int wlen;
             PartScratch& S = ps[p];
-            if (!halo_mode) {
+            const bool whole_to_er = part_to_er && (size_t)p < part_to_er->size() && (*part_to_er)[p] != 0 && !sym;
+            if (whole_to_er) {
+                wlen = 0;  // nothing of this partition is multiplied from a window: nothing is staged
+            } else if (!halo_mode) {
                 wlen = std::min(lds - (s & 1), std::min(n, cfg.n_top > 1 ? row_end : n) - s);
             } else {
                 wlen = own;
@@ -336,7 +342,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 // workgroup needs for everything else (R-MAT: a 5-slab item of 131 pairs each ended
                 // at 116 us of a 120 us launch).  Such rows go to the residual whole, where 64 lanes
                 // share a row.
-                if ((cfg.hub_rule != 2 && c > kWideRow) || direct) {
+                if ((cfg.hub_rule != 2 && c > kWideRow) || direct || whole_to_er) {
                     row_to_er[r - row_begin] = 1;
                     c = 0;
                 }
@@ -452,6 +458,9 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         er_rp[r + 1] = er_rp[r] + (len - cnt_ell[r]);
     }
     const int64_t nnz_er = er_rp[nrows];
+    L->part_nnz_ell.assign(np, 0);
+    for (int p = 0; p < np; ++p)
+        for (int r = pb[p]; r < pb[p + 1]; ++r) L->part_nnz_ell[p] += cnt_ell[r - row_begin];
     const int64_t nnz = (int64_t)rp[row_end] - rp[row_begin];
     const int64_t nnz_ell = nnz - nnz_er;  // entries the ELL part stands for (a kept pair entry counts twice)
     int64_t stored_ell = 0, sym_kept = 0;

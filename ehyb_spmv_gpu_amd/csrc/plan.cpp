@@ -16,6 +16,39 @@ namespace ehyb {
 //   * a sample of its off-diagonal entries has bitwise equal mirror images (a_ij == a_ji).
 // The result never depends on the answer (entries without a partner are stored as they are); only
 // the speed does.
+// Does the LDS window of a partition pay, next to the panel form of the residual?
+//   window:  8 B per stored value (padding included) + its column words, 8 B per staged own row, one
+//            cache line (64 B of fabric and an L2 request -- the scarce resource) per
+//            gathered halo column;
+//   panel:   ~30 B streamed per entry.
+// R-MAT 2^22: the ELL launch took 100 us for 9.6 M entries (10.4 ns each: 40 % padding, 3.3 M halo
+// gathers) while the panel residual did 23.3 M in 142-155 us (6.4 ns each).  -> number of partitions
+// to move, flags per partition of the layout.
+int windows_that_do_not_pay(const HostLayout& H, std::vector<uint8_t>* to_er, int64_t* entries_moved)
+{
+    const int np = H.n_parts;
+    to_er->assign((size_t)np, 0);
+    std::vector<int64_t> stored((size_t)np, 0), words((size_t)np, 0);
+    for (size_t s = 0; s < H.slab_part.size(); ++s) {
+        stored[H.slab_part[s]] += (int64_t)(H.slab_meta[4 * s + 3] >> 16) * 2 * kSlabRows;
+        words[H.slab_part[s]] += (int64_t)(H.slab_meta[4 * s + 3] >> 16) * ((H.slab_meta[4 * s + 3] & 0x3F) + 1);
+    }
+    int count = 0;
+    *entries_moved = 0;
+    for (int p = 0; p < np; ++p) {
+        const int64_t entries = H.part_nnz_ell[p];
+        if (entries == 0) continue;
+        const int64_t halo = H.halo_ptr[p + 1] - H.halo_ptr[p];
+        const int64_t window = 8 * stored[p] + 4 * words[p] + 8 * (int64_t)H.win_len[p] + 64 * halo;
+        if (window * 10 > 30 * entries * 11) {  // more than 10 % dearer than the panel form
+            (*to_er)[p] = 1;
+            ++count;
+            *entries_moved += entries;
+        }
+    }
+    return count;
+}
+
 bool sym_storage_suits(const matrixCOO* m)
 {
     const int n = m->dimension;
@@ -69,6 +102,18 @@ int ehyb_plan_create_host(const matrixCOO* m, int row_begin, int row_end, const 
     int rc;
     try {
         rc = build_layout(m, row_begin, row_end, P->cfg, &P->host);
+        // Where the residual runs in panel form (a large residual without locality: R-MAT), a partition
+        // whose window does not pay is better off in the residual whole: built a second time with those.
+        if (rc == EHYB_OK && P->host.er_panel && !P->host.sym && P->cfg.er_mode != 1 && P->cfg.ell_prune != 2) {
+            std::vector<uint8_t> to_er;
+            int64_t moved = 0;
+            if (windows_that_do_not_pay(P->host, &to_er, &moved) > 0) {
+                if (P->cfg.verbose) printf("%lld ELL entries sit in windows that cost more than the panel residual: rebuilt with those partitions in the residual\n", (long long)moved);
+                HostLayout again;
+                rc = build_layout(m, row_begin, row_end, P->cfg, &again, &to_er);
+                if (rc == EHYB_OK) P->host = std::move(again);
+            }
+        }
     } catch (const std::bad_alloc&) {
         set_error("ehyb_plan_create_host: out of memory while building the layout");
         rc = EHYB_ERR_ALLOC;

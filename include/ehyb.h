@@ -136,7 +136,9 @@ typedef struct ehyb_config {
                               1024-thread workgroup is the wrong shape when the whole matrix is a few MB: the
                               reference has a small-matrix branch for the same reason (kernel.cu:197-284,
                               solver_test.c:56-69).                                                           */
-    int32_t reserved[1];
+    int32_t ell_prune;     /* with the residual in panel form: 0/1 = a partition whose LDS window costs more bytes and
+                              L2 requests than the panel form would for its entries (padding, halo gathers: power-law
+                              matrices) goes to the residual whole, 2 = never                                 */
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);

@@ -46,6 +46,7 @@ def main():
         for pc in args.panel_cols.split(","):
             for br in args.block_rows.split(","):
                 arms.append((f"panel{pc}x{br}", dict(er_mode=2, er_panel_cols=int(pc), er_block_rows=int(br))))
+                arms.append((f"panel{pc}x{br}-windows-kept", dict(er_mode=2, er_panel_cols=int(pc), er_block_rows=int(br), ell_prune=2)))
         for tag, kw in arms:
             cfg = E.make_config(partitioner=part, fuse_er=2, **kw)
             t0 = time.time()
@@ -55,7 +56,7 @@ def main():
             bad, worst = O.check_tolerance(E.vector_recover(yd.download(), perm), y_ref, scale)
             st = plan.stats
             ms = r["ms_total"] / args.iters
-            print(json.dumps({"workload": wl, "arm": tag, "rows": n, "nnz": nnz, "nnz_er": st["nnz_er"], "er_partials": st["er_partials"],
+            print(json.dumps({"workload": wl, "arm": tag, "rows": n, "nnz": nnz, "nnz_ell": st["nnz_ell"], "nnz_er": st["nnz_er"], "er_partials": st["er_partials"],
                               "us_spmv": round(ms * 1e3, 2), "us_ell": round(r["ms_ell_avg"] * 1e3, 2), "us_er": round(r["ms_er_avg"] * 1e3, 2),
                               "GFLOPs": round(2.0 * nnz / ms / 1e6, 1), "er_format_bytes": st["bytes_format"] - st["bytes_format_ell"],
                               "er_GBps": round((st["bytes_format"] - st["bytes_format_ell"]) / max(r["ms_er_avg"], 1e-9) / 1e6, 1),
