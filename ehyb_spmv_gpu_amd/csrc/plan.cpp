@@ -40,7 +40,8 @@ int windows_that_do_not_pay(const HostLayout& H, std::vector<uint8_t>* to_er, in
         if (entries == 0) continue;
         const int64_t halo = H.halo_ptr[p + 1] - H.halo_ptr[p];
         const int64_t window = 8 * stored[p] + 4 * words[p] + 8 * (int64_t)H.win_len[p] + 64 * halo;
-        if (window * 10 > 30 * entries * 11) {  // more than 10 % dearer than the panel form
+        static const int64_t pct = [] { const char* e = getenv("EHYB_PRUNE_PCT"); return e ? atoll(e) : 110ll; }();  // tuning sweeps only
+        if (window * 100 > 30 * entries * pct) {  // more than 10 % dearer than the panel form
             (*to_er)[p] = 1;
             ++count;
             *entries_moved += entries;

@@ -37,7 +37,8 @@ def random_config_kwargs(rng):
                 col_sharing=int(rng.choice([1, 2])), sym_pairs=int(rng.choice([0, 1])) if mode == 2 else 0,
                 cap_split=int(rng.choice([1, 2])), hub_rule=int(rng.choice([1, 2])),
                 er_mode=int(rng.choice([0, 1, 2])), er_panel_cols=int(rng.choice([256, 1024, 8192])),
-                er_block_rows=int(rng.choice([64, 1000, 8192])), direct=int(rng.choice([0, 0, 1, 2])))
+                er_block_rows=int(rng.choice([64, 1000, 8192])), direct=int(rng.choice([0, 0, 1, 2])),
+                ell_prune=int(rng.choice([1, 1, 2])))
 
 
 def build(E, O, seed):

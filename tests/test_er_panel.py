@@ -86,3 +86,26 @@ def test_plan_cache_round_trip_with_panel_form(E, O, tmp_path):
     with pytest.raises(E.EhybError) as e:
         E.Plan.load(bad, upload=False)
     assert e.value.code == 6
+
+
+def test_windows_that_do_not_pay_go_to_the_residual(E, O):
+    """With the residual in panel form a partition whose LDS window costs more (padding, halo gathers)
+    than the panel form would for its entries is given to the residual whole: no window, no halo,
+    zero-width slabs (cfg.ell_prune; plan.cpp windows_that_do_not_pay)."""
+    kw = dict(er_mode=2, lds_doubles=1024, er_panel_cols=1024)
+    c = Case(E, O, "rmat", (15, 1 << 19, 5), E.make_config(**kw))
+    kept = E.Plan(c.m, E.make_config(ell_prune=2, **kw), upload=False)
+    pruned = E.Plan(c.m, E.make_config(**kw), upload=False)
+    a, b = kept.stats, pruned.stats
+    assert b["nnz_ell"] < a["nnz_ell"] and b["nnz_er"] > a["nnz_er"] and b["nnz_ell"] + b["nnz_er"] == c.nnz
+    assert b["halo_cols"] < a["halo_cols"]
+    wl = pruned.array("win_len")
+    assert (wl == 0).any() and (wl > 0).any()
+    # a partition without a window stages nothing and its slabs are empty
+    segs = pruned.array("segs").reshape(-1, 8)
+    meta = pruned.array("slab_meta").reshape(-1, 4)
+    for p_, s0, s1, hn, ps, pe, w, hb in segs:
+        if w == 0:
+            assert hn == 0 and not (meta[s0:s1, 3] >> 16).any()
+    y, written = O.walk_plan(pruned, c.xp)
+    assert written[:c.n].min() == 1 and c.check(y)[0] == 0

@@ -67,7 +67,9 @@ def test_bad_files_are_refused(E, O, tmp_path):
     assert e.value.code == 6
     # a flipped count in the middle of the file: sizes no longer fit together
     bad = bytearray(data)
-    off = data.index(b"EHYBPLN7") + 8 + 8 + 22 * 4 + 20 * 4 + 2 * 8 + 24 * 8   # key, Config, scalars, stats -> count of perm
+    perm_bytes = np.ascontiguousarray(c.perm, dtype=np.int32).tobytes()
+    off = data.index(perm_bytes) - 8                      # the 64-bit element count in front of the stored permutation
+    assert int.from_bytes(data[off:off + 8], "little") == c.n
     bad[off:off + 8] = (int.from_bytes(bad[off:off + 8], "little") - 3).to_bytes(8, "little")
     (tmp_path / "bad.ehyb").write_bytes(bytes(bad))
     with pytest.raises(E.EhybError) as e:
