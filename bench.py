@@ -551,7 +551,9 @@ def main():
     fmt_ell = st["bytes_format_ell"]
     fmt_er = st["bytes_format"] - fmt_ell
     if er_ms > ell_ms:
-        kname, k_ms, k_alg, k_fmt = "ehyb_er_kernel", er_ms, alg_er, fmt_er
+        # the residual launch(es): ehyb_er_kernel (CSR segments) or the two passes of the panel form
+        kname = "ehyb_pb_scale_kernel+ehyb_pb_reduce_kernel" if st["er_partials"] > 0 else "ehyb_er_kernel"
+        k_ms, k_alg, k_fmt = er_ms, alg_er, fmt_er
     else:
         kname, k_ms, k_alg, k_fmt = "ehyb_ell_kernel", ell_ms, alg_ell, fmt_ell
     traffic = pmc_traffic(args.workload, st["sym_pairs"] > 0, kname)
@@ -566,7 +568,8 @@ def main():
                 "alg_frac": round(k_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "ell_kernel_avg_launch_ms": round(ell_ms, 5),
                 "er_kernel_avg_launch_ms": None if (inline or empty) else round(er_ms, 5),
-                "residual": "empty" if empty else ("inline in the ELL launch" if inline else "own launch"),
+                "residual": "empty" if empty else ("inline in the ELL launch" if inline else
+                                                   ("panel form: two launches (x panels, then y blocks in LDS)" if st["er_partials"] > 0 else "own launch (CSR segments)")),
                 "format_bytes_per_spmv": st["bytes_format"],
                 "whole_spmv_real_frac": round(st["bytes_format"] / ((ell_ms + er_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "whole_spmv_alg_GBps": round(st["bytes_alg"] / ((ell_ms + er_ms) * 1e-3) / 1e9, 1)}
