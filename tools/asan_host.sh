@@ -11,7 +11,7 @@ OUT="$ROOT/_ab"
 TMP="$(mktemp -d)"
 mkdir -p "$OUT"
 make -C "$SRC" -j8 >/dev/null                      # the HIP objects (build/ehyb_hip.o, build/ehyb_cg.o)
-for f in common partition reorder layout plan plan_io matrix_io; do
+for f in common partition reorder layout er_panel plan plan_io matrix_io; do
     g++ -O1 -g -fPIC -fopenmp -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer \
         -I"$ROOT/include" -I"$SRC" -c "$SRC/$f.cpp" -o "$TMP/$f.o"
 done
