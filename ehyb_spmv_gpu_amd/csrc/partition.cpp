@@ -408,10 +408,59 @@ int refine_kway(const GView& g, int k, int64_t cap, int passes, std::vector<int>
         }
     }
     std::fill(flag.begin(), flag.end(), 0);  // from here on: "queued for the next pass"
+    // A pass = a parallel FILTER over the work list against a snapshot of the partition (which vertices
+    // have a move worth making at all: a positive gain, a tie that improves the balance, or a way out of
+    // an overfull part), then the exact greedy step below, serially, for those vertices only.  Most
+    // boundary vertices have no such move, so the serial part -- the 1.4 s of the 2.0-2.4 s pre-step of
+    // the audikw_1-like matrix in round 1 -- shrinks to the few per cent that do.  A vertex that only
+    // becomes movable through a move made earlier in the same pass is queued for the next pass like
+    // every neighbour of a moved vertex.  The filter reads only the snapshot: the outcome does not
+    // depend on the thread count.
+    std::vector<char> cand;
     for (int pass = 0; pass < passes && !work.empty(); ++pass) {
         int moves = 0;
         next.clear();
-        for (int v : work) {
+        const bool filter = work.size() >= 4096;
+        if (filter) {
+            cand.assign(work.size(), 0);
+#pragma omp parallel
+            {
+                std::vector<int> lconn(k, 0), ltouched;
+                ltouched.reserve(64);
+#pragma omp for schedule(dynamic, 512)
+                for (int64_t wi = 0; wi < (int64_t)work.size(); ++wi) {
+                    const int v = work[wi];
+                    const int pv = part[v];
+                    ltouched.clear();
+                    int id = 0;
+                    for (int64_t e = g.xadj[v]; e < g.xadj[v + 1]; ++e) {
+                        const int u = g.adj[e];
+                        if (u == v) continue;
+                        const int pu = part[u], w = g.we(e);
+                        if (pu == pv)
+                            id += w;
+                        else {
+                            if (lconn[pu] == 0) ltouched.push_back(pu);
+                            lconn[pu] += w;
+                        }
+                    }
+                    const int wv = g.wv(v);
+                    const bool over = pw[pv] > cap;
+                    char c = 0;
+                    for (int p : ltouched) {
+                        if (!c && pw[p] + wv <= cap + wv) {  // (weights move during the pass: a little slack here, the exact test below)
+                            const int gain = lconn[p] - id;
+                            c = gain > 0 || (gain == 0 && pw[p] + wv < pw[pv]) || over;
+                        }
+                        lconn[p] = 0;
+                    }
+                    cand[wi] = c;
+                }
+            }
+        }
+        for (size_t wi = 0; wi < work.size(); ++wi) {
+            const int v = work[wi];
+            if (filter && !cand[wi]) continue;
             int pv = part[v];
             touched.clear();
             int id = 0;

@@ -84,11 +84,31 @@ static void build_adjacency(const matrixCOO* m, bool symmetric_pattern, std::vec
     const int n = m->dimension;
     const int64_t nnz = m->totalNum;
     xadj->assign((size_t)n + 1, 0);
+    if (symmetric_pattern) {
+        // every (i,j) has its (j,i) stored and the input is row-grouped (rowIdx delimits the rows): row i of
+        // the adjacency is row i of the matrix without its diagonal -- rows are independent
+        const int* rp = m->rowIdx;
+#pragma omp parallel for schedule(static, 4096)
+        for (int i = 0; i < n; ++i) {
+            int c = 0;
+            for (int k = rp[i]; k < rp[i + 1]; ++k) c += m->J[k] != i;
+            (*xadj)[i + 1] = c;
+        }
+        for (int i = 0; i < n; ++i) (*xadj)[i + 1] += (*xadj)[i];
+        adj->resize((size_t)(*xadj)[n]);
+#pragma omp parallel for schedule(static, 4096)
+        for (int i = 0; i < n; ++i) {
+            int64_t at = (*xadj)[i];
+            for (int k = rp[i]; k < rp[i + 1]; ++k)
+                if (m->J[k] != i) (*adj)[at++] = m->J[k];
+        }
+        return;
+    }
     for (int64_t k = 0; k < nnz; ++k) {
         int i = m->I[k], j = m->J[k];
         if (i == j) continue;
         (*xadj)[i + 1]++;
-        if (!symmetric_pattern) (*xadj)[j + 1]++;
+        (*xadj)[j + 1]++;
     }
     for (int i = 0; i < n; ++i) (*xadj)[i + 1] += (*xadj)[i];
     adj->assign((size_t)(*xadj)[n], 0);
@@ -97,7 +117,7 @@ static void build_adjacency(const matrixCOO* m, bool symmetric_pattern, std::vec
         int i = m->I[k], j = m->J[k];
         if (i == j) continue;
         (*adj)[fill[i]++] = j;
-        if (!symmetric_pattern) (*adj)[fill[j]++] = i;
+        (*adj)[fill[j]++] = i;
     }
 }
 
