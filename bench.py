@@ -228,8 +228,10 @@ def run_weak(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
 
 def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     """N > 1, strong scaling (BASELINE config 5): ONE matrix sharded by rows.  Every rank
-    generates the matrix (deterministic generators; a real deployment reads its rows from a file),
-    keeps rows [r0, r1) of the nnz-balanced row blocks, builds its plan from them alone and exchanges x
+    generates the matrix (deterministic generators; a real deployment reads its rows from a file), cuts
+    the rows into one block per GPU -- a k-way graph partition balanced on entries where the matrix has
+    locality, contiguous nnz-balanced blocks for R-MAT --, keeps rows [r0, r1) of its block, builds its
+    plan from them alone (window-sized partitions inside: the second level) and exchanges x
     every step: `--exchange allgather` = the x segments, padded to equal length, through one RCCL
     all_gather_into_tensor (what north_star names); `--exchange halo` = only the entries the rank's
     rows reference, through one all_to_all_single.  The ELL phase (local columns) overlaps either."""
@@ -243,14 +245,27 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     m = E.Matrix.generate(gen, *gargs, cfg=cfg)
     n, nnz = m.n, m.nnz
     log(f"[bench] every rank generated {args.workload}: n={n} nnz={nnz} in {time.time() - t0:.1f}s")
+    x = E.x_glibc(n)
+    if gen == "rmat":
+        # no locality to find: contiguous row blocks of equal entry counts in the matrix's own numbering
+        cuts = D.balanced_row_cuts(m.row_idx.astype(np.int64), world)
+    else:
+        # top level of the two-level partition: a k-way graph partition into one block of rows
+        # per GPU, balanced on entries, so that a GPU's rows reference few columns of the others; the
+        # matrix and x are taken into that numbering (every rank computes the same permutation)
+        t0 = time.time()
+        cfg_top = E.make_config(n_top=world, host_threads=int(cfg.host_threads))
+        m.reorder(cfg_top)
+        pb = m.part_boundary
+        cuts = [int(pb[b]) for b in m.block_first]
+        x = E.vector_reorder(x, m.reorder_list)
+        log(f"[bench] top-level partition into {world} row blocks in {time.time() - t0:.1f}s")
     rowptr = m.row_idx.astype(np.int64)
-    cuts = D.balanced_row_cuts(rowptr, world)
     r0, r1 = cuts[rank], cuts[rank + 1]
     k0, k1 = int(rowptr[r0]), int(rowptr[r1])
     I, J, V = m.I[k0:k1].copy(), m.J[k0:k1].copy(), m.V[k0:k1].copy()
     symmetric = gen in SYMMETRIC_GENERATORS
     m.free()
-    x = E.x_glibc(n)
     y_cpu = O.spmv_coo(n, I, J, V, x)[r0:r1]      # checker (not timed): the oracle on this rank's rows
     scale = O.abs_rowsum(n, I, J, V, x)[r0:r1]
     t0 = time.time()
@@ -292,7 +307,9 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
                        "ghost_columns_per_gpu_max": int(mx[0].item()),
                        "functional_mode": "gloo, host-staged" if stage_on_cpu else None},
             "local_multiply_ms_max_over_ranks": round(float(mx[1].item()), 5),
-            "n1_equivalent": "the N = 1 line's scaling_anchor (same matrix, one GPU)",
+            "n1_equivalent": ("the N = 1 line's scaling_anchor (same matrix, one GPU)" if args.workload == "rmat-24" else
+                              "the N = 1 line's value (same matrix, one GPU)" if args.workload == "audikw_1-like" else
+                              f"bench.py --workload {args.workload} (N = 1)"),
             "alg_GBps": round((12 * nnz + 4 * (n + 1) + 16 * n) / (elapsed / args.steps) / 1e9, 1),
             "roofline": None, "cpu_baseline": None, "parity": {"rows_over_1e-12": bad, "worst_rel": worst},
         }

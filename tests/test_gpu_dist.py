@@ -65,6 +65,8 @@ def test_strong_allgather_three_ranks(gpu):
     assert out["n_gpus"] == 3 and out["scaling"] == "strong"
     assert out["parity"]["rows_over_1e-12"] == 0
     assert "all_gather_into_tensor" in out["config"]["exchange"]
+    # the row blocks come from a graph partition: a GPU's rows reference only a fraction of the others' columns
+    assert out["config"]["ghost_columns_per_gpu_max"] < out["config"]["rows"] // 6
 
 
 def test_world_size_mismatch_is_refused(gpu):
