@@ -106,7 +106,12 @@ def test_linearity_and_phases(E, O, gpu):
     dx.upload(c.xp)
     plan.spmv(dx.ptr, dy.ptr, phase=1)
     plan.spmv(dx.ptr, dy.ptr, phase=2)
-    assert np.array_equal(dy.download(), ya)
+    if plan.stats["er_inline"] == 0:
+        assert np.array_equal(dy.download(), ya)
+    else:
+        # a tiny residual rides inside the ELL launch of the one-call form (summed with the ELL entries
+        # before y is rounded): the two-phase result may differ in the last bits of those rows
+        assert c.check(dy.download())[0] == 0
 
 
 PANEL_CASES = [
