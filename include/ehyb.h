@@ -318,6 +318,9 @@ int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int
  * One launch (ehyb_ell_kernel) when the residual is empty or tiny enough to ride inside
  * it (stats.er_inline > 0), else two: ehyb_ell_kernel then ehyb_er_kernel.
  * Replaces matrixVectorEHYB / matrixVectorEHYB_small (kernel.cu:490-552).
+ * A plan multiplies ONE vector at a time: with the residual in panel form (stats.er_partials > 0) the
+ * partial sums of a multiply live in a buffer of the plan, so two multiplies of the same plan must not
+ * overlap on different streams (the reference is not re-entrant either: global device counters).
  */
 int ehyb_spmv(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream);
 
