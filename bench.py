@@ -590,6 +590,18 @@ def main():
                 "format_bytes_per_spmv": st["bytes_format"],
                 "whole_spmv_real_frac": round(st["bytes_format"] / ((ell_ms + er_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
                 "whole_spmv_alg_GBps": round(st["bytes_alg"] / ((ell_ms + er_ms) * 1e-3) / 1e9, 1)}
+    # the second ceiling SURVEY 8d asks for: a streaming read of 4 GiB measured on this box in this run
+    try:
+        import ctypes as C
+
+        from ehyb_spmv_gpu_amd import _lib
+
+        bw = C.c_double(0)
+        if _lib.load().ehyb_measure_read_bw(C.c_size_t(1 << 32), 5, C.byref(bw)) == 0 and bw.value > 0:
+            roofline["measured_read_ceiling_GBps"] = round(bw.value, 1)
+            roofline["frac_of_measured_ceiling"] = round(achieved / bw.value, 4)
+    except Exception:  # the probe is a convenience: never let it cost the bench line
+        pass
     if st["sym_pairs"] > 0:
         roofline["note"] = ("symmetric pair storage: %d of the %d entries are in-partition pairs a_ij == a_ji stored once "
                             "(one value read, two FMAs, the mirror product added in LDS): frac counts the bytes really "
