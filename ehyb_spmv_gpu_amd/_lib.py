@@ -129,6 +129,11 @@ SIGNATURES = {
     "ehyb_measure_read_bw": (C.c_int, [C.c_size_t, C.c_int, _dp]),
     "ehyb_cg": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp, _ip, _dp]),
     "ehyb_pcg": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp, _ip, _dp]),
+    "ehyb_cg_layout": (C.c_int, [_ip, _ip, _ip, _ip, _ip, _ip]),
+    "ehyb_cg_init_step": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),
+    "ehyb_cg_dot_step": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp]),
+    "ehyb_cg_update_step": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, _vp, _vp, C.c_int, _vp]),
+    "ehyb_cg_direction_step": (C.c_int, [C.c_int, _vp, _vp, _vp, _vp, C.c_int, _vp]),
     "ehyb_mm_read": (C.c_int, [C.c_char_p, _cfgp, _mp, _ip]),
     "ehyb_mm_write": (C.c_int, [C.c_char_p, _mp, C.c_int]),
     "ehyb_matrix_from_csr": (C.c_int, [C.c_int, _i64p, _ip, _dp, _cfgp, _mp]),

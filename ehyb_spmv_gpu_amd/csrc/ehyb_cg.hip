@@ -48,7 +48,9 @@ constexpr int kThreads = EHYB_CG_THREADS;
 constexpr int kMaxGrid = 1024;  // partial sums per dot product
 
 // partial arrays, kMaxGrid doubles each
-enum { A_BB = 0, A_PQ = 1, A_RR = 2, A_RZ0 = 3, A_RZ1 = 4, A_COUNT = 5 };
+// (r.r sits between the two r.z slots, so that the pair an iteration writes -- its new r.z and r.r -- is one
+// contiguous range for a multi-GPU caller's all-reduce: slot of r.z number c = A_RZ0 + 2 c)
+enum { A_BB = 0, A_PQ = 1, A_RZ0 = 2, A_RR = 3, A_RZ1 = 4, A_COUNT = 5 };
 
 // sum over the workgroup, returned to every thread; fixed order
 __device__ __forceinline__ double block_sum(double v)
@@ -113,7 +115,7 @@ __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, const double
                                                              double* __restrict__ x, double* __restrict__ r,
                                                              double* __restrict__ s, int cur)
 {
-    const double alpha = sum_partials(s + (A_RZ0 + cur) * kMaxGrid) / sum_partials(s + A_PQ * kMaxGrid);
+    const double alpha = sum_partials(s + (A_RZ0 + 2 * cur) * kMaxGrid) / sum_partials(s + A_PQ * kMaxGrid);
     double rz = 0.0, rr = 0.0;
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
         x[i] = fma(alpha, p[i], x[i]);
@@ -122,7 +124,7 @@ __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, const double
         rz = fma(ri, dinv ? ri * dinv[i] : ri, rz);
         rr = fma(ri, ri, rr);
     }
-    put_partial(rz, s + (A_RZ0 + (cur ^ 1)) * kMaxGrid);
+    put_partial(rz, s + (A_RZ0 + 2 * (cur ^ 1)) * kMaxGrid);
     put_partial(rr, s + A_RR * kMaxGrid);
 }
 
@@ -131,7 +133,7 @@ __global__ __launch_bounds__(kThreads) void cg_direction_kernel(int n, const dou
                                                                 const double* __restrict__ dinv, double* __restrict__ p,
                                                                 const double* __restrict__ s, int cur)
 {
-    const double beta = sum_partials(s + (A_RZ0 + (cur ^ 1)) * kMaxGrid) / sum_partials(s + (A_RZ0 + cur) * kMaxGrid);
+    const double beta = sum_partials(s + (A_RZ0 + 2 * (cur ^ 1)) * kMaxGrid) / sum_partials(s + (A_RZ0 + 2 * cur) * kMaxGrid);
     for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
         p[i] = fma(beta, p[i], dinv ? r[i] * dinv[i] : r[i]);
 }
@@ -241,7 +243,7 @@ extern "C" int ehyb_pcg(ehyb_plan* P, const double* dinv, const double* b, doubl
         HIP_TRY(hipMemcpyAsync(h.data(), s, h.size() * sizeof(double), hipMemcpyDeviceToHost, st));
         HIP_TRY(hipStreamSynchronize(st));
         rs = read_scalar(A_RR);
-        const double rz = read_scalar(A_RZ0 + (burst & 1));
+        const double rz = read_scalar(A_RZ0 + 2 * (burst & 1));
         if (!(rs == rs) || !(rz == rz)) {
             rs = NAN;
             break;  // NaN: breakdown (matrix or preconditioner not positive definite)
@@ -250,5 +252,68 @@ extern "C" int ehyb_pcg(ehyb_plan* P, const double* dinv, const double* b, doubl
     if (iters_done) *iters_done = it;
     if (rel_residual) *rel_residual = std::sqrt(rs / bb);
     if (!(rs == rs)) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_cg: breakdown (is the matrix symmetric positive definite?)");
+    return EHYB_OK;
+}
+
+// ------------------------------------------------------------------ building blocks for a multi-GPU caller
+// The same four vector kernels for a caller that owns the loop (ehyb_spmv_gpu_amd/dist.py HaloCG: one
+// process per GPU, the multiply through the halo exchange): every rank runs them on its rows with the
+// SAME grid, and an all_reduce (sum) of a slot of the partial array turns every rank's partials into
+// the element-wise global ones -- the kernel that needs the scalar adds them up as before.
+//   s: `slots` slots of `slot_doubles` doubles (ehyb_cg_layout); r.z number c (0/1) lives in slot rz0 + 2 c, r.r
+//   between the two; every launch uses slot_doubles / 2 workgroups.
+extern "C" int ehyb_cg_layout(int* slots, int* slot_doubles, int* slot_bb, int* slot_pq, int* slot_rr, int* slot_rz0)
+{
+    if (slots) *slots = A_COUNT;
+    if (slot_doubles) *slot_doubles = kMaxGrid;
+    if (slot_bb) *slot_bb = A_BB;
+    if (slot_pq) *slot_pq = A_PQ;
+    if (slot_rr) *slot_rr = A_RR;
+    if (slot_rz0) *slot_rz0 = A_RZ0;
+    return EHYB_OK;
+}
+
+static int check_vec(int n, const void* a, const void* b, const void* c, const char* who)
+{
+    if (n < 0 || !a || !b || !c) EHYB_FAIL(EHYB_ERR_ARG, "%s: bad arguments", who);
+    return EHYB_OK;
+}
+
+// r = b - q, p = z = M^-1 r; partials of r.z (slot rz0), r.r, b.b
+extern "C" int ehyb_cg_init_step(int n, const double* b, const double* q, const double* dinv, double* r, double* p, double* s,
+                                 void* stream)
+{
+    int rc = check_vec(n, b, q, s, "ehyb_cg_init_step");
+    if (rc != EHYB_OK || !r || !p) return rc != EHYB_OK ? rc : EHYB_ERR_ARG;
+    hipLaunchKernelGGL(cg_init_kernel, dim3(kMaxGrid / 2), dim3(kThreads), 0, (hipStream_t)stream, n, b, q, dinv, r, p, s);
+    HIP_TRY(hipGetLastError());
+    return EHYB_OK;
+}
+// partials of p.q (slot pq)
+extern "C" int ehyb_cg_dot_step(int n, const double* p, const double* q, double* s, void* stream)
+{
+    int rc = check_vec(n, p, q, s, "ehyb_cg_dot_step");
+    if (rc != EHYB_OK) return rc;
+    hipLaunchKernelGGL(cg_dot_kernel, dim3(kMaxGrid / 2), dim3(kThreads), 0, (hipStream_t)stream, n, p, q, s);
+    HIP_TRY(hipGetLastError());
+    return EHYB_OK;
+}
+// alpha = rz[cur] / pq; x += alpha p; r -= alpha q; partials of the new r.z (slot rz0 + (cur ^ 1)) and r.r
+extern "C" int ehyb_cg_update_step(int n, const double* p, const double* q, const double* dinv, double* x, double* r, double* s,
+                                   int cur, void* stream)
+{
+    int rc = check_vec(n, p, q, s, "ehyb_cg_update_step");
+    if (rc != EHYB_OK || !x || !r) return rc != EHYB_OK ? rc : EHYB_ERR_ARG;
+    hipLaunchKernelGGL(cg_update_kernel, dim3(kMaxGrid / 2), dim3(kThreads), 0, (hipStream_t)stream, n, p, q, dinv, x, r, s, cur & 1);
+    HIP_TRY(hipGetLastError());
+    return EHYB_OK;
+}
+// beta = rz[cur ^ 1] / rz[cur]; p = z + beta p
+extern "C" int ehyb_cg_direction_step(int n, const double* r, const double* dinv, double* p, const double* s, int cur, void* stream)
+{
+    int rc = check_vec(n, r, p, s, "ehyb_cg_direction_step");
+    if (rc != EHYB_OK) return rc;
+    hipLaunchKernelGGL(cg_direction_kernel, dim3(kMaxGrid / 2), dim3(kThreads), 0, (hipStream_t)stream, n, r, dinv, p, s, cur & 1);
+    HIP_TRY(hipGetLastError());
     return EHYB_OK;
 }

@@ -404,10 +404,13 @@ class HaloCG:
     """(Jacobi-)preconditioned conjugate gradients over the ranks of a HaloSpmv: the iterating caller
     of the multi-GPU path ("iterating x <- y requires every GPU to obtain the other
     segments" -- here the direction vector p is what travels, through the halo exchange inside
-    HaloSpmv.step).  Every rank holds its rows of x, r, p, q in plan order on its GPU; the three
-    dot products of an iteration are two all_reduce calls on device scalars ([p.q], then
-    [r.z, r.r]); the host reads the residual norm every `check_every` iterations only.
-    Same recurrences as the single-GPU ehyb_pcg (csrc/ehyb_cg.hip)."""
+    HaloSpmv.step).  Every rank holds its rows of x, r, p, q in plan order on its GPU.  The vector work
+    is done by the fused kernels of the single-GPU solver (csrc/ehyb_cg.hip, ehyb_cg_*_step: three
+    launches per iteration besides the multiply); the dot products never leave the devices: a kernel
+    leaves one partial sum per workgroup, an all_reduce of that slot (4 KiB per dot product) makes every
+    rank's partials the element-wise global ones, and the kernel that needs the scalar adds them up.
+    Two all_reduce calls per iteration ([p.q], then [r.z, r.r]); the host reads the residual norm every
+    `check_every` iterations only.  Same recurrences as ehyb_pcg."""
 
     def __init__(self, halo_spmv, inv_diag_local=None):
         import torch
@@ -417,50 +420,72 @@ class HaloCG:
         self.sh = halo_spmv
         self.L = halo_spmv.L
         self.dev = halo_spmv.x.device
+        self.lib = H._lib.load()
+        slots, sd, bb, pq, rr, rz0 = (C.c_int() for _ in range(6))
+        H._check(self.lib.ehyb_cg_layout(*(C.byref(v) for v in (slots, sd, bb, pq, rr, rz0))), "ehyb_cg_layout")
+        self.slot_doubles, self.grid = sd.value, sd.value // 2
+        self.A_BB, self.A_PQ, self.A_RR, self.A_RZ0 = bb.value, pq.value, rr.value, rz0.value
+        self.s = torch.zeros(slots.value * sd.value, dtype=torch.float64, device=self.dev)
         self.dinv = None
         if inv_diag_local is not None:
             self.dinv = torch.from_numpy(self.L.x_to_plan(np.asarray(inv_diag_local, dtype=np.float64))).to(self.dev)
+        # gloo (functional mode on one GPU) cannot reduce device tensors: staged through the host there
+        self.stage = self.L.world > 1 and dist.get_backend(self.L.group) != "nccl"
 
-    def _sum(self, t):
-        if self.L.world > 1:
-            self.dist.all_reduce(t, group=self.L.group)
-        return t
+    def _slot(self, first, count=1):
+        """`count` neighbouring slots of the partial array (the part of the last one that is written)."""
+        sd = self.slot_doubles
+        return self.s[first * sd:(first + count - 1) * sd + self.grid]
+
+    def _allreduce(self, view):
+        if self.L.world == 1:
+            return
+        if self.stage:
+            h = view.cpu()
+            self.dist.all_reduce(h, group=self.L.group)
+            view.copy_(h)
+        else:
+            self.dist.all_reduce(view, group=self.L.group)
+
+    def _scalar(self, slot):
+        return float(self.s[slot * self.slot_doubles:slot * self.slot_doubles + self.grid].sum().item())
 
     def solve(self, b_local, max_iter=1000, rtol=1e-10, check_every=10, x0_local=None):
         """b_local, x0_local: this rank's segments in global label order (host arrays).
         -> (x_local, iterations, relative residual)"""
-        torch, L, sh = self.torch, self.L, self.sh
+        torch, L, sh, lib = self.torch, self.L, self.sh, self.lib
         n = L.n_loc
         b = torch.from_numpy(L.x_to_plan(np.asarray(b_local, dtype=np.float64))).to(self.dev)
         x = torch.zeros(n, dtype=torch.float64, device=self.dev)
         if x0_local is not None:
             x.copy_(torch.from_numpy(L.x_to_plan(np.asarray(x0_local, dtype=np.float64))))
-        apply_m = (lambda r: r * self.dinv) if self.dinv is not None else (lambda r: r)
-        sh.x[:n].copy_(x)
-        sh.step()                                   # q = A x0
-        r = b - sh.y
-        z = apply_m(r)
-        p = z.clone()
-        s = self._sum(torch.stack([torch.dot(r, z), torch.dot(r, r), torch.dot(b, b)]))
-        rz = s[0].clone()
-        bb = float(s[2].item()) or 1.0
-        rr = float(s[1].item())
-        it = 0
+        r = torch.empty(n, dtype=torch.float64, device=self.dev)
+        p = sh.x[:n]                     # the direction vector lives where the multiply reads it
+        q = sh.y
+        dinv = self.dinv.data_ptr() if self.dinv is not None else None
+        st = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
+        s_ptr = self.s.data_ptr()
+        p.copy_(x)
+        sh.step()                                            # q = A x0
+        H._check(lib.ehyb_cg_init_step(n, b.data_ptr(), q.data_ptr(), dinv, r.data_ptr(), p.data_ptr(), s_ptr, st()), "ehyb_cg_init_step")
+        self._allreduce(self._slot(self.A_BB))
+        self._allreduce(self._slot(self.A_RZ0, 2))           # r.z number 0 and r.r are neighbours
+        bb = self._scalar(self.A_BB) or 1.0
+        rr = self._scalar(self.A_RR)
+        it, cur = 0, 0
         while it < max_iter and (rr / bb) ** 0.5 > rtol:
             for _ in range(min(check_every, max_iter - it)):
-                sh.x[:n].copy_(p)
-                sh.step()                           # q = A p: halo exchange of p + two-phase multiply
-                q = sh.y
-                pq = self._sum(torch.dot(p, q).reshape(1))
-                alpha = rz / pq[0]
-                x.add_(p * alpha)
-                r.sub_(q * alpha)
-                z = apply_m(r)
-                s = self._sum(torch.stack([torch.dot(r, z), torch.dot(r, r)]))
-                p = z + p * (s[0] / rz)
-                rz = s[0].clone()
+                sh.step()                                    # q = A p: halo exchange of p + two-phase multiply
+                H._check(lib.ehyb_cg_dot_step(n, p.data_ptr(), q.data_ptr(), s_ptr, st()), "ehyb_cg_dot_step")
+                self._allreduce(self._slot(self.A_PQ))
+                H._check(lib.ehyb_cg_update_step(n, p.data_ptr(), q.data_ptr(), dinv, x.data_ptr(), r.data_ptr(), s_ptr, cur, st()),
+                         "ehyb_cg_update_step")
+                # the new r.z (number cur ^ 1, slot rz0 + 2 (cur ^ 1)) and r.r (slot rz0 + 1): neighbours either way
+                self._allreduce(self._slot(self.A_RZ0 + (cur ^ 1), 2))
+                H._check(lib.ehyb_cg_direction_step(n, r.data_ptr(), dinv, p.data_ptr(), s_ptr, cur, st()), "ehyb_cg_direction_step")
+                cur ^= 1
                 it += 1
-            rr = float(s[1].item())                 # the only host read in the loop
+            rr = self._scalar(self.A_RR)                     # the only host read in the loop
             if rr != rr:
                 raise RuntimeError("HaloCG: breakdown (is the matrix symmetric positive definite?)")
         return L.y_from_plan(x.cpu().numpy()), it, (rr / bb) ** 0.5

@@ -389,6 +389,29 @@ int ehyb_cg(ehyb_plan* plan, const double* b_dev, double* x_dev, int max_iter, d
 int ehyb_pcg(ehyb_plan* plan, const double* inv_diag_dev, const double* b_dev, double* x_dev, int max_iter,
              double rtol, int check_every, void* stream, int* iters_done, double* rel_residual);
 
+/*
+ * The vector kernels of ehyb_pcg as building blocks for a caller that owns the loop -- the multi-GPU CG of
+ * ehyb_spmv_gpu_amd/dist.py (HaloCG), where q = A p goes through the halo exchange.  s is the partial-sum
+ * array: `slots` slots of `slot_doubles` doubles (ehyb_cg_layout).  Every rank launches the same grid, so an
+ * all-reduce (sum) of a slot makes every rank's partials the element-wise global ones and the kernel that
+ * needs the scalar adds them up as in the single-GPU solve.  cur (0/1) says which of the two r.z slots
+ * holds the current r.z (number c lives in slot rz0 + 2 c, r.r in the slot between them, so what an
+ * iteration writes is one contiguous range): it alternates from iteration to iteration.  All
+ * asynchronous on `stream`.
+ */
+int ehyb_cg_layout(int* slots, int* slot_doubles, int* slot_bb, int* slot_pq, int* slot_rr, int* slot_rz0);
+/* r = b - q, p = M^-1 r; partials of r.z (slot rz0), r.r, b.b */
+int ehyb_cg_init_step(int n, const double* b_dev, const double* q_dev, const double* inv_diag_dev, double* r_dev, double* p_dev,
+                      double* s_dev, void* stream);
+/* partials of p.q */
+int ehyb_cg_dot_step(int n, const double* p_dev, const double* q_dev, double* s_dev, void* stream);
+/* alpha = r.z[cur] / p.q;  x += alpha p;  r -= alpha q;  partials of the new r.z (number cur ^ 1) and r.r */
+int ehyb_cg_update_step(int n, const double* p_dev, const double* q_dev, const double* inv_diag_dev, double* x_dev, double* r_dev,
+                        double* s_dev, int cur, void* stream);
+/* beta = r.z[cur ^ 1] / r.z[cur];  p = M^-1 r + beta p   (the reference's kernelMyxpy, kernel.cu:288-296) */
+int ehyb_cg_direction_step(int n, const double* r_dev, const double* inv_diag_dev, double* p_dev, const double* s_dev, int cur,
+                           void* stream);
+
 /* -------------------------------------------- harness pieces (solver_test.c) */
 
 /*
