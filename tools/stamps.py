@@ -61,7 +61,8 @@ def main():
     t0 = s[:, 0].min()
     start, staged, end, xcc = (s[:, 0] - t0) / 100.0, (s[:, 1] - t0) / 100.0, (s[:, 2] - t0) / 100.0, s[:, 3]
     items = plan.array("items").reshape(-1, 8)
-    if os.environ.get("EHYB_XCD_MAP", "1") != "0":  # workgroup b took item xcd_item(b) (ehyb_hip.hip)
+    # plain storage: workgroup b took item xcd_item(b) (ehyb_hip.hip); symmetric pairs: item b (heaviest first)
+    if os.environ.get("EHYB_XCD_MAP", "1") != "0" and st["sym_pairs"] == 0:
         b = np.arange(n_items)
         k, j, chunk, rem = b & 7, b >> 3, n_items >> 3, n_items & 7
         items = items[k * chunk + np.minimum(k, rem) + j]
