@@ -68,7 +68,7 @@ WORKLOADS = {
 REFERENCE_SIZING = {"audikw_1-like": (164, 6144, 0)}
 
 SYMMETRIC_GENERATORS = ("fem3d", "fem3d_graded", "kkt3d", "stencil2d")  # A == A^T by construction (include/ehyb.h)
-SYM_MIN_ROWS = 32768  # EHYB_SYM_MIN_ROWS (include/ehyb.h): below it plain storage is faster
+SYM_MIN_ROWS = 45056  # EHYB_SYM_MIN_ROWS (include/ehyb.h): below it the direct shape with every entry stored is faster
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
 

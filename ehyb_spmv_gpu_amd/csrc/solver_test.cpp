@@ -61,7 +61,7 @@ static std::vector<long long> split_numbers(const char* s)
 static void usage()
 {
     printf("usage: solver_test -i <iters> (-m <name> | -g <spec>) [-w 1|2] [-l lds_doubles] [-T threads] [-c plan.cache] [-S 0|1] [-v]\n"
-           "  -S 0|1    symmetric pair storage off / on (default: on for symmetric matrices of >= 32768 rows --\n"
+           "  -S 0|1    symmetric pair storage off / on (default: on for symmetric matrices of >= 45056 rows --\n"
            "            each in-partition pair a_ij == a_ji is stored once)\n"
            "  -c file   plan cache: reuse the permutation + layout saved by an earlier run on the same matrix,\n"
            "            or write it (the reference repeats mt-metis + COO2EHYB on every run)\n"

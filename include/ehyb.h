@@ -63,13 +63,18 @@ enum { EHYB_PART_AUTO = 0, EHYB_PART_CONTIGUOUS = 1, EHYB_PART_MULTILEVEL = 2, E
 #define EHYB_LDS_MAX_DOUBLES 20480   /* 160 KiB of LDS per workgroup on gfx950 */
 #define EHYB_SLAB_ROWS       64      /* one row per lane of a wave64           */
 
-/* Symmetric pair storage runs one workgroup per partition; below about 30,000 rows there are too
- * few partitions to fill the 256 CUs and plain storage is faster (tools/sym_crossover.py, fem3d with
- * 3 unknowns per node: 21,000 rows 9.7 vs 7.3 us, 42,000 rows 9.9 vs 11.0 us, 84,000 rows 13.6 vs 16.8 us).
- * Callers that pick the storage from the matrix's symmetry (solver_test, bench.py) use this line. */
-#define EHYB_SYM_MIN_ROWS 32768
-/* Plans of at most this many rows run in the direct (window-less, one small launch) shape: cfg.direct. */
-#define EHYB_DIRECT_MAX_ROWS 24576
+/* Which shape for which size (tools/direct_crossover.py, fem3d with 3 unknowns per node, ~78 entries per
+ * row, microseconds per SpMV: direct / window with every entry stored / symmetric pair storage):
+ *    24,576 rows   5.6 /  8.8 /  9.4        65,535 rows  14.8 / 16.5 / 13.1
+ *    32,766 rows   7.2 /  9.3 /  9.7        81,918 rows  17.4 / 17.4 / 13.8
+ *    40,959 rows   9.5 / 10.6 /  9.8        98,304 rows  20.6 / 19.7 / 15.0
+ *    49,152 rows  11.6 / 14.3 / 11.1       131,070 rows  25.9 / 21.9 / 15.7
+ * Symmetric pair storage (one workgroup per partition) needs enough partitions to fill the 256 CUs: it
+ * pays from about 45,000 rows; callers that pick the storage from the matrix's symmetry (matrixReorder,
+ * spmvGPuEHYB, solver_test, bench.py) use EHYB_SYM_MIN_ROWS.  Below, and for unsymmetric matrices up to
+ * EHYB_DIRECT_MAX_ROWS, the direct shape (cfg.direct: no window, one small launch) is the fastest. */
+#define EHYB_SYM_MIN_ROWS 45056
+#define EHYB_DIRECT_MAX_ROWS 81920
 
 /* OpenMP threads the host builder uses when cfg.host_threads is 0: what OpenMP would take, capped by
  * the CPUs the process may really use (affinity mask, cgroup CPU quota). */

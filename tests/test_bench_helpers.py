@@ -44,7 +44,7 @@ def test_workload_table(E):
     assert not B.symmetric_storage_pays(*B.WORKLOADS["bcsstk17-like"][:2])            # below EHYB_SYM_MIN_ROWS
     assert not B.symmetric_storage_pays(*B.WORKLOADS["rmat-24"][:2])
     assert B.partitioner_for(E, "rmat") == E.EHYB_PART_CONTIGUOUS and B.partitioner_for(E, "fem3d") == E.EHYB_PART_AUTO
-    assert B.SYM_MIN_ROWS == 32768
+    assert B.SYM_MIN_ROWS == 45056
     # the generators behind the two audikw_1 stand-ins hit audikw_1's size (943,695 rows, 77,651,847 entries)
     for wl in ("audikw_1-like", "audikw_1-graded"):
         assert B.WORKLOADS[wl][1][0] == 943695

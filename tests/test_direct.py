@@ -19,7 +19,7 @@ CASES = [
 def test_direct_layout_walks_to_the_reference_product(E, O, name, kind, args):
     cfg = E.make_config()                                  # defaults: automatic for <= EHYB_DIRECT_MAX_ROWS rows
     c = Case(E, O, kind, args, cfg)
-    assert c.n <= 24576
+    assert c.n <= 81920
     plan = E.Plan(c.m, cfg, upload=False)
     st = plan.stats
     assert st["nnz_ell"] == 0 and st["nnz_er"] == c.nnz and st["size_block_ell"] == 0 and st["er_partials"] == 0
@@ -40,5 +40,5 @@ def test_direct_is_only_automatic_for_default_windows(E, O):
         assert (st["nnz_ell"] == 0) == want, kw
     # larger matrices keep the window
     cfg = E.make_config()
-    c = Case(E, O, "fem3d", (30000, 3, 22, 22, 13500, 1, 1), cfg)
+    c = Case(E, O, "fem3d", (90000, 3, 32, 32, 13500, 1, 1), cfg)
     assert E.Plan(c.m, cfg, upload=False).stats["nnz_ell"] > 0

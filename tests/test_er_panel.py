@@ -11,7 +11,7 @@ CASES = [
     ("rmat_s14", "rmat", (14, 1 << 17, 1), dict(lds_doubles=512, er_panel_cols=512, er_block_rows=300)),
     ("rmat_s12_dense", "rmat", (12, 1 << 18, 5), dict(lds_doubles=256, er_panel_cols=256, er_block_rows=64)),
     ("kkt_contiguous", "kkt3d", (12,), dict(lds_doubles=512, partitioner=1)),
-    ("rmat_s16_defaults", "rmat", (16, 1 << 19, 3), dict()),
+    ("rmat_s16_defaults", "rmat", (16, 1 << 19, 3), dict(direct=2)),
     ("fem_reference_window", "fem3d", (30000, 3, 22, 22, 13500, 1, 1), dict(window_mode=1, lds_doubles=1024, er_panel_cols=1024)),
     ("rmat_sym_storage", "rmat", (14, 1 << 17, 4), dict(lds_doubles=512, sym_pairs=1, er_panel_cols=256)),
 ]
@@ -45,7 +45,7 @@ def test_mode_selection(E, O):
     assert E.Plan(c.m, cfg1, upload=False).stats["er_partials"] == 0
     assert E.Plan(c.m, E.make_config(er_mode=0, lds_doubles=512), upload=False).stats["er_partials"] == 0   # 64 k entries: CSR
     assert E.Plan(c.m, E.make_config(er_mode=2, lds_doubles=512), upload=False).stats["er_partials"] > 0
-    cfg = E.make_config(er_mode=2)
+    cfg = E.make_config(er_mode=2, direct=2)
     f = Case(E, O, "fem3d", (30000, 3, 22, 22, 13500, 1, 1), cfg)
     st = E.Plan(f.m, cfg, upload=False).stats
     assert st["er_partials"] == 0 and (st["nnz_er"] == 0 or st["er_inline"] > 0)
