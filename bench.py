@@ -227,10 +227,11 @@ def run_weak(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
 
 
 def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
-    """N > 1, strong scaling (BASELINE config 5): ONE matrix sharded by rows.  Every rank
-    generates the matrix (deterministic generators; a real deployment reads its rows from a file), cuts
-    the rows into one block per GPU -- a k-way graph partition balanced on entries where the matrix has
-    locality, contiguous nnz-balanced blocks for R-MAT --, keeps rows [r0, r1) of its block, builds its
+    """N > 1, strong scaling (BASELINE config 5): ONE matrix sharded by rows, one block per GPU.
+    R-MAT: contiguous blocks with equal numbers of edge samples, every rank generating its own block only
+    (ehyb_gen_rmat_block).  Matrices with locality: every rank generates the matrix (deterministic
+    generators; a real deployment reads its rows from a file) and takes its block of a k-way graph
+    partition balanced on entries.  A rank keeps rows [r0, r1) of its block, builds its
     plan from them alone (window-sized partitions inside: the second level) and exchanges x
     every step: `--exchange allgather` = the x segments, padded to equal length, through one RCCL
     all_gather_into_tensor (what north_star names); `--exchange halo` = only the entries the rank's
@@ -242,14 +243,21 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
 
     gen, gargs, desc = WORKLOADS[args.workload]
     t0 = time.time()
-    m = E.Matrix.generate(gen, *gargs, cfg=cfg)
-    n, nnz = m.n, m.nnz
-    log(f"[bench] every rank generated {args.workload}: n={n} nnz={nnz} in {time.time() - t0:.1f}s")
-    x = E.x_glibc(n)
     if gen == "rmat":
-        # no locality to find: contiguous row blocks of equal entry counts in the matrix's own numbering
-        cuts = D.balanced_row_cuts(m.row_idx.astype(np.int64), world)
+        # no locality to find: contiguous row blocks with equal numbers of edge samples in the matrix's own
+        # numbering; every rank draws all samples twice (histogram, then its own block) and keeps only its rows
+        m = E.Matrix.generate("rmat_block", *gargs, rank, world, cfg=cfg)
+        n, cuts = m.n, m.block_cuts
+        t = torch.tensor([float(m.nnz)], dtype=torch.float64, device=dev)
+        dist.all_reduce(t)
+        nnz = int(t.item())
+        log(f"[bench] every rank generated its row block of {args.workload}: n={n} nnz={nnz} (rank 0: {m.nnz}) in {time.time() - t0:.1f}s")
+        x = E.x_glibc(n)
     else:
+        m = E.Matrix.generate(gen, *gargs, cfg=cfg)
+        n, nnz = m.n, m.nnz
+        log(f"[bench] every rank generated {args.workload}: n={n} nnz={nnz} in {time.time() - t0:.1f}s")
+        x = E.x_glibc(n)
         # top level of the two-level partition: a k-way graph partition into one block of rows
         # per GPU, balanced on entries, so that a GPU's rows reference few columns of the others; the
         # matrix and x are taken into that numbering (every rank computes the same permutation)

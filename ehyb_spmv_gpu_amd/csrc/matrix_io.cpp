@@ -481,6 +481,117 @@ static int gen_fem3d_impl(int n, int dof, int nx, int ny, int extra_ppm, int scr
     return EHYB_OK;
 }
 
+// One R-MAT edge sample: every sample has its own generator state, so the result does not depend on the
+// thread count (nor on which process draws it).  (a,b,c,d) = (0.57,0.19,0.19,0.05).
+static inline void rmat_sample(int scale, uint64_t seed, int64_t e, int* pi, int* pj)
+{
+    uint64_t s = mix64(seed * 0x9E3779B97F4A7C15ull + (uint64_t)e);
+    int i = 0, j = 0;
+    for (int l = 0; l < scale; ++l) {
+        uint32_t r = (uint32_t)(splitmix64(s) >> 40) % 100;  // percent
+        int bi, bj;
+        if (r < 57) bi = 0, bj = 0;
+        else if (r < 76) bi = 0, bj = 1;
+        else if (r < 95) bi = 1, bj = 0;
+        else bi = 1, bj = 1;
+        i = (i << 1) | bi;
+        j = (j << 1) | bj;
+    }
+    *pi = i;
+    *pj = j;
+}
+
+// Rows of block `block` of the SAME matrix ehyb_gen_rmat(scale, edges, seed) makes, for a process that
+// owns one of n_blocks row blocks (strong scaling, one process per GPU): the blocks are contiguous row
+// ranges holding about equally many edge samples (cuts[0..n_blocks], the same on every process: they
+// come from a histogram pass over all samples), and only the samples of the own block are kept, sorted
+// and merged.  Dimension 2^scale, rows outside the block empty.
+int ehyb_gen_rmat_block(int scale, int64_t edges, uint64_t seed, int block, int n_blocks, int* cuts, const ehyb_config* cfg,
+                        matrixCOO* out)
+{
+    clear_error();
+    OmpScope omp_scope(cfg);
+    if (!out || !cuts || scale < 1 || scale > 30 || edges < 1 || n_blocks < 1 || block < 0 || block >= n_blocks)
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_rmat_block: bad arguments");
+    const int n = 1 << scale;
+    if (n_blocks > n) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_rmat_block: more blocks than rows");
+    // pass 1: samples per row (every process, nothing stored)
+    std::vector<int64_t> hist((size_t)n + 1, 0);
+    {
+        const int nt = omp_get_max_threads();
+        std::vector<std::vector<int32_t>> part((size_t)nt);
+#pragma omp parallel
+        {
+            std::vector<int32_t>& h = part[omp_get_thread_num()];
+            h.assign((size_t)n, 0);
+#pragma omp for schedule(static, 65536)
+            for (int64_t e = 0; e < edges; ++e) {
+                int i, j;
+                rmat_sample(scale, seed, e, &i, &j);
+                ++h[i];
+            }
+        }
+        for (const auto& h : part)
+            if (!h.empty())
+                for (int i = 0; i < n; ++i) hist[i + 1] += h[i];
+    }
+    for (int i = 0; i < n; ++i) hist[i + 1] += hist[i];
+    cuts[0] = 0;
+    for (int b = 1; b < n_blocks; ++b) {
+        const int64_t goal = hist[n] * b / n_blocks;
+        int c = (int)(std::lower_bound(hist.begin(), hist.end(), goal) - hist.begin());
+        c = std::min(std::max(c, cuts[b - 1] + 1), n - (n_blocks - b));
+        cuts[b] = c;
+    }
+    cuts[n_blocks] = n;
+    const int r0 = cuts[block], r1 = cuts[block + 1];
+    // pass 2: the own block's samples, grouped by row
+    const int64_t mine = hist[r1] - hist[r0];
+    std::vector<int> cols((size_t)mine);
+    {
+        std::vector<int64_t> fill(hist.begin() + r0, hist.begin() + r1);
+        for (auto& f : fill) f -= hist[r0];
+        // samples of one row come from different threads: a serial scatter keeps it simple and ordered
+        // (the sort below makes the order irrelevant anyway); the sampling itself is the parallel part
+        const int64_t chunk = 1 << 22;
+        std::vector<int> bi((size_t)chunk), bj((size_t)chunk);
+        for (int64_t e0 = 0; e0 < edges; e0 += chunk) {
+            const int64_t m2 = std::min(chunk, edges - e0);
+#pragma omp parallel for schedule(static, 65536)
+            for (int64_t q = 0; q < m2; ++q) rmat_sample(scale, seed, e0 + q, &bi[(size_t)q], &bj[(size_t)q]);
+            for (int64_t q = 0; q < m2; ++q)
+                if (bi[(size_t)q] >= r0 && bi[(size_t)q] < r1) cols[(size_t)fill[bi[(size_t)q] - r0]++] = bj[(size_t)q];
+        }
+    }
+    std::vector<int> ucnt((size_t)(r1 - r0));
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int i = r0; i < r1; ++i) {
+        auto b = cols.begin() + (hist[i] - hist[r0]), e = cols.begin() + (hist[i + 1] - hist[r0]);
+        std::sort(b, e);
+        ucnt[(size_t)(i - r0)] = (int)(std::unique(b, e) - b);
+    }
+    int64_t nnz = 0;
+    for (int c : ucnt) nnz += c;
+    int rc = alloc_matrix(n, nnz, out);
+    if (rc != EHYB_OK) return rc;
+    for (int i = r0; i < r1; ++i) out->numInRow[i] = ucnt[(size_t)(i - r0)];
+    rc = finish_matrix(out, cfg);
+    if (rc != EHYB_OK) return rc;
+#pragma omp parallel for schedule(dynamic, 4096)
+    for (int i = r0; i < r1; ++i) {
+        int64_t at = out->rowIdx[i];
+        const int64_t src = hist[i] - hist[r0];
+        for (int k = 0; k < ucnt[(size_t)(i - r0)]; ++k) {
+            const int j = cols[(size_t)(src + k)];
+            out->I[at + k] = i;
+            out->J[at + k] = j;
+            out->V[at + k] = hash_value_mixed((uint64_t)i, (uint64_t)j, seed);
+            if (i == j) out->diag[i] = out->V[at + k];
+        }
+    }
+    return EHYB_OK;
+}
+
 int ehyb_gen_rmat(int scale, int64_t edges, uint64_t seed, const ehyb_config* cfg, matrixCOO* out)
 {
     clear_error();
@@ -491,22 +602,7 @@ int ehyb_gen_rmat(int scale, int64_t edges, uint64_t seed, const ehyb_config* cf
     // (a,b,c,d) = (0.57,0.19,0.19,0.05); every edge has its own generator state, so the
     // result does not depend on the thread count
 #pragma omp parallel for schedule(static, 65536)
-    for (int64_t e = 0; e < edges; ++e) {
-        uint64_t s = mix64(seed * 0x9E3779B97F4A7C15ull + (uint64_t)e);
-        int i = 0, j = 0;
-        for (int l = 0; l < scale; ++l) {
-            uint32_t r = (uint32_t)(splitmix64(s) >> 40) % 100;  // percent
-            int bi, bj;
-            if (r < 57) bi = 0, bj = 0;
-            else if (r < 76) bi = 0, bj = 1;
-            else if (r < 95) bi = 1, bj = 0;
-            else bi = 1, bj = 1;
-            i = (i << 1) | bi;
-            j = (j << 1) | bj;
-        }
-        ei[e] = i;
-        ej[e] = j;
-    }
+    for (int64_t e = 0; e < edges; ++e) rmat_sample(scale, seed, e, &ei[e], &ej[e]);
     // group by row, sort + unique the columns of each row
     std::vector<int64_t> rp((size_t)n + 1, 0);
     for (int64_t e = 0; e < edges; ++e) rp[ei[e] + 1]++;

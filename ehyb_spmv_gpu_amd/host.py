@@ -135,6 +135,11 @@ class Matrix:
         elif kind == "rmat":
             scale, edges, seed = args
             rc = m.lib.ehyb_gen_rmat(scale, edges, seed, cp, C.byref(m.c))
+        elif kind == "rmat_block":
+            scale, edges, seed, block, n_blocks = args
+            cuts = (C.c_int * (n_blocks + 1))()
+            rc = m.lib.ehyb_gen_rmat_block(scale, edges, seed, block, n_blocks, cuts, cp, C.byref(m.c))
+            m.block_cuts = [int(c) for c in cuts]
         elif kind == "stencil2d":
             nx, ny, points, extra, seed = args
             rc = m.lib.ehyb_gen_stencil2d(nx, ny, points, extra, seed, cp, C.byref(m.c))

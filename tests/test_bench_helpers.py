@@ -81,3 +81,27 @@ def test_world_size_must_match_gpus(monkeypatch):
     with pytest.raises(SystemExit) as e:
         B.main()
     assert "WORLD_SIZE=2" in str(e.value)
+
+
+def test_rmat_row_blocks_are_the_rows_of_the_full_matrix(E):
+    """ehyb_gen_rmat_block (strong scaling: every process generates its own row block only): the blocks of
+    all processes are exactly the rows of ehyb_gen_rmat's matrix, the cuts are the same on every process
+    and balance the edge samples."""
+    import numpy as np
+
+    full = E.Matrix.generate("rmat", 15, 1 << 18, 5)
+    A = full.to_scipy()
+    for world in (1, 3, 8):
+        total, cuts0 = 0, None
+        for b in range(world):
+            m = E.Matrix.generate("rmat_block", 15, 1 << 18, 5, b, world)
+            cuts0 = cuts0 or m.block_cuts
+            assert m.block_cuts == cuts0 and cuts0[0] == 0 and cuts0[-1] == full.n and all(np.diff(cuts0) > 0)
+            r0, r1 = cuts0[b], cuts0[b + 1]
+            B_ = m.to_scipy()
+            assert (B_[r0:r1] != A[r0:r1]).nnz == 0 and B_[:r0].nnz == 0 and B_[r1:].nnz == 0
+            assert np.array_equal(m.V, full.V[full.row_idx[r0]:full.row_idx[r1]])
+            total += m.nnz
+        assert total == full.nnz
+        per_block = np.diff(np.asarray(full.row_idx)[cuts0])
+        assert per_block.max() <= 1.25 * per_block.mean() + 5000          # balanced on samples (hub rows are lumpy)
