@@ -1,28 +1,31 @@
-// Panel form of a LARGE residual: the random gather of x is traded for two streaming passes.
+// Panel form of a LARGE residual WITHOUT locality: the random gather of x is traded for two streaming passes.
 //
 // The reference multiplies its residual ("ER") rows straight from global memory: value and column
 // streamed, x[column] gathered wherever it lies (kernel.cu:169-194).  On a matrix without locality
-// (R-MAT) nearly every such gather misses the 4 MiB L2 of its XCD and moves a whole sector over the
-// fabric for 8 useful bytes: the CSR residual kernel of this library (ehyb_er_kernel) spends 243 us on
-// the 23 M residual entries of R-MAT 2^22 -- about 64 B of fabric traffic per entry besides the 12 B it
-// streams.  The explicit cache of the ELL part (x window in LDS) removes exactly that cost, but only
-// for columns near the row's own partition.  This form extends the idea to ALL columns:
+// (R-MAT) every such gather is its own request to L2 -- 65 % of them hit, but 25 M requests per launch
+// are what bounds the CSR residual kernel of this library (ehyb_er_kernel: 210 us for the 23 M residual
+// entries of R-MAT 2^22, ~110 G entries/s at any size).  The explicit cache of the ELL
+// part (x window in LDS) removes exactly that cost, but only for columns near the row's own partition.
+// This form extends the idea to ALL columns:
 //
-//   pass 1 "scale"   entries grouped by COLUMN PANEL (pb_panel_cols consecutive columns).  A workgroup
-//                    stages its panel of x in LDS (coalesced) and streams (value, 16-bit local column,
-//                    slot): product = value * x_lds[column]; products of one row that sit next to
-//                    each other inside a 64-entry chunk are summed across lanes and ONE partial per
-//                    such piece is written to partial[slot] -- a hub row of 50,000 entries leaves a
-//                    few hundred partials.
+//   pass 1 "scale"   entries grouped by COLUMN PANEL (er_panel_cols consecutive columns, default 8192 =
+//                    64 KiB).  A workgroup stages its panel of x in LDS (coalesced) and streams (value,
+//                    16-bit local column, slot): product = value * x_lds[column]; products of one row
+//                    that sit next to each other inside a 64-entry chunk are summed in the wave's LDS
+//                    words and ONE partial per such piece is written to partial[slot] -- a hub row of
+//                    50,000 entries leaves a few hundred partials.
 //   pass 2 "reduce"  partials grouped by ROW BLOCK (consecutive rows holding about equally many
-//                    partials, at most pb_rows_max rows).  A workgroup keeps the block's y
-//                    accumulators in LDS, streams (partial, 16-bit local row), adds (ds_add_f64; equal
-//                    neighbouring rows summed across lanes first) and finally y[row] += accumulator.
+//                    entries, at most er_block_rows rows, default 2048 = 16 KiB).  A workgroup keeps the
+//                    block's y accumulators in LDS, streams (partial, 16-bit local row), adds
+//                    (ds_add_f64) and finally y[row] += accumulator.
 //
 // Inside a panel the entries are ordered by row, and the partial slots are numbered by (row block,
 // panel, row): a pass-1 workgroup writes runs of consecutive slots, a pass-2 workgroup reads ONE
 // contiguous range.  Every byte of both passes is streamed: 14 B read + <= 8 B written + <= 10 B read
-// per entry instead of 12 B + a sector.  Rows of any length and any skew are fine; no global atomics.
+// per entry instead of 12 B + an L2 request.  Rows of any length and any skew are fine; no global
+// atomics.  Chosen by build_layout for residuals of 2^21 entries and more whose columns show no
+// locality (or cfg.er_mode = 2); measured 1.35-1.4x the CSR form on R-MAT 2^22 / 2^24, behind it
+// where neighbouring rows read neighbouring columns (kkt3d on contiguous partitions).
 #include "ehyb_internal.h"
 
 #include <omp.h>
