@@ -254,8 +254,14 @@ class HaloExchange:
         if L.world == 1:
             return
         if self.a2a:
-            dist.all_to_all_single(self.ghosts, self.send_buf, self.recv_counts, self.send_counts, group=self.group)
-            return
+            try:
+                dist.all_to_all_single(self.ghosts, self.send_buf, self.recv_counts, self.send_counts, group=self.group)
+                return
+            except RuntimeError as err:  # a backend without uneven splits: grouped send/recv pairs from here on
+                import sys
+
+                print(f"[ehyb] all_to_all_single failed ({err}); falling back to batched isend/irecv", file=sys.stderr, flush=True)
+                self.a2a = False
         send, recv = (self.send_buf.cpu(), torch.empty(L.n_ghost, dtype=torch.float64)) if self.stage else (self.send_buf, self.ghosts)
         ops, so, ro = [], 0, 0
         for q in range(L.world):
