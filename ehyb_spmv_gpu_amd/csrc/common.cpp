@@ -206,6 +206,17 @@ int ehyb_sizing(int dimension, const ehyb_config* cfg, int* nParts, int* vectorC
     if (dimension <= 0) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_sizing: dimension %d", dimension);
     Config c = resolve_config(cfg);
     int cache = c.part_rows;
+    // Plain storage, halo window, default sizing: a matrix of a few hundred thousand rows has fewer
+    // full-size partitions than there are work items (256), so several items re-stage the same 160 KiB
+    // window.  About 160 partitions are the better trade between restaging and halo columns
+    // (tools/part_rows_sweep.py, us per SpMV with 11,264-row partitions against the best size: 196 k rows
+    // 45.3 -> 30.0 at 2048 rows, 393 k rows 65.9 -> 53.2 at 2048, 943 k rows 148.5 -> 136.2 at 5632; from
+    // 2.7 M rows on the full-size partitions are as good as any).
+    if (c.sym_pairs != 1 && c.window_mode == EHYB_WINDOW_HALO && c.lds_doubles == EHYB_LDS_MAX_DOUBLES &&
+        c.part_rows == round_down(EHYB_LDS_MAX_DOUBLES * 11 / 20, kSlabRows)) {
+        const int64_t want = ((int64_t)dimension / 160 + kSlabRows - 1) / kSlabRows * kSlabRows;
+        cache = (int)std::min<int64_t>(cache, std::max<int64_t>(2048, want));
+    }
     // the graph partitioner needs slack to balance; contiguous blocks are cut exactly
     int64_t usable = c.partitioner == EHYB_PART_CONTIGUOUS ? cache : std::max<int64_t>(kSlabRows, (int64_t)(cache * 0.97));
     int64_t parts = (dimension + usable - 1) / usable;
