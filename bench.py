@@ -404,6 +404,17 @@ def dropin_case(E, O, np, workload, x, y_cpu, scale, steps, log):
     return out
 
 
+def side_arm(name, fn, log):
+    """The extra measurements of the N = 1 line (plain storage, drop-in calls, vendor library, scaling anchor)
+    must not cost the headline its line: a failure there -- a parity mismatch included -- is reported under
+    the arm's own key."""
+    try:
+        return fn()
+    except (Exception, SystemExit) as err:  # noqa: BLE001
+        log(f"[bench] {name} FAILED: {err}")
+        return {"error": str(err) or type(err).__name__}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -622,16 +633,17 @@ def main():
     plain = None
     if st["sym_pairs"] > 0 and not args.no_plain_arm:
         t0 = time.time()
-        plain = one_gpu_case(E, O, np, args.workload, False, kw, args.steps, args.warmup, log, y_cpu=y_cpu, scale=scale, x=x)
+        plain = side_arm("plain-storage arm", lambda: one_gpu_case(E, O, np, args.workload, False, kw, args.steps, args.warmup, log,
+                                                                   y_cpu=y_cpu, scale=scale, x=x), log)
         plain["note"] = "every entry stored (bench.py --sym-pairs off); same run, same GPU"
-        log(f"[bench] plain-storage arm: {plain['value']} GFLOP/s ({time.time() - t0:.1f}s incl. its own pre-step)")
+        log(f"[bench] plain-storage arm: {plain.get('value')} GFLOP/s ({time.time() - t0:.1f}s incl. its own pre-step)")
 
     # ---- the same matrix through the reference-named calls with the reference driver's sizing
     dropin = None
     if args.workload in REFERENCE_SIZING and not args.no_dropin_arm:
         t0 = time.time()
-        dropin = dropin_case(E, O, np, args.workload, x, y_cpu, scale, args.steps, log)
-        log(f"[bench] drop-in path: {dropin['value']} GFLOP/s with {dropin['nParts_used']} partitions ({time.time() - t0:.1f}s)")
+        dropin = side_arm("drop-in path", lambda: dropin_case(E, O, np, args.workload, x, y_cpu, scale, args.steps, log), log)
+        log(f"[bench] drop-in path: {dropin.get('value')} GFLOP/s with {dropin.get('nParts_used')} partitions ({time.time() - t0:.1f}s)")
 
     # ---- vendor library on the same matrix (opt-in; not part of the product path)
     vendor = None
@@ -639,7 +651,7 @@ def main():
         sys.path.insert(0, os.path.join(ROOT, "tools"))
         import compare_rocsparse as R
 
-        vendor = R.rocsparse_arm(E, O, np, gen, gargs, x, y_cpu, scale, iters=min(args.steps, 100))
+        vendor = side_arm("vendor baseline", lambda: R.rocsparse_arm(E, O, np, gen, gargs, x, y_cpu, scale, iters=min(args.steps, 100)), log)
         log(f"[bench] rocSPARSE CSR: {vendor}")
 
     # ---- N = 1 point of the strong-scaling curve: the N > 1 default workload on this GPU
@@ -647,10 +659,10 @@ def main():
     if args.workload == "audikw_1-like" and not args.no_scaling_anchor:
         t0 = time.time()
         del y_cpu, scale
-        anchor = one_gpu_case(E, O, np, "rmat-24", False, {}, min(args.steps, 50), min(args.warmup, 5), log)
+        anchor = side_arm("scaling anchor", lambda: one_gpu_case(E, O, np, "rmat-24", False, {}, min(args.steps, 50), min(args.warmup, 5), log), log)
         anchor["workload"] = "rmat-24"
         anchor["note"] = "BASELINE config 5's matrix on ONE GPU: the N = 1 point for `bench.py --gpus N` (strong scaling, same matrix)"
-        log(f"[bench] scaling anchor rmat-24 on one GPU: {anchor['value']} GFLOP/s, {anchor['ms_per_step']} ms ({time.time() - t0:.1f}s)")
+        log(f"[bench] scaling anchor rmat-24 on one GPU: {anchor.get('value')} GFLOP/s, {anchor.get('ms_per_step')} ms ({time.time() - t0:.1f}s)")
 
     ms_per_step = elapsed / args.steps * 1e3
     out = {

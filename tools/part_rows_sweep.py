@@ -12,8 +12,12 @@ import ehyb_spmv_gpu_amd as E  # noqa: E402
 
 CASES = [("fem3d", (196608, 3, 42, 42, 13500, 1, 1)), ("fem3d", (393216, 3, 52, 52, 13500, 1, 1)), ("fem3d", (943695, 3, 68, 68, 13500, 1, 1)),
          ("kkt3d", (110,))]
+SIZES = (11264, 8192, 5632, 3712, 2048, 1024)
+if len(sys.argv) > 1 and sys.argv[1] == "mid":   # the range where the direct shape hands over to the windows
+    CASES = [("fem3d", (n, 3, 40, 40, 13500, 1, 1)) for n in (98304, 131070, 163839, 196608, 262143)]
+    SIZES = (11264, 8192, 4096, 2048)
 for kind, args in CASES:
-    for pr in (0, 8192, 5632, 3712, 2048, 1024):
+    for pr in SIZES:
         kw = dict(direct=2)
         if pr:
             kw["part_rows"] = pr
