@@ -18,6 +18,7 @@ from .host import (  # noqa: F401
     Matrix,
     Plan,
     device_count,
+    entry_order,
     host_threads,
     make_config,
     partition_graph,

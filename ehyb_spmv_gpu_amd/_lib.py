@@ -61,6 +61,7 @@ class Config(C.Structure):
         ("er_block_rows", C.c_int32),
         ("direct", C.c_int32),
         ("ell_prune", C.c_int32),
+        ("value_map", C.c_int32),
     ]
 
 
@@ -118,6 +119,8 @@ SIGNATURES = {
     "ehyb_spmv_phase": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
     "ehyb_spmv_bench": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _dp, _dp, _dp]),
     "ehyb_spmv_host": (C.c_int, [_vp, _dp, _dp, C.c_int]),
+    "ehyb_plan_set_values": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, _vp]),
+    "ehyb_entry_order": (C.c_int, [C.c_int, _ip, _ip, _P(C.c_int32)]),
     "ehyb_device_count": (C.c_int, [_ip]),
     "ehyb_device_set": (C.c_int, [C.c_int]),
     "ehyb_device_name": (C.c_int, [C.c_char_p, C.c_int]),

@@ -119,6 +119,7 @@ Config resolve_config(const ehyb_config* in)
     c.er_block_rows = z.er_block_rows > 0 ? std::min(16384, std::max(64, z.er_block_rows)) : 2048;  // measured best on R-MAT 2^22 (1024-4096 level, 8192 25 % slower)
     c.direct = (z.direct == 1 || z.direct == 2) ? z.direct : 0;
     c.ell_prune = z.ell_prune == 2 ? 2 : 1;
+    c.value_map = z.value_map == 1 ? 1 : 0;
     // the automatic choice of the direct shape is for callers that left the window sizing alone: a caller
     // that names a window (lds_doubles / part_rows other than the defaults) gets that window
     if (c.direct == 0 && (c.lds_doubles != EHYB_LDS_MAX_DOUBLES || c.part_rows != round_down(EHYB_LDS_MAX_DOUBLES * 11 / 20, kSlabRows) ||
@@ -175,6 +176,7 @@ void ehyb_config_resolve(const ehyb_config* in, ehyb_config* out)
     r.er_block_rows = c.er_block_rows;
     r.direct = c.direct;
     r.ell_prune = c.ell_prune;
+    r.value_map = c.value_map;
     *out = r;
 }
 

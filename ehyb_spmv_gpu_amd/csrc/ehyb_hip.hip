@@ -641,7 +641,8 @@ static void free_device(ehyb_plan* P)
                      (void**)&P->d_slab_meta,  (void**)&P->d_items,     (void**)&P->d_segs,       (void**)&P->d_er_seg_ptr,
                      (void**)&P->d_er_seg_row, (void**)&P->d_er_col,    (void**)&P->d_er_val,     (void**)&P->d_er_blocks,
                      (void**)&P->d_slab_lrow,  (void**)&P->d_pb_val,    (void**)&P->d_pb_col,     (void**)&P->d_pb_dst,
-                     (void**)&P->d_pb_units1,  (void**)&P->d_pb_row,    (void**)&P->d_pb_units2,  (void**)&P->d_pb_partial};
+                     (void**)&P->d_pb_units1,  (void**)&P->d_pb_row,    (void**)&P->d_pb_units2,  (void**)&P->d_pb_partial,
+                     (void**)&P->d_ell_src,    (void**)&P->d_ell_src2,  (void**)&P->d_er_src,     (void**)&P->d_pb_src};
     for (void** q : ptrs) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;

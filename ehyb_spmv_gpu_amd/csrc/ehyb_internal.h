@@ -49,6 +49,7 @@ struct Config {
     int er_block_rows;
     int direct;             // 0 automatic, 1 on, 2 off
     int ell_prune;          // 0/1: windows that cost more than the panel residual are given up, 2 = never
+    int value_map;          // 1: keep the slot maps of the value streams (ehyb_plan_set_values)
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -123,6 +124,13 @@ struct HostLayout {
     std::vector<int32_t> pb_units1;   // {first column, columns, first entry, end entry}
     std::vector<uint16_t> pb_row;     // per partial: row - first row of its block
     std::vector<int32_t> pb_units2;   // {first partial, end partial, first row, rows}
+
+    // slot maps (cfg.value_map): entry of the source matrix every slot of a value stream was filled from, -1 = padding
+    std::vector<int32_t> ell_src;     // like ell_val
+    std::vector<int32_t> ell_src2;    // like ell_val, sym only: the mirror entry the slot also stands for, else -1
+    std::vector<int32_t> er_src;      // like er_val
+    std::vector<int32_t> pb_src;      // like pb_val
+    int64_t src_entries = 0;          // entries of the source matrix (length ehyb_plan_set_values expects)
 
     ehyb_stats stats{};
 };
@@ -200,4 +208,10 @@ struct ehyb_plan {
     uint16_t* d_pb_row = nullptr;
     int32_t* d_pb_units2 = nullptr;
     double* d_pb_partial = nullptr;  // [pb_partials] written by pass 1, read by pass 2: one multiply at a time per plan
+    // slot maps on the device, uploaded by the first ehyb_plan_set_values
+    int32_t* d_ell_src = nullptr;
+    int32_t* d_ell_src2 = nullptr;
+    int32_t* d_er_src = nullptr;
+    int32_t* d_pb_src = nullptr;
+    bool host_values_stale = false;  // the device values were refilled: the host copy no longer matches
 };

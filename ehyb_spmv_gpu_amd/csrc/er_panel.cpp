@@ -115,6 +115,8 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     L->pb_val.assign((size_t)padded, 0.0);
     L->pb_col.assign((size_t)padded, 0);
     L->pb_dst.assign((size_t)padded, 0xFFFFFFFFu);
+    const bool vmap = !L->er_src.empty();
+    L->pb_src.assign(vmap ? (size_t)padded : 0, -1);
 
     // ---- pieces: runs of one row inside a 64-entry chunk of a panel, numbered in pass-1 order
     // piece_of[pos] (temporarily in pb_dst), and per piece its row
@@ -144,6 +146,7 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
                 if (k == b || ((k - b) & 63) == 0 || erow[src] != erow[order[(size_t)k - 1]]) piece_row[(size_t)++piece] = erow[src];
                 const int64_t pos = pstart[p] + (k - b);
                 L->pb_val[(size_t)pos] = evalv[src];
+                if (vmap) L->pb_src[(size_t)pos] = L->er_src[src];
                 L->pb_col[(size_t)pos] = (uint16_t)(ecol[src] - p * W);
                 L->pb_dst[(size_t)pos] = (uint32_t)piece;
             }

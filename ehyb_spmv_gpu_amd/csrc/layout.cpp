@@ -59,7 +59,8 @@ inline int halo_lookup(const std::vector<int32_t>& halo, int col)
 //     as its longest row).
 //   * Entries inside a group (the diagonal blocks) stay as they are.
 // state is indexed by entry number minus k0.
-void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64_t k0, uint8_t* state)
+// partner (may be null): for every kept entry (state 1) the entry it also stands for, indexed like state.
+void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64_t k0, uint8_t* state, int32_t* partner)
 {
     const int own = e - s;
     const int* J = m->J;
@@ -143,6 +144,7 @@ void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64
                 if (state[lo->second - k0] == 0 && V[lo->second] == V[k]) {
                     state[k - k0] = 1;
                     state[lo->second - k0] = 2;
+                    if (partner) partner[k - k0] = (int32_t)lo->second;
                     break;
                 }
         }
@@ -238,12 +240,15 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     const int64_t k0 = rp[row_begin];
     std::vector<uint8_t> state;       // per entry: 0 as it is, 1 kept + scatter, 2 dropped
     std::vector<int32_t> dropped;     // per row
+    std::vector<int32_t> partner;     // per kept entry: the dropped entry it also stands for (value map only)
+    const bool vmap = cfg.value_map == 1;
     if (sym) {
         state.assign((size_t)(rp[row_end] - k0), 0);
+        if (vmap) partner.assign(state.size(), -1);
         dropped.assign(nrows, 0);
 #pragma omp parallel for schedule(dynamic, 2)
         for (int p = 0; p < np; ++p) {
-            sym_orient_partition(m, rp, pb[p], pb[p + 1], k0, state.data());
+            sym_orient_partition(m, rp, pb[p], pb[p + 1], k0, state.data(), vmap ? partner.data() : nullptr);
             for (int r = pb[p]; r < pb[p + 1]; ++r) {
                 int d = 0;
                 for (int k = rp[r]; k < rp[r + 1]; ++k) d += state[k - k0] == 2;
@@ -562,6 +567,14 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     L->slab_lrow.assign(sym ? (size_t)nslabs * kSlabRows : 0, (uint16_t)0xFFFF);
     std::vector<int32_t> tcol((size_t)nnz_er);
     std::vector<double> tval((size_t)nnz_er);
+    // slot maps (cfg.value_map): the entry every slot of a value stream is filled from, so that the numeric
+    // phase can be repeated on the device for new values (ehyb_plan_set_values)
+    std::vector<int32_t> tsrc(vmap ? (size_t)nnz_er : 0);
+    L->ell_src.assign(vmap ? (size_t)size_stream : 0, -1);
+    L->ell_src2.assign(vmap && sym ? (size_t)size_stream : 0, -1);
+    L->er_src.clear();
+    L->pb_src.clear();
+    L->src_entries = m->totalNum;
     int overflow = 0;
 #pragma omp parallel for schedule(dynamic, 4)
     for (int p = 0; p < np; ++p) {
@@ -609,6 +622,10 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                     }
                     size_t at = (size_t)(((pp + k_ell / 2) * kSlabRows + lane) * 2 + (k_ell & 1));
                     L->ell_val[at] = m->V[k];
+                    if (vmap) {
+                        L->ell_src[at] = k;
+                        if (st8 == 1) L->ell_src2[at] = partner[k - k0];
+                    }
                     if (st8 == 1) {
                         if (local >= 0x8000 || j < s || j >= e) {  // only own rows have an accumulator
                             overflow = 1;
@@ -623,6 +640,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 } else {
                     tcol[(size_t)k_er] = j;
                     tval[(size_t)k_er] = m->V[k];
+                    if (vmap) tsrc[(size_t)k_er] = k;
                     if (L->inline_er) {
                         const uint32_t ke = (uint32_t)(k_er - er_rp[r - row_begin]);
                         if (ke >= 2 * ner) {
@@ -630,6 +648,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                             continue;
                         }
                         L->ell_val[(size_t)(((pp + w2 + ke / 2) * kSlabRows + lane) * 2 + (ke & 1))] = m->V[k];
+                        if (vmap) L->ell_src[(size_t)(((pp + w2 + ke / 2) * kSlabRows + lane) * 2 + (ke & 1))] = k;
                         L->ell_col[(size_t)(cp + (uint64_t)w2 * G + (uint64_t)(ke / 2) * 2 * kSlabRows + (ke & 1) * kSlabRows + lane)] = (uint32_t)j;
                     }
                     ++k_er;
@@ -778,8 +797,10 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     }
     L->er_col.resize((size_t)nnz_er);
     L->er_val.resize((size_t)nnz_er);
+    if (vmap) L->er_src.resize((size_t)nnz_er);
 #pragma omp parallel for schedule(static)
     for (int64_t i = 0; i < nseg; ++i) {
+        if (vmap) std::copy(tsrc.begin() + segs[i].begin, tsrc.begin() + segs[i].begin + segs[i].len, L->er_src.begin() + L->er_seg_ptr[i]);
         std::copy(tcol.begin() + segs[i].begin, tcol.begin() + segs[i].begin + segs[i].len,
                   L->er_col.begin() + L->er_seg_ptr[i]);
         std::copy(tval.begin() + segs[i].begin, tval.begin() + segs[i].begin + segs[i].len,

@@ -169,6 +169,10 @@ int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int
         case EHYB_ARR_PB_UNITS1: VIEW(H.pb_units1);
         case EHYB_ARR_PB_ROW: VIEW(H.pb_row);
         case EHYB_ARR_PB_UNITS2: VIEW(H.pb_units2);
+        case EHYB_ARR_ELL_SRC: VIEW(H.ell_src);
+        case EHYB_ARR_ER_SRC: VIEW(H.er_src);
+        case EHYB_ARR_PB_SRC: VIEW(H.pb_src);
+        case EHYB_ARR_ELL_SRC2: VIEW(H.ell_src2);
         case EHYB_ARR_ER_BINS:
             *ptr = (const void*)H.er_bins;
             *count = 8;

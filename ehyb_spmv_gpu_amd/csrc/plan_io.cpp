@@ -128,6 +128,8 @@ int ehyb_plan_save(const ehyb_plan* plan, const int* reorder_list, uint64_t matr
 {
     clear_error();
     if (!plan || !path) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_save: null argument");
+    if (plan->host_values_stale)
+        EHYB_FAIL(EHYB_ERR_STATE, "ehyb_plan_save: the plan's values were replaced on the device (ehyb_plan_set_values); its host copy is stale");
     HostLayout& H = const_cast<HostLayout&>(plan->host);  // each_array takes non-const; nothing is modified
     File f(fopen(path, "wb"));
     if (!f) EHYB_FAIL(EHYB_ERR_IO, "ehyb_plan_save: cannot create %s", path);

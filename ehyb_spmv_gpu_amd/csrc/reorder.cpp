@@ -496,6 +496,33 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
     return EHYB_OK;
 }
 
+// Where every entry of the reordered matrix came from: new row `pos` is old row rows_of[pos] copied in its
+// stored order (the permuted-CSR step above, reordering.c:348-362), so the entry order is a function of the
+// old row pointer and the permutation alone.
+extern "C" int ehyb_entry_order(int dimension, const int* row_idx_before, const int* reorder_list, int32_t* entry_order)
+{
+    clear_error();
+    const int n = dimension;
+    if (n <= 0 || !row_idx_before || !reorder_list || !entry_order) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_entry_order: bad arguments");
+    std::vector<int> old_of(n, -1);
+    for (int i = 0; i < n; ++i) {
+        const int t = reorder_list[i];
+        if ((unsigned)t >= (unsigned)n || old_of[t] >= 0) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_entry_order: reorder_list is not a permutation (entry %d)", i);
+        old_of[t] = i;
+    }
+    std::vector<int64_t> rp_new(n + 1, 0);
+    for (int t = 0; t < n; ++t) rp_new[t + 1] = rp_new[t] + (row_idx_before[old_of[t] + 1] - row_idx_before[old_of[t]]);
+    if (rp_new[n] != (int64_t)row_idx_before[n] - row_idx_before[0]) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_entry_order: row_idx_before is not a row pointer");
+    OmpScope omp(0);
+#pragma omp parallel for schedule(static, 1024)
+    for (int t = 0; t < n; ++t) {
+        const int o = old_of[t];
+        int64_t dst = rp_new[t];
+        for (int k = row_idx_before[o]; k < row_idx_before[o + 1]; ++k) entry_order[dst++] = k;
+    }
+    return EHYB_OK;
+}
+
 extern "C" int ehyb_top_boundary(const matrixCOO* m, const ehyb_config* cfg, int n_top, int* part_of_block)
 {
     if (!m || !part_of_block || n_top < 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_top_boundary: bad arguments");

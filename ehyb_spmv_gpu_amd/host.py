@@ -26,6 +26,7 @@ ARRAYS = {
     "segs": (18, np.int32), "perm": (19, np.int32), "slab_lrow": (20, np.uint16),
     "pb_val": (21, np.float64), "pb_col": (22, np.uint16), "pb_dst": (23, np.uint32), "pb_units1": (24, np.int32),
     "pb_row": (25, np.uint16), "pb_units2": (26, np.int32),
+    "ell_src": (27, np.int32), "er_src": (28, np.int32), "pb_src": (29, np.int32), "ell_src2": (30, np.int32),
 }
 
 
@@ -264,6 +265,18 @@ def vector_reorder(v, reorder_list):
     return out
 
 
+def entry_order(row_idx_before, reorder_list):
+    """ehyb_entry_order: out[k_new] = k_old, the place of every entry of the reordered matrix in the caller's
+    arrays before ehyb_matrix_reorder (the V scatter of reordering.c:348-362 as an index list)."""
+    rp = np.ascontiguousarray(row_idx_before, dtype=np.int32)
+    lst = np.ascontiguousarray(reorder_list, dtype=np.int32)
+    n = len(lst)
+    assert rp.shape == (n + 1,)
+    out = np.empty(int(rp[-1]) - int(rp[0]), dtype=np.int32)
+    _check(_lib.load().ehyb_entry_order(n, _ptr(rp, C.c_int), _ptr(lst, C.c_int), _ptr(out, C.c_int32)), "ehyb_entry_order")
+    return out
+
+
 def vector_recover(v_rodr, reorder_list):
     """vectorRecover (reordering.c:386-391): out[i] = v_rodr[list[i]]."""
     v = np.ascontiguousarray(v_rodr, dtype=np.float64)
@@ -357,6 +370,21 @@ class Plan:
         y = np.zeros(self.n, dtype=np.float64)
         _check(self.lib.ehyb_spmv_host(self.h, _ptr(x, C.c_double), _ptr(y, C.c_double), iters), "ehyb_spmv_host")
         return y
+
+    def set_values(self, values, entry_order=None, stream=0):
+        """ehyb_plan_set_values: the numeric phase of the build again, on the device, for new values on the
+        plan's pattern (needs cfg.value_map = 1).  values / entry_order: numpy arrays (host) or, both of them,
+        device pointers given as (ptr, count) tuples."""
+        if isinstance(values, tuple):
+            ptr, count = values
+            order = None if entry_order is None else C.c_void_p(entry_order[0])
+            _check(self.lib.ehyb_plan_set_values(self.h, C.c_void_p(ptr), count, order, 1, C.c_void_p(stream)), "ehyb_plan_set_values")
+            return
+        v = np.ascontiguousarray(values, dtype=np.float64)
+        o = None if entry_order is None else np.ascontiguousarray(entry_order, dtype=np.int32)
+        assert o is None or o.shape == v.shape
+        _check(self.lib.ehyb_plan_set_values(self.h, v.ctypes.data_as(C.c_void_p), len(v), o.ctypes.data_as(C.c_void_p) if o is not None else None,
+                                             0, C.c_void_p(stream)), "ehyb_plan_set_values")
 
     def bench(self, x_dev, y_dev, stream=0, warmup=10, iters=100, per_kernel=True):
         t, e, r = C.c_double(), C.c_double(), C.c_double()

@@ -144,6 +144,10 @@ typedef struct ehyb_config {
     int32_t ell_prune;     /* with the residual in panel form: 0/1 = a partition whose LDS window costs more bytes and
                               L2 requests than the panel form would for its entries (padding, halo gathers: power-law
                               matrices) goes to the residual whole, 2 = never                                 */
+    int32_t value_map;     /* 1 = the plan remembers, for every slot of its value streams, which entry of the matrix it
+                              was filled from (4 B per stored value on the host, and on the device from the first
+                              ehyb_plan_set_values on): the NUMERIC phase of the build can then be repeated on the
+                              GPU for new values on the same pattern.  0 = off                                 */
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);
@@ -310,7 +314,14 @@ enum {
     EHYB_ARR_PB_UNITS1     = 24,/* int32  [4*u1] pass-1 work units {first column, columns, first entry, end entry}  */
     EHYB_ARR_PB_ROW        = 25,/* uint16 [er_partials] row of the partial - first row of its row block; partials are
                                    numbered by (row block, panel, row)                                     */
-    EHYB_ARR_PB_UNITS2     = 26 /* int32  [4*u2] pass-2 work units {first partial, end partial, first row, rows}    */
+    EHYB_ARR_PB_UNITS2     = 26,/* int32  [4*u2] pass-2 work units {first partial, end partial, first row, rows}    */
+    /* slot maps of the value streams (cfg.value_map; empty otherwise): index into the V array of the matrix the plan
+       was built from, -1 = padding.  What ehyb_plan_set_values gathers through on the device. */
+    EHYB_ARR_ELL_SRC       = 27,/* int32  same length as ELL_VAL                                                      */
+    EHYB_ARR_ER_SRC        = 28,/* int32  same length as ER_VAL                                                       */
+    EHYB_ARR_PB_SRC        = 29,/* int32  same length as PB_VAL                                                       */
+    EHYB_ARR_ELL_SRC2      = 30 /* int32  same length as ELL_VAL, symmetric pair storage only: the mirror entry a_ji
+                                   this slot also stands for (-1: the slot stands for one entry)                      */
 };
 int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int64_t* count);
 
@@ -354,6 +365,31 @@ int ehyb_spmv_bench(ehyb_plan* plan, const double* x_dev, double* y_dev, void* s
  */
 int spmvGPuEHYB_cfg(matrixCOO* localMatrix, const double* vectorIn, double* vectorOut, const int MAXIter,
                     int* realIter, const ehyb_config* cfg, double* ms_total);
+
+/*
+ * Numeric phase of the build on the GPU: new VALUES on the pattern the plan was built from.
+ * The reference fills its ELL / ER value arrays on one host thread (convert.c:316-369, after the scatter of V
+ * through the permutation in reordering.c:348-362) and repeats partition, conversion and upload for every
+ * matrix.  A plan built with cfg.value_map = 1 keeps the slot maps of its value streams; this call gathers
+ * `values` through them straight into the device arrays the kernels read (ehyb_fill_kernel: ELL stream,
+ * residual segments or panel stream), padding = 0.0 -- no partitioner, no layout pass, no re-upload of the
+ * index arrays.
+ *   values       count doubles = the V array of a matrix with the SAME row-grouped pattern: in the order of the
+ *                reordered matrix the plan was built from (entry_order NULL), or in the caller's order BEFORE
+ *                ehyb_matrix_reorder with entry_order[k] = place of reordered entry k in `values`
+ *                (ehyb_entry_order computes it).
+ *   on_device    0: values / entry_order are host arrays (uploaded for the call);  1: both are device pointers.
+ * With symmetric pair storage a slot stands for a_ij AND a_ji: the new values must be bitwise equal there; they
+ * are checked on the device first and the plan is left untouched (EHYB_ERR_ARG) if any pair differs.
+ * After a successful call the HOST copy of the value arrays (ehyb_plan_host_array, ehyb_plan_save) is stale:
+ * ehyb_plan_save refuses such a plan.  Synchronous with respect to `stream` when on_device = 0.
+ */
+int ehyb_plan_set_values(ehyb_plan* plan, const double* values, int64_t count, const int32_t* entry_order,
+                         int on_device, void* stream);
+/* entry_order[k_new] = k_old: where entry k_new of the matrix AFTER ehyb_matrix_reorder sat in the caller's
+ * row-grouped arrays before it (rows move as wholes and keep their stored order).  row_idx_before = the rowIdx of
+ * the matrix before the call (dimension+1 ints), reorder_list as the call left it. */
+int ehyb_entry_order(int dimension, const int* row_idx_before, const int* reorder_list, int32_t* entry_order);
 
 /* Convenience: host vectors in, host vector out (H2D, `iters` multiplies, D2H). */
 int ehyb_spmv_host(ehyb_plan* plan, const double* x_host, double* y_host, int iters);
