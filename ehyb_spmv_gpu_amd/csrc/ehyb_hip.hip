@@ -365,18 +365,21 @@ __global__ __launch_bounds__(THREADS) void ehyb_er_kernel(const int4* __restrict
 
 // ------------------------------------------------------------------ panel residual (er_panel.cpp)
 // Pass 1: one workgroup per unit {first column, columns, first entry, end entry}.  The unit's panel of
-// x is staged in LDS; (value, 16-bit local column, slot) are streamed, four 64-entry chunks per wave
-// and step (twelve independent loads in flight), the products of one row that sit next to each other
-// in a chunk are summed across the lanes and the first lane of each such piece stores the partial.
+// x is staged in LDS; (value, 16-bit column word) are streamed, eight 64-entry chunks per wave and step.
+// The column word carries two flags from which a lane works out the slot of its partial (er_panel.cpp,
+// encode_panel_slots): bit 15 = first entry of a piece (entries of one row that are neighbours in the
+// chunk), bit 14 = the piece's slot is not the previous piece's + 1 but comes from the jump list.  The
+// products of a piece are summed in the wave's LDS words and its first lane stores the partial.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __restrict__ units,
                                                                 const double* __restrict__ val,
-                                                                const uint16_t* __restrict__ col,
-                                                                const uint32_t* __restrict__ dst,
+                                                                const uint16_t* __restrict__ colf,
+                                                                const uint2* __restrict__ chunk,
+                                                                const uint32_t* __restrict__ jump,
                                                                 const double* __restrict__ x,
                                                                 double* __restrict__ partial, int panel_cols, int probe)
 {
-    // probe (tools/er_ab.py --probe, timing diagnostics only, results wrong): 1 no lane sums, 2 no stores,
+    // probe (tools/panel_sweep.py, timing diagnostics only, results wrong): 1 no lane sums, 2 no stores,
     // 4 no LDS gather, 8 no panel staging
     extern __shared__ __attribute__((aligned(16))) double win[];
     constexpr int WAVES = THREADS / 64;
@@ -408,42 +411,59 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
     double* scr = win + panel_cols + 64 * wave;  // this wave's 64 piece accumulators, behind the panel
     scr[lane] = 0.0;
     const int c0 = u.z >> 6, c1 = u.w >> 6;  // chunks of 64 entries
-    constexpr int K = 8;  // chunks per wave and step: 24 independent loads in flight per lane
+    constexpr int K = 8;  // chunks per wave and step: 16 independent vector loads in flight per lane
+    const unsigned long long below = (2ull << lane) - 1ull;  // the lanes up to and including this one
     for (int c = c0 + K * wave; c < c1; c += K * WAVES) {
         double v[K];
-        uint32_t cc[K], d[K];
+        uint32_t cw[K];
+        uint2 rec[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const bool in = c + j < c1;
-            const size_t pos = (size_t)(in ? c + j : c) * 64 + lane;
+            const int cj = c + j < c1 ? c + j : c;  // wave-uniform
+            const size_t pos = (size_t)cj * 64 + lane;
             v[j] = val[pos];
-            cc[j] = col[pos];
-            d[j] = in ? dst[pos] : 0xFFFFFFFFu;
+            cw[j] = colf[pos];
+            rec[j] = chunk[cj];
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const double prod = (probe & 4) ? v[j] * (double)cc[j] : v[j] * win[cc[j]];
-            // head = first lane of a piece (entries of one row that are neighbours in this chunk share a slot)
-            const uint32_t before = (uint32_t)__builtin_amdgcn_update_dpp((int)~d[j], (int)d[j], 0x138 /* wave_shr:1 */, 0xf, 0xf, false);
-            const bool head = lane == 0 || before != d[j];
-            const unsigned long long heads = __ballot(head);
-            double sum = prod;
-            if (heads != ~0ull && !(probe & 1)) {
-                // Some lanes share a slot: the piece sums are formed in this wave's 64 LDS words (zero between
-                // uses), one ds_add_f64 per lane, one read + one store of zero per piece.  (Shuffle trees --
-                // six ds_bpermute rounds per chunk -- cost 17 us of a 127 us launch here and 17 of 80 in pass 2.)
-                const int run = (int)__popcll(heads & ((2ull << lane) - 1ull)) - 1;
-                unsafeAtomicAdd(&scr[run], prod);
-                if (head) {
-                    sum = scr[run];
-                    scr[run] = 0.0;
+            if (c + j < c1) {  // wave-uniform
+                const uint32_t cl = cw[j] & 0x3FFFu;
+                const double prod = (probe & 4) ? v[j] * (double)cl : v[j] * win[cl];
+                const bool head = (cw[j] & 0x8000u) != 0;
+                const unsigned long long heads = __ballot(head);
+                const unsigned long long jumps = __ballot((cw[j] & 0x4000u) != 0);
+                const int hcount = (int)__popcll(heads & below);  // pieces begun up to this lane, >= 1
+                double sum = prod;
+                if (heads != ~0ull && !(probe & 1)) {
+                    // Some lanes share a slot: the piece sums are formed in this wave's 64 LDS words (zero between
+                    // uses), one ds_add_f64 per lane, one read + one store of zero per piece.  (Shuffle trees --
+                    // six ds_bpermute rounds per chunk -- cost 17 us of a 127 us launch here and 17 of 80 in pass 2.)
+                    unsafeAtomicAdd(&scr[hcount - 1], prod);
+                    if (head) {
+                        sum = scr[hcount - 1];
+                        scr[hcount - 1] = 0.0;
+                    }
                 }
-            }
-            if (head && d[j] != 0xFFFFFFFFu && (!(probe & 2) || sum == 123.456)) {
-                if (probe & 256)
-                    __builtin_nontemporal_store(sum, &partial[d[j]]);
-                else
-                    partial[d[j]] = sum;
+                if (head) {
+                    // the piece's slot: the chunk's first slot, or the last jump at or below this lane, plus the pieces since
+                    const unsigned long long jb = jumps & below;
+                    uint32_t slot;
+                    if (jb == 0) {
+                        slot = rec[j].x + (uint32_t)(hcount - 1);
+                    } else {
+                        const int lj = 63 - (int)__clzll((long long)jb);
+                        const uint32_t at = jump[rec[j].y + (uint32_t)__popcll(jb) - 1u];
+                        const uint32_t since = (uint32_t)(hcount - (int)__popcll(heads & ((2ull << lj) - 1ull)));
+                        slot = at == 0xFFFFFFFFu ? at : at + since;  // padding at the end of a panel: one piece, never stored
+                    }
+                    if (slot != 0xFFFFFFFFu && (!(probe & 2) || sum == 123.456)) {
+                        if (probe & 256)
+                            __builtin_nontemporal_store(sum, &partial[slot]);
+                        else
+                            partial[slot] = sum;
+                    }
+                }
             }
         }
     }
@@ -591,19 +611,28 @@ static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st, 
     return launch_ell_impl<false>(P, x, y, st, inl, nullptr);
 }
 
+// which: 1 = pass 1 (scale), 2 = pass 2 (reduce), 3 = both
+static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st, int probe, int which)
+{
+    const HostLayout& H = P->host;
+    const int u1 = (int)(H.pb_units1.size() / 4), u2 = (int)(H.pb_units2.size() / 4);
+    if (which & 1)
+        hipLaunchKernelGGL(ehyb_pb_scale_kernel<512>, dim3(u1), dim3(512), (size_t)(H.pb_panel_cols + 512) * 8, st, (const int4*)P->d_pb_units1,
+                           P->d_pb_val, P->d_pb_colf, (const uint2*)P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, probe);
+    if (which & 2)
+        hipLaunchKernelGGL(ehyb_pb_reduce_kernel<512>, dim3(u2), dim3(512), (size_t)H.pb_rows_max * 8, st, (const int4*)P->d_pb_units2,
+                           P->d_pb_partial, P->d_pb_row, y, probe);
+    HIP_TRY(hipGetLastError());
+    return EHYB_OK;
+}
+
 static int launch_er(ehyb_plan* P, const double* x, double* y, hipStream_t st)
 {
     const HostLayout& H = P->host;
     if (H.er_bins[3] == 0) return EHYB_OK;
     if (H.er_panel) {  // panel form: scale (x panels in LDS) then reduce (y blocks in LDS)
         static const int pb_probe = [] { const char* e = getenv("EHYB_PB_PROBE"); return e ? atoi(e) : 0; }();  // timing diagnostics only
-        const int u1 = (int)(H.pb_units1.size() / 4), u2 = (int)(H.pb_units2.size() / 4);
-        hipLaunchKernelGGL(ehyb_pb_scale_kernel<512>, dim3(u1), dim3(512), (size_t)(H.pb_panel_cols + 512) * 8, st, (const int4*)P->d_pb_units1,
-                           P->d_pb_val, P->d_pb_col, P->d_pb_dst, x, P->d_pb_partial, H.pb_panel_cols, pb_probe);
-        hipLaunchKernelGGL(ehyb_pb_reduce_kernel<512>, dim3(u2), dim3(512), (size_t)H.pb_rows_max * 8, st, (const int4*)P->d_pb_units2,
-                           P->d_pb_partial, P->d_pb_row, y, pb_probe);
-        HIP_TRY(hipGetLastError());
-        return EHYB_OK;
+        return launch_panel(P, x, y, st, pb_probe, 3);
     }
     const int n_blocks = (int)(H.er_blocks.size() / 4);
     if (P->cfg.er_threads != 256) EHYB_FAIL(EHYB_ERR_ARG, "residual workgroup size %d not built (256)", P->cfg.er_threads);
@@ -640,7 +669,7 @@ static void free_device(ehyb_plan* P)
     void** ptrs[] = {(void**)&P->d_halo_cols,  (void**)&P->d_ell_val,   (void**)&P->d_ell_col,    (void**)&P->d_lane_group,
                      (void**)&P->d_slab_meta,  (void**)&P->d_items,     (void**)&P->d_segs,       (void**)&P->d_er_seg_ptr,
                      (void**)&P->d_er_seg_row, (void**)&P->d_er_col,    (void**)&P->d_er_val,     (void**)&P->d_er_blocks,
-                     (void**)&P->d_slab_lrow,  (void**)&P->d_pb_val,    (void**)&P->d_pb_col,     (void**)&P->d_pb_dst,
+                     (void**)&P->d_slab_lrow,  (void**)&P->d_pb_val,    (void**)&P->d_pb_colf,    (void**)&P->d_pb_chunk,   (void**)&P->d_pb_jump,
                      (void**)&P->d_pb_units1,  (void**)&P->d_pb_row,    (void**)&P->d_pb_units2,  (void**)&P->d_pb_partial,
                      (void**)&P->d_ell_src,    (void**)&P->d_ell_src2,  (void**)&P->d_er_src,     (void**)&P->d_pb_src};
     for (void** q : ptrs) {
@@ -754,6 +783,31 @@ int ehyb_debug_ell_stamps(ehyb_plan* P, const double* x, double* y, unsigned lon
     return EHYB_OK;
 }
 
+// Diagnostic (tools/panel_sweep.py): mean time of each pass of the panel residual alone, `iters` launches each
+// between HIP events on the null stream; probe switches single steps of the kernels off (results wrong then).
+int ehyb_debug_panel_times(ehyb_plan* P, const double* x, double* y, int iters, int probe, double* ms_scale, double* ms_reduce)
+{
+    if (!P || !P->uploaded || !P->host.er_panel || iters < 1 || !ms_scale || !ms_reduce) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_debug_panel_times: bad arguments");
+    hipEvent_t a, b;
+    HIP_TRY(hipEventCreate(&a));
+    HIP_TRY(hipEventCreate(&b));
+    double* out[2] = {ms_scale, ms_reduce};
+    int rc = EHYB_OK;
+    for (int which = 1; which <= 2 && rc == EHYB_OK; ++which) {
+        for (int i = 0; i < 3 && rc == EHYB_OK; ++i) rc = launch_panel(P, x, y, nullptr, probe, which);
+        (void)hipEventRecord(a, nullptr);
+        for (int i = 0; i < iters && rc == EHYB_OK; ++i) rc = launch_panel(P, x, y, nullptr, probe, which);
+        (void)hipEventRecord(b, nullptr);
+        (void)hipEventSynchronize(b);
+        float ms = 0;
+        (void)hipEventElapsedTime(&ms, a, b);
+        *out[which - 1] = ms / iters;
+    }
+    (void)hipEventDestroy(a);
+    (void)hipEventDestroy(b);
+    return rc;
+}
+
 int ehyb_plan_upload(ehyb_plan* P)
 {
     clear_error();
@@ -781,8 +835,9 @@ int ehyb_plan_upload(ehyb_plan* P)
     if (H.er_panel) {
         // the residual launch runs the panel form: the CSR segments stay on the host
         UP(d_pb_val, pb_val)
-        UP(d_pb_col, pb_col)
-        UP(d_pb_dst, pb_dst)
+        UP(d_pb_colf, pb_colf)
+        UP(d_pb_chunk, pb_chunk)
+        UP(d_pb_jump, pb_jump)
         UP(d_pb_units1, pb_units1)
         UP(d_pb_row, pb_row)
         UP(d_pb_units2, pb_units2)

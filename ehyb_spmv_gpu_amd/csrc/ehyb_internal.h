@@ -124,6 +124,10 @@ struct HostLayout {
     std::vector<int32_t> pb_units1;   // {first column, columns, first entry, end entry}
     std::vector<uint16_t> pb_row;     // per partial: row - first row of its block
     std::vector<int32_t> pb_units2;   // {first partial, end partial, first row, rows}
+    // what pass 1 streams in place of pb_col + pb_dst (derived from them by encode_panel_slots, not stored in plan files)
+    std::vector<uint16_t> pb_colf;    // column | head flag (bit 15) | jump flag (bit 14)
+    std::vector<uint32_t> pb_chunk;   // per 64-entry chunk {slot of its first piece, first jump}
+    std::vector<uint32_t> pb_jump;    // slots of the jump heads, stream order
 
     // slot maps (cfg.value_map): entry of the source matrix every slot of a value stream was filled from, -1 = padding
     std::vector<int32_t> ell_src;     // like ell_val
@@ -138,6 +142,7 @@ struct HostLayout {
 int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* out,
                  const std::vector<uint8_t>* part_to_er = nullptr);
 int build_panel_residual(const Config& cfg, HostLayout* L);  // er_panel.cpp; reads the CSR residual of *L
+void encode_panel_slots(HostLayout* L);                      // er_panel.cpp; pb_col + pb_dst -> pb_colf, pb_chunk, pb_jump
 bool sym_storage_suits(const matrixCOO* m);
 int windows_that_do_not_pay(const HostLayout& H, std::vector<uint8_t>* to_er, int64_t* entries_moved);  // plan.cpp  // spmvGPuEHYB's own choice of the storage (plan.cpp)
 
@@ -202,8 +207,9 @@ struct ehyb_plan {
     int32_t* d_er_blocks = nullptr;
     uint16_t* d_slab_lrow = nullptr;
     double* d_pb_val = nullptr;
-    uint16_t* d_pb_col = nullptr;
-    uint32_t* d_pb_dst = nullptr;
+    uint16_t* d_pb_colf = nullptr;
+    uint32_t* d_pb_chunk = nullptr;
+    uint32_t* d_pb_jump = nullptr;
     int32_t* d_pb_units1 = nullptr;
     uint16_t* d_pb_row = nullptr;
     int32_t* d_pb_units2 = nullptr;

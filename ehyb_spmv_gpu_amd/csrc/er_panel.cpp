@@ -35,6 +35,66 @@
 
 namespace ehyb {
 
+// What pass 1 really streams instead of the 4-byte slot of every entry (pb_dst stays on the host as the
+// definition the tests and the oracle read).  Inside a 64-entry chunk the entries are sorted by row, so their
+// slots are runs: a piece keeps its slot, the next piece of the same row block has the next slot, and only where
+// the chunk crosses into another row block (or into the padding at the end of a panel) the slot jumps.  Hence
+//   pb_colf  [entry]  bits 0-13 the panel-local column, bit 15 = first entry of a piece ("head"; lane 0 always),
+//                     bit 14 = head whose slot does not follow the previous piece's: taken from the jump list;
+//   pb_chunk [chunk]  {slot of the chunk's first piece, index of the chunk's first jump in pb_jump};
+//   pb_jump  [jumps]  slot of every bit-14 head in stream order (0xFFFFFFFF = padding: nothing is stored).
+// slot(lane) = (no jump at or below the lane ? chunk slot : pb_jump[first + jumps at or below - 1]) + heads since.
+// R-MAT 2^24: 4 B per entry become 0.125 + ~0.45 B.
+void encode_panel_slots(HostLayout* L)
+{
+    const int64_t padded = (int64_t)L->pb_dst.size();
+    const int64_t chunks = padded / 64;
+    L->pb_colf.assign((size_t)padded, 0);
+    L->pb_chunk.assign((size_t)chunks * 2, 0);
+    L->pb_jump.clear();
+    if (padded == 0) return;
+    const uint32_t* dst = L->pb_dst.data();
+    const uint16_t* col = L->pb_col.data();
+    // jumps per chunk first (parallel), then their places
+    std::vector<int64_t> jfirst((size_t)chunks + 1, 0);
+#pragma omp parallel for schedule(static, 256)
+    for (int64_t c = 0; c < chunks; ++c) {
+        const uint32_t* d = dst + c * 64;
+        int j = 0;
+        uint32_t prev_head = d[0];
+        for (int l = 1; l < 64; ++l)
+            if (d[l] != d[l - 1]) {
+                j += d[l] != prev_head + 1 || prev_head == 0xFFFFFFFFu;
+                prev_head = d[l];
+            }
+        jfirst[(size_t)c + 1] = j;
+    }
+    for (int64_t c = 0; c < chunks; ++c) jfirst[(size_t)c + 1] += jfirst[(size_t)c];
+    L->pb_jump.resize((size_t)jfirst[(size_t)chunks]);
+#pragma omp parallel for schedule(static, 256)
+    for (int64_t c = 0; c < chunks; ++c) {
+        const uint32_t* d = dst + c * 64;
+        uint16_t* f = L->pb_colf.data() + c * 64;
+        int64_t j = jfirst[(size_t)c];
+        L->pb_chunk[(size_t)c * 2] = d[0];
+        L->pb_chunk[(size_t)c * 2 + 1] = (uint32_t)j;
+        uint32_t prev_head = d[0];
+        f[0] = (uint16_t)(col[c * 64] | 0x8000u);
+        for (int l = 1; l < 64; ++l) {
+            uint16_t w = col[c * 64 + l];
+            if (d[l] != d[l - 1]) {
+                w |= 0x8000u;
+                if (d[l] != prev_head + 1 || prev_head == 0xFFFFFFFFu) {
+                    w |= 0x4000u;
+                    L->pb_jump[(size_t)j++] = d[l];
+                }
+                prev_head = d[l];
+            }
+            f[l] = w;
+        }
+    }
+}
+
 int build_panel_residual(const Config& cfg, HostLayout* L)
 {
     const int64_t nnz_er = (int64_t)L->er_col.size();
@@ -66,8 +126,8 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
         ++cnt_row[r];
     }
     // (tuning knobs for tools/er_ab.py only: EHYB_PB_UNITS1 / EHYB_PB_UNITS2 = work units aimed at per pass)
-    static const int64_t env_u1 = [] { const char* e = getenv("EHYB_PB_UNITS1"); return e ? atoll(e) : 0ll; }();
-    static const int64_t env_u2 = [] { const char* e = getenv("EHYB_PB_UNITS2"); return e ? atoll(e) : 0ll; }();
+    const int64_t env_u1 = [] { const char* e = getenv("EHYB_PB_UNITS1"); return e ? atoll(e) : 0ll; }();
+    const int64_t env_u2 = [] { const char* e = getenv("EHYB_PB_UNITS2"); return e ? atoll(e) : 0ll; }();
     const int64_t target = std::min<int64_t>(std::max<int64_t>(nnz_er / (env_u2 > 0 ? env_u2 : 2048), 4096), 1 << 20);
     std::vector<int32_t> rb_first;  // first row (plan numbering) of every block, + end
     std::vector<int32_t> rb_of_row((size_t)nrows);
@@ -202,7 +262,9 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     L->er_panel = true;
     // bytes the two launches move: entries (value, column, slot) + the staged panels + partials out;
     // partials (value, row) in + the touched y rows read and written
-    L->pb_bytes = 14 * padded + 8 * staged + 8 * n_pieces + 10 * n_pieces + 16 * L->stats.rows_er +
+    encode_panel_slots(L);
+    // (value, column+flags) + chunk records + jump list instead of a 4-byte slot per entry
+    L->pb_bytes = 10 * padded + 8 * (padded / 64) + 4 * (int64_t)L->pb_jump.size() + 8 * staged + 8 * n_pieces + 10 * n_pieces + 16 * L->stats.rows_er +
                   16 * (int64_t)(L->pb_units1.size() / 4 + L->pb_units2.size() / 4);
     if (cfg.verbose)
         printf("panel residual: %lld entries (%lld with padding) in %d panels of %d columns -> %lld partials, %zu + %zu work units, "

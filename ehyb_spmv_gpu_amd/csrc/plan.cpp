@@ -169,6 +169,9 @@ int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int
         case EHYB_ARR_PB_UNITS1: VIEW(H.pb_units1);
         case EHYB_ARR_PB_ROW: VIEW(H.pb_row);
         case EHYB_ARR_PB_UNITS2: VIEW(H.pb_units2);
+        case EHYB_ARR_PB_COLF: VIEW(H.pb_colf);
+        case EHYB_ARR_PB_CHUNK: VIEW(H.pb_chunk);
+        case EHYB_ARR_PB_JUMP: VIEW(H.pb_jump);
         case EHYB_ARR_ELL_SRC: VIEW(H.ell_src);
         case EHYB_ARR_ER_SRC: VIEW(H.er_src);
         case EHYB_ARR_PB_SRC: VIEW(H.pb_src);

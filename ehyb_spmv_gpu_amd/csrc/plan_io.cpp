@@ -94,6 +94,8 @@ bool panel_consistent(const HostLayout& H)
     }
     for (uint32_t d : H.pb_dst)
         if (d != 0xFFFFFFFFu && d >= (uint64_t)H.pb_partials) return false;
+    for (uint16_t c : H.pb_col)
+        if (c >= H.pb_panel_cols) return false;  // bits 14 and 15 of the streamed column word are flags
     return true;
 }
 
@@ -199,6 +201,7 @@ int ehyb_plan_load(const char* path, uint64_t expect_key, ehyb_plan** plan, int*
         H.lds_doubles > 0 && H.lds_doubles <= EHYB_LDS_MAX_DOUBLES && (perm.empty() || perm.size() == (size_t)H.n_cols) &&
         panel_consistent(H);
     if (!consistent) EHYB_FAIL(EHYB_ERR_FORMAT, "ehyb_plan_load: %s holds inconsistent array sizes", path);
+    if (H.er_panel) encode_panel_slots(&H);  // what pass 1 streams is derived from pb_col + pb_dst, not stored
     if (reorder_list) {
         if (perm.empty()) EHYB_FAIL(EHYB_ERR_FORMAT, "ehyb_plan_load: %s holds no permutation", path);
         std::copy(perm.begin(), perm.end(), reorder_list);

@@ -26,6 +26,7 @@ ARRAYS = {
     "segs": (18, np.int32), "perm": (19, np.int32), "slab_lrow": (20, np.uint16),
     "pb_val": (21, np.float64), "pb_col": (22, np.uint16), "pb_dst": (23, np.uint32), "pb_units1": (24, np.int32),
     "pb_row": (25, np.uint16), "pb_units2": (26, np.int32),
+    "pb_colf": (31, np.uint16), "pb_chunk": (32, np.uint32), "pb_jump": (33, np.uint32),
     "ell_src": (27, np.int32), "er_src": (28, np.int32), "pb_src": (29, np.int32), "ell_src2": (30, np.int32),
 }
 

@@ -320,8 +320,14 @@ enum {
     EHYB_ARR_ELL_SRC       = 27,/* int32  same length as ELL_VAL                                                      */
     EHYB_ARR_ER_SRC        = 28,/* int32  same length as ER_VAL                                                       */
     EHYB_ARR_PB_SRC        = 29,/* int32  same length as PB_VAL                                                       */
-    EHYB_ARR_ELL_SRC2      = 30 /* int32  same length as ELL_VAL, symmetric pair storage only: the mirror entry a_ji
+    EHYB_ARR_ELL_SRC2      = 30,/* int32  same length as ELL_VAL, symmetric pair storage only: the mirror entry a_ji
                                    this slot also stands for (-1: the slot stands for one entry)                      */
+    /* panel form: what pass 1 streams in place of PB_COL + PB_DST (derived from them; PB_DST stays the definition).
+       Inside a 64-entry chunk the slots are runs, so 4 bytes per entry become two flag bits:                          */
+    EHYB_ARR_PB_COLF       = 31,/* uint16 like PB_COL: bits 0-13 column, bit 15 = first entry of a piece (its partial),
+                                   bit 14 = that piece's slot does not follow the previous piece's (see PB_JUMP)      */
+    EHYB_ARR_PB_CHUNK      = 32,/* uint32 [2 per chunk] {slot of the chunk's first piece, index of its first jump}     */
+    EHYB_ARR_PB_JUMP       = 33 /* uint32 slot of every bit-14 piece in stream order; 0xFFFFFFFF = padding            */
 };
 int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int64_t* count);
 

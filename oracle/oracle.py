@@ -295,6 +295,27 @@ def walk_plan(plan, x):
     return y, written
 
 
+def decode_panel_slots(colf, chunk, jump):
+    """Slot of every entry from what pass 1 of the panel residual really streams (include/ehyb.h
+    EHYB_ARR_PB_COLF / PB_CHUNK / PB_JUMP), computed as ehyb_pb_scale_kernel does per 64-entry chunk:
+    slot = (no jump flag at or below the lane ? the chunk's first slot : the jump list's entry for the last
+    jump at or below it) + pieces begun since.  -> (local column, slot) per entry; 0xFFFFFFFF = padding."""
+    colf = colf.astype(np.int64).reshape(-1, 64)
+    chunk = chunk.astype(np.int64).reshape(-1, 2)
+    jump = jump.astype(np.int64)
+    head = (colf >> 15) & 1
+    jmp = (colf >> 14) & 1
+    assert np.all(head[:, 0] == 1) and np.all(jmp[:, 0] == 0) and np.all(jmp <= head)
+    hcount = np.cumsum(head, axis=1)
+    jcount = np.cumsum(jmp, axis=1)
+    assert len(jump) == int(jmp.sum()) and np.all(chunk[1:, 1] == np.cumsum(jmp.sum(axis=1))[:-1]) and (len(chunk) == 0 or chunk[0, 1] == 0)
+    h_at_jump = np.maximum.accumulate(np.where(jmp == 1, hcount, 0), axis=1)
+    at = np.where(jcount > 0, jump[np.minimum(chunk[:, 1:2] + jcount - 1, max(len(jump) - 1, 0))] if len(jump) else 0, chunk[:, 0:1])
+    since = np.where(jcount > 0, hcount - h_at_jump, hcount - 1)
+    slot = np.where(at == 0xFFFFFFFF, 0xFFFFFFFF, at + since)
+    return (colf & 0x3FFF).reshape(-1), slot.reshape(-1)
+
+
 def walk_panel_residual(plan, x):
     """y contribution of the residual in panel form (include/ehyb.h EHYB_ARR_PB_*): pass 1 per unit
     {first column, columns, first entry, end entry} multiplies with the unit's x panel and sums the
@@ -307,6 +328,9 @@ def walk_panel_residual(plan, x):
     prow = plan.array("pb_row").astype(np.int64)
     P = plan.stats["er_partials"]
     assert len(val) == len(col) == len(dst) and len(val) % 64 == 0 and len(prow) == P
+    # what the kernel streams (flags + chunk records + jump list) must decode to exactly these columns and slots
+    col_k, dst_k = decode_panel_slots(plan.array("pb_colf"), plan.array("pb_chunk"), plan.array("pb_jump"))
+    assert np.array_equal(col_k, col) and np.array_equal(dst_k, dst), "compressed slots of pass 1 do not decode to pb_dst"
     pad = dst == 0xFFFFFFFF
     assert not val[pad].any() and dst[~pad].max() < P and plan.stats["nnz_er"] == int((~pad).sum())
     # an entry's slot is shared only with neighbours inside its own 64-entry chunk (what the lane sums assume)

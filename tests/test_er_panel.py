@@ -33,8 +33,12 @@ def test_panel_form_walks_to_the_reference_product(E, O, name, kind, args, kw):
     u2 = plan.array("pb_units2").reshape(-1, 4)
     assert np.all(u1[:, 1] <= cfg.er_panel_cols) and np.all(u1[:, 0] % cfg.er_panel_cols == 0)
     assert np.all(u2[:, 3] <= cfg.er_block_rows)
-    # bytes: both passes streamed -- entries at 14 B, partials at 18 B, plus panels and y
-    assert st["bytes_format"] - st["bytes_format_ell"] >= 14 * st["nnz_er"] + 18 * st["er_partials"]
+    # bytes: both passes streamed -- entries at 10 B (value, column word with the two slot flags) plus the jump
+    # list, partials at 18 B, plus panels and y; the jump list holds at most one slot per partial
+    er_bytes = st["bytes_format"] - st["bytes_format_ell"]
+    jumps = len(plan.array("pb_jump"))
+    assert jumps <= st["er_partials"] + len(plan.array("pb_chunk")) // 2
+    assert er_bytes >= 10 * st["nnz_er"] + 18 * st["er_partials"] + 4 * jumps
 
 
 def test_mode_selection(E, O):

@@ -59,7 +59,7 @@ def test_refilled_plan_multiplies_like_a_fresh_one(E, O, gpu, name, kind, args, 
     fresh = E.Plan(c.m, cfg)
     assert fresh.stats == plan.stats
     yf = fresh.spmv_host(c.xp)
-    if not sym:
+    if not sym and plan.stats["er_partials"] == 0:   # (LDS atomics -- symmetric pairs, panel residual -- add in any order)
         assert np.array_equal(yf.view(np.int64), y2p.view(np.int64)), "refilled and fresh plan differ bitwise"
     else:
         assert np.all(np.abs(yf - y2p) <= 1e-12 * np.maximum(E.vector_reorder(scale2, c.perm), 1e-300))
