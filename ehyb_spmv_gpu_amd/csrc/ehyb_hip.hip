@@ -368,13 +368,14 @@ __global__ __launch_bounds__(THREADS) void ehyb_er_kernel(const int4* __restrict
 // x is staged in LDS; (value, 16-bit column word) are streamed, eight 64-entry chunks per wave and step.
 // The column word carries two flags from which a lane works out the slot of its partial (er_panel.cpp,
 // encode_panel_slots): bit 15 = first entry of a piece (entries of one row that are neighbours in the
-// chunk), bit 14 = the piece's slot is not the previous piece's + 1 but comes from the jump list.  The
-// products of a piece are summed in the wave's LDS words and its first lane stores the partial.
+// chunk), bit 14 = the piece's slot is not the previous piece's + 1: a "jump", with an entry in the jump list
+// from which every lane behind it (up to the next jump) gets its slot by adding the pieces begun before its own.
+// The products of a piece are summed in the wave's LDS words and its first lane stores the partial.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __restrict__ units,
                                                                 const double* __restrict__ val,
                                                                 const uint16_t* __restrict__ colf,
-                                                                const uint2* __restrict__ chunk,
+                                                                const uint32_t* __restrict__ chunk,
                                                                 const uint32_t* __restrict__ jump,
                                                                 const double* __restrict__ x,
                                                                 double* __restrict__ partial, int panel_cols, int probe)
@@ -411,61 +412,76 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
     double* scr = win + panel_cols + 64 * wave;  // this wave's 64 piece accumulators, behind the panel
     scr[lane] = 0.0;
     const int c0 = u.z >> 6, c1 = u.w >> 6;  // chunks of 64 entries
-    constexpr int K = 8;  // chunks per wave and step: 16 independent vector loads in flight per lane
-    const unsigned long long below = (2ull << lane) - 1ull;  // the lanes up to and including this one
+    constexpr int K = 8;  // chunks per wave and step: 24 independent vector loads in flight per lane
+    // The jump-list range of a chunk is known from the chunk records alone (wave-uniform, scalar loads): they are
+    // fetched one step ahead, so that the jump entries travel together with the values and column words instead
+    // of behind them (a gather that waits for the flags doubled the latency per step: 345 -> 470 us on R-MAT 2^24).
+    uint32_t f0[K], fn[K];
+#pragma unroll
+    for (int j = 0; j < K; ++j) {
+        const int cj = min(c0 + K * wave + j, c1 - 1);
+        f0[j] = chunk[cj];
+        fn[j] = chunk[cj + 1] - f0[j];
+    }
     for (int c = c0 + K * wave; c < c1; c += K * WAVES) {
         double v[K];
-        uint32_t cw[K];
-        uint2 rec[K];
+        uint32_t cw[K], jv[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             const int cj = c + j < c1 ? c + j : c;  // wave-uniform
             const size_t pos = (size_t)cj * 64 + lane;
             v[j] = val[pos];
             cw[j] = colf[pos];
-            rec[j] = chunk[cj];
+            jv[j] = (uint32_t)lane < fn[j] ? jump[f0[j] + lane] : 0u;  // lane l: the chunk's l-th jump entry
+        }
+        uint32_t g0[K], gn[K];  // the records of the next step
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int cj = min(c + K * WAVES + j, c1 - 1);
+            g0[j] = chunk[cj];
+            gn[j] = chunk[cj + 1] - g0[j];
+        }
+        uint32_t slot[K], piece[K];
+        double xw[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const bool head = (cw[j] & 0x8000u) != 0, jmp = (cw[j] & 0x4000u) != 0;
+            const unsigned long long heads = __ballot(head), jumps = __ballot(jmp);
+            // pieces / jumps begun in the lanes below this one (v_mbcnt), plus its own
+            const uint32_t hc = __builtin_amdgcn_mbcnt_hi((uint32_t)(heads >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)heads, 0u)) + (head ? 1u : 0u);
+            const uint32_t jc = __builtin_amdgcn_mbcnt_hi((uint32_t)(jumps >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)jumps, 0u)) + (jmp ? 1u : 0u);
+            // the entry of the last jump at or below this lane sits in lane jc - 1 (lane 0 is always a jump)
+            const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((jc - 1u) << 2), (int)jv[j]);
+            piece[j] = hc - 1u;
+            slot[j] = head ? base + hc - 1u : 0xFFFFFFFFu;  // 0xFFFFFFFF: nothing to store (also what the padding piece yields)
+            const uint32_t cl = cw[j] & 0x3FFFu;
+            xw[j] = (probe & 4) ? (double)cl : win[cl];
+            cw[j] = heads == ~0ull ? 1u : 0u;  // every lane its own piece: no sums needed
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             if (c + j < c1) {  // wave-uniform
-                const uint32_t cl = cw[j] & 0x3FFFu;
-                const double prod = (probe & 4) ? v[j] * (double)cl : v[j] * win[cl];
-                const bool head = (cw[j] & 0x8000u) != 0;
-                const unsigned long long heads = __ballot(head);
-                const unsigned long long jumps = __ballot((cw[j] & 0x4000u) != 0);
-                const int hcount = (int)__popcll(heads & below);  // pieces begun up to this lane, >= 1
+                const double prod = v[j] * xw[j];
                 double sum = prod;
-                if (heads != ~0ull && !(probe & 1)) {
+                if (!cw[j] && !(probe & 1)) {
                     // Some lanes share a slot: the piece sums are formed in this wave's 64 LDS words (zero between
                     // uses), one ds_add_f64 per lane, one read + one store of zero per piece.  (Shuffle trees --
                     // six ds_bpermute rounds per chunk -- cost 17 us of a 127 us launch here and 17 of 80 in pass 2.)
-                    unsafeAtomicAdd(&scr[hcount - 1], prod);
-                    if (head) {
-                        sum = scr[hcount - 1];
-                        scr[hcount - 1] = 0.0;
-                    }
+                    unsafeAtomicAdd(&scr[piece[j]], prod);
+                    if (slot[j] != 0xFFFFFFFFu) sum = scr[piece[j]];
+                    __builtin_amdgcn_wave_barrier();
+                    scr[piece[j]] = 0.0;
                 }
-                if (head) {
-                    // the piece's slot: the chunk's first slot, or the last jump at or below this lane, plus the pieces since
-                    const unsigned long long jb = jumps & below;
-                    uint32_t slot;
-                    if (jb == 0) {
-                        slot = rec[j].x + (uint32_t)(hcount - 1);
-                    } else {
-                        const int lj = 63 - (int)__clzll((long long)jb);
-                        const uint32_t at = jump[rec[j].y + (uint32_t)__popcll(jb) - 1u];
-                        const uint32_t since = (uint32_t)(hcount - (int)__popcll(heads & ((2ull << lj) - 1ull)));
-                        slot = at == 0xFFFFFFFFu ? at : at + since;  // padding at the end of a panel: one piece, never stored
-                    }
-                    if (slot != 0xFFFFFFFFu && (!(probe & 2) || sum == 123.456)) {
-                        if (probe & 256)
-                            __builtin_nontemporal_store(sum, &partial[slot]);
-                        else
-                            partial[slot] = sum;
-                    }
+                if (slot[j] != 0xFFFFFFFFu && (!(probe & 2) || sum == 123.456)) {
+                    if (probe & 256)
+                        __builtin_nontemporal_store(sum, &partial[slot[j]]);
+                    else
+                        partial[slot[j]] = sum;
                 }
             }
         }
+#pragma unroll
+        for (int j = 0; j < K; ++j) f0[j] = g0[j], fn[j] = gn[j];
     }
 }
 
@@ -618,7 +634,7 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
     const int u1 = (int)(H.pb_units1.size() / 4), u2 = (int)(H.pb_units2.size() / 4);
     if (which & 1)
         hipLaunchKernelGGL(ehyb_pb_scale_kernel<512>, dim3(u1), dim3(512), (size_t)(H.pb_panel_cols + 512) * 8, st, (const int4*)P->d_pb_units1,
-                           P->d_pb_val, P->d_pb_colf, (const uint2*)P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, probe);
+                           P->d_pb_val, P->d_pb_colf, P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, probe);
     if (which & 2)
         hipLaunchKernelGGL(ehyb_pb_reduce_kernel<512>, dim3(u2), dim3(512), (size_t)H.pb_rows_max * 8, st, (const int4*)P->d_pb_units2,
                            P->d_pb_partial, P->d_pb_row, y, probe);

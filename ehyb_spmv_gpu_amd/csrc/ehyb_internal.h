@@ -126,8 +126,8 @@ struct HostLayout {
     std::vector<int32_t> pb_units2;   // {first partial, end partial, first row, rows}
     // what pass 1 streams in place of pb_col + pb_dst (derived from them by encode_panel_slots, not stored in plan files)
     std::vector<uint16_t> pb_colf;    // column | head flag (bit 15) | jump flag (bit 14)
-    std::vector<uint32_t> pb_chunk;   // per 64-entry chunk {slot of its first piece, first jump}
-    std::vector<uint32_t> pb_jump;    // slots of the jump heads, stream order
+    std::vector<uint32_t> pb_chunk;   // per 64-entry chunk: its first jump
+    std::vector<uint32_t> pb_jump;    // per jump: slot - pieces before it in its chunk
 
     // slot maps (cfg.value_map): entry of the source matrix every slot of a value stream was filled from, -1 = padding
     std::vector<int32_t> ell_src;     // like ell_val

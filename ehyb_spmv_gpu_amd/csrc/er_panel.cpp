@@ -40,17 +40,19 @@ namespace ehyb {
 // slots are runs: a piece keeps its slot, the next piece of the same row block has the next slot, and only where
 // the chunk crosses into another row block (or into the padding at the end of a panel) the slot jumps.  Hence
 //   pb_colf  [entry]  bits 0-13 the panel-local column, bit 15 = first entry of a piece ("head"; lane 0 always),
-//                     bit 14 = head whose slot does not follow the previous piece's: taken from the jump list;
-//   pb_chunk [chunk]  {slot of the chunk's first piece, index of the chunk's first jump in pb_jump};
-//   pb_jump  [jumps]  slot of every bit-14 head in stream order (0xFFFFFFFF = padding: nothing is stored).
-// slot(lane) = (no jump at or below the lane ? chunk slot : pb_jump[first + jumps at or below - 1]) + heads since.
-// R-MAT 2^24: 4 B per entry become 0.125 + ~0.45 B.
+//                     bit 14 = head whose slot does not follow the previous piece's ("jump"; lane 0 always);
+//   pb_chunk [chunk]  index of the chunk's first jump in pb_jump (+ one end entry);
+//   pb_jump  [jumps]  slot of the jump piece minus the number of pieces before it in its chunk, so that
+//                     slot(lane) = pb_jump[first + jumps up to the lane - 1] + pieces before the lane's  (mod 2^32)
+//                     for every lane, whichever jump it follows; the padding piece at the end of a panel gets
+//                     the value that makes this 0xFFFFFFFF = nothing is stored.
+// R-MAT 2^24: 4 B per entry become ~0.6 B.
 void encode_panel_slots(HostLayout* L)
 {
     const int64_t padded = (int64_t)L->pb_dst.size();
     const int64_t chunks = padded / 64;
     L->pb_colf.assign((size_t)padded, 0);
-    L->pb_chunk.assign((size_t)chunks * 2, 0);
+    L->pb_chunk.assign((size_t)chunks + 1, 0);
     L->pb_jump.clear();
     if (padded == 0) return;
     const uint32_t* dst = L->pb_dst.data();
@@ -60,33 +62,35 @@ void encode_panel_slots(HostLayout* L)
 #pragma omp parallel for schedule(static, 256)
     for (int64_t c = 0; c < chunks; ++c) {
         const uint32_t* d = dst + c * 64;
-        int j = 0;
+        int j = 1;
         uint32_t prev_head = d[0];
         for (int l = 1; l < 64; ++l)
             if (d[l] != d[l - 1]) {
-                j += d[l] != prev_head + 1 || prev_head == 0xFFFFFFFFu;
+                j += d[l] != prev_head + 1;
                 prev_head = d[l];
             }
         jfirst[(size_t)c + 1] = j;
     }
     for (int64_t c = 0; c < chunks; ++c) jfirst[(size_t)c + 1] += jfirst[(size_t)c];
     L->pb_jump.resize((size_t)jfirst[(size_t)chunks]);
+    L->pb_chunk[(size_t)chunks] = (uint32_t)jfirst[(size_t)chunks];
 #pragma omp parallel for schedule(static, 256)
     for (int64_t c = 0; c < chunks; ++c) {
         const uint32_t* d = dst + c * 64;
         uint16_t* f = L->pb_colf.data() + c * 64;
         int64_t j = jfirst[(size_t)c];
-        L->pb_chunk[(size_t)c * 2] = d[0];
-        L->pb_chunk[(size_t)c * 2 + 1] = (uint32_t)j;
-        uint32_t prev_head = d[0];
-        f[0] = (uint16_t)(col[c * 64] | 0x8000u);
+        L->pb_chunk[(size_t)c] = (uint32_t)j;
+        uint32_t prev_head = d[0], pieces = 0;  // pieces begun before the current lane's
+        f[0] = (uint16_t)(col[c * 64] | 0xC000u);
+        L->pb_jump[(size_t)j++] = d[0];
         for (int l = 1; l < 64; ++l) {
             uint16_t w = col[c * 64 + l];
             if (d[l] != d[l - 1]) {
+                ++pieces;
                 w |= 0x8000u;
-                if (d[l] != prev_head + 1 || prev_head == 0xFFFFFFFFu) {
+                if (d[l] != prev_head + 1) {
                     w |= 0x4000u;
-                    L->pb_jump[(size_t)j++] = d[l];
+                    L->pb_jump[(size_t)j++] = d[l] - pieces;  // mod 2^32: 0xFFFFFFFF - pieces for the padding piece
                 }
                 prev_head = d[l];
             }
@@ -264,7 +268,7 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     // partials (value, row) in + the touched y rows read and written
     encode_panel_slots(L);
     // (value, column+flags) + chunk records + jump list instead of a 4-byte slot per entry
-    L->pb_bytes = 10 * padded + 8 * (padded / 64) + 4 * (int64_t)L->pb_jump.size() + 8 * staged + 8 * n_pieces + 10 * n_pieces + 16 * L->stats.rows_er +
+    L->pb_bytes = 10 * padded + 4 * (padded / 64 + 1) + 4 * (int64_t)L->pb_jump.size() + 8 * staged + 8 * n_pieces + 10 * n_pieces + 16 * L->stats.rows_er +
                   16 * (int64_t)(L->pb_units1.size() / 4 + L->pb_units2.size() / 4);
     if (cfg.verbose)
         printf("panel residual: %lld entries (%lld with padding) in %d panels of %d columns -> %lld partials, %zu + %zu work units, "

@@ -325,9 +325,12 @@ enum {
     /* panel form: what pass 1 streams in place of PB_COL + PB_DST (derived from them; PB_DST stays the definition).
        Inside a 64-entry chunk the slots are runs, so 4 bytes per entry become two flag bits:                          */
     EHYB_ARR_PB_COLF       = 31,/* uint16 like PB_COL: bits 0-13 column, bit 15 = first entry of a piece (its partial),
-                                   bit 14 = that piece's slot does not follow the previous piece's (see PB_JUMP)      */
-    EHYB_ARR_PB_CHUNK      = 32,/* uint32 [2 per chunk] {slot of the chunk's first piece, index of its first jump}     */
-    EHYB_ARR_PB_JUMP       = 33 /* uint32 slot of every bit-14 piece in stream order; 0xFFFFFFFF = padding            */
+                                   bit 14 = that piece's slot does not follow the previous piece's: a "jump" (the
+                                   first entry of a chunk always is one)                                              */
+    EHYB_ARR_PB_CHUNK      = 32,/* uint32 [chunks+1] index of the chunk's first jump in PB_JUMP; last = number of jumps */
+    EHYB_ARR_PB_JUMP       = 33 /* uint32 per jump: its slot minus the pieces before it in its chunk (mod 2^32), so that
+                                   slot(entry) = PB_JUMP[chunk's first + jumps up to the entry - 1] + pieces before the
+                                   entry's; the padding piece of a panel's last chunk yields 0xFFFFFFFF             */
 };
 int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int64_t* count);
 

@@ -298,21 +298,19 @@ def walk_plan(plan, x):
 def decode_panel_slots(colf, chunk, jump):
     """Slot of every entry from what pass 1 of the panel residual really streams (include/ehyb.h
     EHYB_ARR_PB_COLF / PB_CHUNK / PB_JUMP), computed as ehyb_pb_scale_kernel does per 64-entry chunk:
-    slot = (no jump flag at or below the lane ? the chunk's first slot : the jump list's entry for the last
-    jump at or below it) + pieces begun since.  -> (local column, slot) per entry; 0xFFFFFFFF = padding."""
+    slot = PB_JUMP[chunk's first jump + jumps up to the lane - 1] + pieces begun before the lane's (mod 2^32).
+    -> (local column, slot) per entry; 0xFFFFFFFF = padding."""
     colf = colf.astype(np.int64).reshape(-1, 64)
-    chunk = chunk.astype(np.int64).reshape(-1, 2)
+    assert len(chunk) == len(colf) + 1 and chunk[-1] == len(jump)
+    chunk = chunk.astype(np.int64)[:-1].reshape(-1, 1)
     jump = jump.astype(np.int64)
     head = (colf >> 15) & 1
     jmp = (colf >> 14) & 1
-    assert np.all(head[:, 0] == 1) and np.all(jmp[:, 0] == 0) and np.all(jmp <= head)
+    assert np.all(head[:, 0] == 1) and np.all(jmp[:, 0] == 1) and np.all(jmp <= head)
     hcount = np.cumsum(head, axis=1)
     jcount = np.cumsum(jmp, axis=1)
-    assert len(jump) == int(jmp.sum()) and np.all(chunk[1:, 1] == np.cumsum(jmp.sum(axis=1))[:-1]) and (len(chunk) == 0 or chunk[0, 1] == 0)
-    h_at_jump = np.maximum.accumulate(np.where(jmp == 1, hcount, 0), axis=1)
-    at = np.where(jcount > 0, jump[np.minimum(chunk[:, 1:2] + jcount - 1, max(len(jump) - 1, 0))] if len(jump) else 0, chunk[:, 0:1])
-    since = np.where(jcount > 0, hcount - h_at_jump, hcount - 1)
-    slot = np.where(at == 0xFFFFFFFF, 0xFFFFFFFF, at + since)
+    assert len(jump) == int(jmp.sum()) and (len(chunk) == 0 or chunk[0, 0] == 0) and np.all(chunk[1:, 0] == np.cumsum(jmp.sum(axis=1))[:-1])
+    slot = (jump[chunk + jcount - 1] + hcount - 1) & 0xFFFFFFFF
     return (colf & 0x3FFF).reshape(-1), slot.reshape(-1)
 
 

@@ -37,7 +37,7 @@ def test_panel_form_walks_to_the_reference_product(E, O, name, kind, args, kw):
     # list, partials at 18 B, plus panels and y; the jump list holds at most one slot per partial
     er_bytes = st["bytes_format"] - st["bytes_format_ell"]
     jumps = len(plan.array("pb_jump"))
-    assert jumps <= st["er_partials"] + len(plan.array("pb_chunk")) // 2
+    assert jumps <= st["er_partials"] + len(plan.array("pb_chunk"))
     assert er_bytes >= 10 * st["nnz_er"] + 18 * st["er_partials"] + 4 * jumps
 
 
