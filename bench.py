@@ -433,6 +433,8 @@ def main():
     ap.add_argument("--no-plain-arm", action="store_true",
                     help="N=1 with symmetric pair storage: skip the extra plain-storage measurement of the same matrix")
     ap.add_argument("--no-dropin-arm", action="store_true", help="N=1: skip the run through the reference-named calls")
+    ap.add_argument("--no-refill-arm", action="store_true",
+                    help="N=1: build the plan without slot maps and skip the timing of the numeric phase on the device (ehyb_plan_set_values)")
     ap.add_argument("--no-scaling-anchor", action="store_true", help="N=1: skip the one-GPU run of the N>1 default workload")
     ap.add_argument("--vendor-baseline", action="store_true", help="N=1: also time rocSPARSE CSR SpMV on the same matrix (opt-in)")
     ap.add_argument("--sym-pairs", default="auto", choices=["auto", "on", "off"],
@@ -518,7 +520,7 @@ def main():
 
     if sym:
         kw["sym_pairs"] = 1
-    cfg = E.make_config(partitioner=partitioner_for(E, gen), verbose=1 if args.verbose else 0, **kw)
+    cfg = E.make_config(partitioner=partitioner_for(E, gen), verbose=1 if args.verbose else 0, value_map=0 if args.no_refill_arm else 1, **kw)
     t0 = time.time()
     m = E.Matrix.generate(gen, *gargs, cfg=cfg)
     n, nnz = m.n, m.nnz
@@ -625,6 +627,36 @@ def main():
         roofline["note"] = ("symmetric pair storage: %d of the %d entries are in-partition pairs a_ij == a_ji stored once "
                             "(one value read, two FMAs, the mirror product added in LDS): frac counts the bytes really "
                             "moved; alg_frac prices every entry at 12 B (SURVEY 8d) and may exceed 1" % (2 * st["sym_pairs"], st["nnz"]))
+    # ---- numeric phase of the build on the device: the plan's own values handed over again, as a host
+    # array and as a device array, then the multiply checked once more.  After the timed loop: it cannot touch `value`.
+    refill = None
+    if not args.no_refill_arm:
+        def refill_case():
+            V = np.ascontiguousarray(m.V, dtype=np.float64)
+            t0 = time.perf_counter()
+            plan.set_values(V)                       # first call: uploads the slot maps too
+            t_first = time.perf_counter() - t0
+            t0 = time.perf_counter()
+            plan.set_values(V)
+            t_host = time.perf_counter() - t0
+            v_d = torch.from_numpy(V).to(dev)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            plan.set_values((v_d.data_ptr(), len(V)), stream=stream)
+            torch.cuda.synchronize()
+            t_dev = time.perf_counter() - t0
+            y_d.zero_()
+            plan.spmv(xp, yp, stream)
+            torch.cuda.synchronize()
+            b2, w2 = O.check_tolerance(E.vector_recover(y_d.cpu().numpy(), perm), y_cpu, scale)
+            if b2:
+                raise SystemExit(f"refilled plan differs from the CPU oracle in {b2} rows")
+            return {"api": "ehyb_plan_set_values (csrc/ehyb_fill.hip): new values on the plan's pattern gathered into the value streams on the GPU",
+                    "ms_host_values": round(t_host * 1e3, 2), "ms_host_values_first_call": round(t_first * 1e3, 2),
+                    "ms_device_values": round(t_dev * 1e3, 3), "slots": st["size_block_ell"] + st["er_inline"] + (0 if inline else st["nnz_er"]),
+                    "parity_after": {"rows_over_1e-12": b2, "worst_rel": w2}}
+        refill = side_arm("numeric-phase arm", refill_case, log)
+        log(f"[bench] numeric phase on the device: {refill}")
     plan.destroy()
     del x_d, y_d
     m.free()
@@ -679,6 +711,8 @@ def main():
         "alg_GBps": round((12 * nnz + 4 * (n + 1) + 16 * n) / (elapsed / args.steps) / 1e9, 1),
         "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
     }
+    if refill:
+        out["numeric_refill"] = refill
     if plain:
         out["plain_storage"] = plain
     if dropin:

@@ -36,7 +36,7 @@
 namespace ehyb {
 
 // What pass 1 really streams instead of the 4-byte slot of every entry (pb_dst stays on the host as the
-// definition the tests and the oracle read).  Inside a 64-entry chunk the entries are sorted by row, so their
+// definition the layout tests read).  Inside a 64-entry chunk the entries are sorted by row, so their
 // slots are runs: a piece keeps its slot, the next piece of the same row block has the next slot, and only where
 // the chunk crosses into another row block (or into the padding at the end of a panel) the slot jumps.  Hence
 //   pb_colf  [entry]  bits 0-13 the panel-local column, bit 15 = first entry of a piece ("head"; lane 0 always),

@@ -150,7 +150,7 @@ def test_config5_rmat24_one_gpu(E, O, gpu):
     merging duplicates), hub rows of > 100,000 entries split into atomically combined segments, four
     fifths of the entries in the residual.  A graph partitioner finds nothing to cut in R-MAT (124 M of
     133 M edges cut after two minutes): contiguous partitions, as bench.py uses for this workload."""
-    cfg = E.make_config(partitioner=E.EHYB_PART_CONTIGUOUS)
+    cfg = E.make_config(partitioner=E.EHYB_PART_CONTIGUOUS, value_map=1)
     c = Case(E, O, "rmat", (24, 1 << 27, 1), cfg)
     assert c.n == 1 << 24 and 1.2e8 < c.nnz < 1.35e8
     plan = E.Plan(c.m, cfg)
@@ -160,3 +160,6 @@ def test_config5_rmat24_one_gpu(E, O, gpu):
     bad, worst = c.check(y)
     assert bad == 0, f"worst {worst:.3e}"
     _check_scaled_and_checksum(c, plan, y)
+    # numeric phase on the device at this size (ELL stream + 120 M-entry panel stream): V -> 4 V is exact
+    plan.set_values(4.0 * c.m.V)
+    assert c.check(0.25 * plan.spmv_host(c.xp))[0] == 0

@@ -44,7 +44,7 @@ def test_sym_matches_oracle(E, O, gpu, name, kind, args, lds, threads):
 
 def test_sym_full_size_audikw_like(E, O, gpu):
     """BASELINE config 2 in full with symmetric pair storage: 256 equal partitions, one workgroup (and CU) each."""
-    cfg = E.make_config(sym_pairs=1)
+    cfg = E.make_config(sym_pairs=1, value_map=1)
     c = Case(E, O, "fem3d", (943695, 3, 68, 68, 13500, 1, 1), cfg)
     plan = E.Plan(c.m, cfg)
     st = plan.stats
@@ -57,3 +57,12 @@ def test_sym_full_size_audikw_like(E, O, gpu):
     colsum = np.zeros(c.n)
     np.add.at(colsum, c.m.J, c.m.V)
     assert abs(y.sum() - float(colsum @ c.xp)) <= 1e-11 * float(np.abs(c.m.V).sum())
+    # the numeric phase on the device at full size (ehyb_plan_set_values): A -> -3 A + sign pattern kept symmetric;
+    # scaling by a power of two times three is not exact, so the refilled plan is compared with the oracle's y on
+    # the new values, which for V' = -3 V is -3 y_ref up to the rounding of the products
+    plan.set_values(-3.0 * c.m.V)
+    y3 = plan.spmv_host(c.xp)
+    bad, worst = O.check_tolerance(c.recover(y3), -3.0 * c.y_ref, 3.0 * c.scale)
+    assert bad == 0, f"after the refill: worst {worst:.3e}"
+    plan.set_values(c.m.V)                       # and back: the original product again
+    assert c.check(plan.spmv_host(c.xp))[0] == 0
