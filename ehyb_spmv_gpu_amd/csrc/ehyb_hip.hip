@@ -139,6 +139,7 @@ struct EllArgs {
     double* __restrict__ y;
     int win_cap;
     int xcd_map;  // 1: workgroup b takes item xcd_item(b), so that each XCD works on one contiguous run of items
+    int windowless_zero;  // 1: a partition without a window gets y = 0 here; 0: the panel residual's second pass assigns its y
     unsigned long long* __restrict__ stamps;
 };
 
@@ -275,6 +276,7 @@ __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict
         // a partition whose rows all went to the residual (its window did not pay, plan.cpp): nothing to
         // stage, no slab to walk -- the residual launch adds to y, so y = 0 in one coalesced sweep
         // (walking its empty slabs cost 22 us on R-MAT 2^22, 70 us on 2^24)
+        if (!A.windowless_zero) return;  // pb_assign: pass 2 of the panel residual is the only writer of these rows
         const int r0 = max(ps, (int)A.slab_meta[sb].z), r1 = min(pe, r0 + (se - sb) * 64);
         for (int i = r0 + (int)threadIdx.x; i < r1; i += THREADS) A.y[i] = 0.0;
         return;
@@ -486,9 +488,10 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
 }
 
 // Pass 2: one workgroup per unit {first partial, end partial, first row, rows}.  The row block's
-// accumulators live in LDS; (partial, 16-bit local row) are streamed, equal neighbouring rows summed
-// across lanes first, then one ds_add_f64 per run; finally y[row] += accumulator for the rows that
-// received something (the ELL launch has written y before).
+// accumulators live in LDS; (partial, 16-bit local row) are streamed and added (ds_add_f64); finally
+// y[row] += accumulator for the rows that received something (the ELL launch has written y before) -- or,
+// for a block of rows whose partitions have no window (rows < 0 in the unit), y[row] = accumulator for
+// every row: the ELL launch leaves those rows alone.
 template <int THREADS>
 __global__ __launch_bounds__(THREADS) void ehyb_pb_reduce_kernel(const int4* __restrict__ units,
                                                                  const double* __restrict__ partial,
@@ -497,7 +500,9 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_reduce_kernel(const int4* __r
 {
     // probe (timing diagnostics only): 16 no lane sums, 32 no LDS adds, 64 no write-back, 128 no zeroing
     extern __shared__ __attribute__((aligned(16))) double yacc[];
-    const int4 u = units[blockIdx.x];
+    int4 u = units[blockIdx.x];
+    const bool assign = u.w < 0;  // the block is the only writer of its rows (partitions without a window): y = sum, zeros included
+    u.w = assign ? -u.w : u.w;
     if (!(probe & 128))
         for (int i = threadIdx.x; i < u.w; i += THREADS) yacc[i] = 0.0;
     __syncthreads();
@@ -524,6 +529,10 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_reduce_kernel(const int4* __r
     // y[row] += accumulator for the rows that received something: the loads of a batch first, then the stores
     double* __restrict__ yp = y + u.z;
     if (probe & 64) return;
+    if (assign) {
+        for (int i = threadIdx.x; i < u.w; i += THREADS) yp[i] = yacc[i];
+        return;
+    }
     for (int i0 = 0; i0 < u.w; i0 += K * THREADS) {
         double a[K], yo[K];
 #pragma unroll
@@ -578,6 +587,7 @@ static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long 
     // on by default: plain storage 143 -> 134 us on the audikw_1-like matrix; EHYB_XCD_MAP=0 for the A/B
     static const int xcd_env = [] { const char* e = getenv("EHYB_XCD_MAP"); return e ? atoi(e) : 1; }();
     A.xcd_map = P->host.sym ? 0 : xcd_env;  // symmetric pairs: items are sorted heaviest first, dispatched in that order
+    A.windowless_zero = P->host.pb_assign ? 0 : 1;
     return A;
 }
 

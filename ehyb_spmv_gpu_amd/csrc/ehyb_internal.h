@@ -123,7 +123,12 @@ struct HostLayout {
     std::vector<uint32_t> pb_dst;     // partial slot; 0xFFFFFFFF = padding
     std::vector<int32_t> pb_units1;   // {first column, columns, first entry, end entry}
     std::vector<uint16_t> pb_row;     // per partial: row - first row of its block
-    std::vector<int32_t> pb_units2;   // {first partial, end partial, first row, rows}
+    std::vector<int32_t> pb_units2;   // {first partial, end partial, first row, rows}; rows < 0: the block ASSIGNS y (-rows rows)
+    // Partitions that went to the residual whole (their window did not pay, plan.cpp) have no ELL work at all:
+    // with pb_assign their rows get y from pass 2 alone (row blocks that assign instead of add, also where no
+    // partial arrives), the ELL launch skips them, and their slabs cost its work items nothing.
+    bool pb_assign = false;
+    std::vector<uint8_t> part_windowless;  // [n_parts] host only
     // what pass 1 streams in place of pb_col + pb_dst (derived from them by encode_panel_slots, not stored in plan files)
     std::vector<uint16_t> pb_colf;    // column | head flag (bit 15) | jump flag (bit 14)
     std::vector<uint32_t> pb_chunk;   // per 64-entry chunk: its first jump

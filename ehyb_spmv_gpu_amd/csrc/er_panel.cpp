@@ -135,13 +135,20 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     const int64_t target = std::min<int64_t>(std::max<int64_t>(nnz_er / (env_u2 > 0 ? env_u2 : 2048), 4096), 1 << 20);
     std::vector<int32_t> rb_first;  // first row (plan numbering) of every block, + end
     std::vector<int32_t> rb_of_row((size_t)nrows);
+    // pb_assign: rows of partitions without a window get y from pass 2 alone, so a block never mixes them with
+    // rows the ELL launch writes
+    std::vector<uint8_t> row_assign(L->pb_assign ? (size_t)nrows : 0, 0);
+    if (L->pb_assign)
+        for (int p = 0; p < L->n_parts; ++p)
+            if (L->part_windowless[p])
+                std::fill(row_assign.begin() + (L->part_boundary[p] - row_begin), row_assign.begin() + (L->part_boundary[p + 1] - row_begin), (uint8_t)1);
     {
         int64_t acc = 0;
         int first = 0;
         rb_first.push_back(row_begin);
         for (int r = 0; r < nrows; ++r) {
             // close the block in front of this row if taking it would overshoot
-            if (r > first && (acc + cnt_row[r] > target || r - first >= rows_max)) {
+            if (r > first && (acc + cnt_row[r] > target || r - first >= rows_max || (L->pb_assign && row_assign[r] != row_assign[r - 1]))) {
                 rb_first.push_back(row_begin + r);
                 first = r;
                 acc = 0;
@@ -249,16 +256,20 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
             L->pb_units1.insert(L->pb_units1.end(), u, u + 4);
             staged += u[1];
         }
-    // pass 2: {first slot, end slot, first row, rows}; blocks without partials are skipped
+    // pass 2: {first slot, end slot, first row, rows}; blocks without partials are skipped -- unless the block
+    // ASSIGNS y (rows stored negative): then it is the only writer of its rows
     L->pb_units2.clear();
     int max_rows = 0;
-    int64_t rows_touched = 0;
+    int64_t rows_touched = 0, rows_assigned = 0;
     for (int b = 0; b < n_rb; ++b) {
-        if (rb_count[b + 1] == rb_count[b]) continue;
-        const int32_t u[4] = {(int32_t)rb_count[b], (int32_t)rb_count[b + 1], rb_first[b], rb_first[b + 1] - rb_first[b]};
+        const bool assign = L->pb_assign && row_assign[(size_t)(rb_first[b] - row_begin)] != 0;
+        if (rb_count[b + 1] == rb_count[b] && !assign) continue;
+        const int rows = rb_first[b + 1] - rb_first[b];
+        const int32_t u[4] = {(int32_t)rb_count[b], (int32_t)rb_count[b + 1], rb_first[b], assign ? -rows : rows};
         L->pb_units2.insert(L->pb_units2.end(), u, u + 4);
-        max_rows = std::max(max_rows, u[3]);
-        rows_touched += u[3];
+        max_rows = std::max(max_rows, rows);
+        rows_touched += rows;
+        rows_assigned += assign ? rows : 0;
     }
     L->pb_panel_cols = W;
     L->pb_rows_max = max_rows;
@@ -268,7 +279,7 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     // partials (value, row) in + the touched y rows read and written
     encode_panel_slots(L);
     // (value, column+flags) + chunk records + jump list instead of a 4-byte slot per entry
-    L->pb_bytes = 10 * padded + 4 * (padded / 64 + 1) + 4 * (int64_t)L->pb_jump.size() + 8 * staged + 8 * n_pieces + 10 * n_pieces + 16 * L->stats.rows_er +
+    L->pb_bytes = 10 * padded + 4 * (padded / 64 + 1) + 4 * (int64_t)L->pb_jump.size() + 8 * staged + 8 * n_pieces + 10 * n_pieces + (L->pb_assign ? 8 * rows_assigned + 16 * std::max<int64_t>(0, L->stats.rows_er - rows_assigned) : 16 * L->stats.rows_er) +
                   16 * (int64_t)(L->pb_units1.size() / 4 + L->pb_units2.size() / 4);
     if (cfg.verbose)
         printf("panel residual: %lld entries (%lld with padding) in %d panels of %d columns -> %lld partials, %zu + %zu work units, "

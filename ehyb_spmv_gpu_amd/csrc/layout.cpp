@@ -269,6 +269,13 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     std::vector<int32_t> row_at(nrows), slot_of(nrows);
     const bool share = cfg.col_sharing != 2;
     L->win_len.assign(np, 0);
+    L->part_windowless.assign(np, 0);
+    // Called with partitions to give up (plan.cpp, after a first build that ended in the panel form): the panel
+    // form is kept for this build too, and the rows of those partitions get their y from its second pass alone
+    bool any_windowless = false;
+    if (part_to_er && !sym)
+        for (uint8_t f : *part_to_er) any_windowless |= f != 0;
+    const bool assign_mode = any_windowless && !direct && cfg.er_mode != 1;
     int bad_col = 0, bad_row = 0;
 #pragma omp parallel
     {
@@ -325,6 +332,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 }
             }
             L->win_len[p] = wlen;
+            L->part_windowless[p] = whole_to_er ? 1 : 0;
             const int nslab = (own + kSlabRows - 1) / kSlabRows;
             S.slab_w2.assign(nslab, 0);
             for (int r = s; r < e; ++r) {
@@ -686,6 +694,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         auto slab_cost = [&](int64_t sidx) {
             const int64_t pairs = L->slab_pair_ptr[sidx + 1] - L->slab_pair_ptr[sidx];
             const int64_t words = L->slab_col_ptr[sidx + 1] - L->slab_col_ptr[sidx];
+            if (assign_mode && L->part_windowless[L->slab_part[sidx]]) return (int64_t)0;  // the ELL launch skips it
             return pairs * (kSlabRows * 16) + words * 4 + 1024;
         };
         // Work items: the global slab sequence cut into `want` = items_per_cu x 256 runs of equal cost
@@ -848,8 +857,9 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     // the kernel streams at 5.3 TB/s; where they do not (R-MAT) every entry is its own L2 request and the
     // panel form wins.  Locality is read off the residual itself: distinct 128-byte
     // lines of x per entry over windows of 1024 consecutive residual entries.
-    bool want_panel = cfg.er_mode == 2;
-    if (cfg.er_mode == 0 && !L->inline_er && !direct && nnz_er >= (1 << 21)) {
+    bool want_panel = cfg.er_mode == 2 || assign_mode;
+    L->pb_assign = false;
+    if (cfg.er_mode == 0 && !assign_mode && !L->inline_er && !direct && nnz_er >= (1 << 21)) {
         const int64_t win = 1024, nwin = std::min<int64_t>(64, nnz_er / win);
         int64_t lines = 0;
         std::vector<int32_t> tmp((size_t)win);
@@ -863,9 +873,12 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         if (cfg.verbose) printf("residual locality: %.3f distinct x lines per entry -> %s form\n", (double)lines / (double)(nwin * win), want_panel ? "panel" : "CSR");
     }
     if (!L->inline_er && !direct && nnz_er > 0 && want_panel) {
+        L->pb_assign = assign_mode;
         const int rc_pb = build_panel_residual(cfg, L);
         if (rc_pb != EHYB_OK) return rc_pb;
+        if (!L->er_panel) L->pb_assign = false;
     }
+    if (assign_mode && !L->pb_assign) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: partitions were given up but the residual did not end in panel form");
     // ---- statistics (convert.c:140,310; spmv.cu:82)
     st.nnz = nnz;
     st.nnz_ell = nnz_ell;

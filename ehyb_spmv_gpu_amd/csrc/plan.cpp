@@ -112,7 +112,7 @@ int ehyb_plan_create_host(const matrixCOO* m, int row_begin, int row_end, const 
                 if (P->cfg.verbose) printf("%lld ELL entries sit in windows that cost more than the panel residual: rebuilt with those partitions in the residual\n", (long long)moved);
                 HostLayout again;
                 rc = build_layout(m, row_begin, row_end, P->cfg, &again, &to_er);
-                if (rc == EHYB_OK) P->host = std::move(again);
+                if (rc == EHYB_OK && again.er_panel) P->host = std::move(again);
             }
         }
     } catch (const std::bad_alloc&) {

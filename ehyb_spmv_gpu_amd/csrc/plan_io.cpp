@@ -17,7 +17,7 @@ using namespace ehyb;
 
 namespace {
 
-const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '7'};
+const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '8'};
 const char kEnd[8] = {'E', 'H', 'Y', 'B', 'E', 'N', 'D', '4'};
 
 struct FileCloser {
@@ -71,6 +71,7 @@ struct Scalars {
     int32_t sym, yacc_doubles;
     int32_t er_panel, pb_panel_cols, pb_rows_max, direct;
     int64_t pb_partials, pb_bytes;
+    int32_t pb_assign, reserved;
 };
 
 // The panel residual's arrays must fit together as the two kernels index them.
@@ -90,7 +91,9 @@ bool panel_consistent(const HostLayout& H)
     }
     for (size_t u = 0; u < H.pb_units2.size(); u += 4) {
         const int32_t* q = &H.pb_units2[u];
-        if (q[0] < 0 || q[1] < q[0] || q[1] > H.pb_partials || q[2] < H.row_begin || q[3] < 1 || q[3] > H.pb_rows_max || q[2] + q[3] > H.row_end) return false;
+        const int32_t rows = q[3] < 0 ? -q[3] : q[3];  // negative: the block assigns y (pb_assign)
+        if (q[0] < 0 || q[1] < q[0] || q[1] > H.pb_partials || q[2] < H.row_begin || rows < 1 || rows > H.pb_rows_max || q[2] + rows > H.row_end) return false;
+        if (q[3] < 0 && !H.pb_assign) return false;
     }
     for (uint32_t d : H.pb_dst)
         if (d != 0xFFFFFFFFu && d >= (uint64_t)H.pb_partials) return false;
@@ -136,7 +139,7 @@ int ehyb_plan_save(const ehyb_plan* plan, const int* reorder_list, uint64_t matr
     File f(fopen(path, "wb"));
     if (!f) EHYB_FAIL(EHYB_ERR_IO, "ehyb_plan_save: cannot create %s", path);
     Scalars s{H.n_cols, H.row_begin, H.row_end, H.n_parts, H.lds_doubles, H.inline_er ? 1 : 0, {0}, H.sym ? 1 : 0, H.yacc_doubles,
-              H.er_panel ? 1 : 0, H.pb_panel_cols, H.pb_rows_max, H.direct ? 1 : 0, H.pb_partials, H.pb_bytes};
+              H.er_panel ? 1 : 0, H.pb_panel_cols, H.pb_rows_max, H.direct ? 1 : 0, H.pb_partials, H.pb_bytes, H.pb_assign ? 1 : 0, 0};
     memcpy(s.er_bins, H.er_bins, sizeof s.er_bins);
     std::vector<int32_t> perm;
     if (reorder_list) perm.assign(reorder_list, reorder_list + H.n_cols);
@@ -186,6 +189,7 @@ int ehyb_plan_load(const char* path, uint64_t expect_key, ehyb_plan** plan, int*
     H.sym = s.sym != 0, H.yacc_doubles = s.yacc_doubles;
     H.er_panel = s.er_panel != 0, H.pb_panel_cols = s.pb_panel_cols, H.pb_rows_max = s.pb_rows_max, H.direct = s.direct != 0;
     H.pb_partials = s.pb_partials, H.pb_bytes = s.pb_bytes;
+    H.pb_assign = s.pb_assign != 0 && H.er_panel;
     memcpy(H.er_bins, s.er_bins, sizeof s.er_bins);
     // the sizes the kernels rely on must fit together -- a damaged file must not reach the GPU
     const size_t nslab = H.slab_row.size(), nseg = H.er_seg_row.size();

@@ -350,7 +350,9 @@ int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int
 int ehyb_spmv(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream);
 
 /* phase 1: ELL part only (needs only window columns);  phase 2: residual only
- * (y += ...);  phase 0: both.  Lets a multi-GPU caller overlap the x exchange. */
+ * (y += ...);  phase 0: both.  Lets a multi-GPU caller overlap the x exchange.
+ * Phase 2 must follow phase 1 on the same stream before y is read: where partitions were given up to a
+ * panel-form residual (their windows did not pay), phase 1 leaves their rows alone and phase 2 ASSIGNS them. */
 int ehyb_spmv_phase(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream, int phase);
 
 /*

@@ -181,6 +181,10 @@ def walk_plan(plan, x):
     assert sym or plan.stats["sym_pairs"] == 0
     y_mirror = np.zeros(n)
     next_seg, next_slab = 0, 0
+    # panel residual whose second pass ASSIGNS the rows of partitions without a window (units with rows < 0):
+    # the ELL launch skips those partitions, pass 2 is the only writer of their rows
+    u2_all = plan.array("pb_units2").reshape(-1, 4)
+    pb_assign = plan.stats["er_partials"] > 0 and bool(np.any(u2_all[:, 3] < 0))
     for g0, g1, is0, is1, e0, e64, e16, e1 in items:
         # an item = consecutive segments covering the consecutive slabs [is0, is1); items follow each other
         # in slab order -- except with symmetric pairs, where an item is a partition and the items are
@@ -207,6 +211,10 @@ def walk_plan(plan, x):
             assert (ps, pe, wl, hb, hn) == (int(pb[p]), int(pb[p + 1]), int(win_len[p]), int(halo_ptr[p]), int(halo_ptr[p + 1] - halo_ptr[p]))
             base = ps & ~1  # the LDS image starts at the even row at or below the partition start
             win = np.concatenate([x[base:ps + wl], x[halo_cols[hb:hb + hn]]])
+            if pb_assign and wl == 0 and hn == 0:
+                # ehyb_ell_kernel returns at once for such a segment: nothing stored, nothing written
+                assert not np.any(meta[s0:s1, 3] >> 8), "a partition without a window holds ELL or inline entries"
+                continue
             for s in range(s0, s1):
                 # record word 3: ELL pairs << 16 | inline residual pairs << 8 | column groups - 1
                 npairs, ner, G = int(meta[s, 3] >> 16), int(meta[s, 3] >> 8) & 0xFF, int(meta[s, 3] & 0x3F) + 1
@@ -286,7 +294,7 @@ def walk_plan(plan, x):
         np.add.at(y_csr, np.repeat(seg_row & 0x7FFFFFFF, np.diff(seg_ptr)), er_val * x[er_col])
     if plan.stats["er_partials"] > 0:
         # panel form of the residual, walked as ehyb_pb_scale_kernel / ehyb_pb_reduce_kernel index it
-        y_pb = walk_panel_residual(plan, x)
+        y_pb = walk_panel_residual(plan, x, written)
         tol = 1e-12 * (np.abs(er_val * x[er_col]).sum() / max(1, len(seg_row)) + np.abs(y_csr).max() + 1e-300)
         assert np.allclose(y_pb, y_csr, rtol=0, atol=tol), "panel form and CSR segments of the residual disagree"
         y += y_pb
@@ -314,7 +322,7 @@ def decode_panel_slots(colf, chunk, jump):
     return (colf & 0x3FFF).reshape(-1), slot.reshape(-1)
 
 
-def walk_panel_residual(plan, x):
+def walk_panel_residual(plan, x, written=None):
     """y contribution of the residual in panel form (include/ehyb.h EHYB_ARR_PB_*): pass 1 per unit
     {first column, columns, first entry, end entry} multiplies with the unit's x panel and sums the
     entries of every slot; pass 2 per unit {first partial, end partial, first row, rows} adds the
@@ -354,7 +362,16 @@ def walk_panel_residual(plan, x):
     seen = np.zeros(P, dtype=np.int32)
     rows_seen = np.zeros(n, dtype=np.int32)
     for pb, pe, r0, nr in u2:
-        assert pe > pb and prow[pb:pe].max() < nr
+        if nr < 0:
+            # the block assigns: it is the only writer of its rows (their partitions have no window), also
+            # where no partial arrives
+            nr = -nr
+            assert pe >= pb
+            if written is not None:
+                written[r0:r0 + nr] += 1
+        else:
+            assert pe > pb
+        assert pe == pb or prow[pb:pe].max() < nr
         np.add.at(y, r0 + prow[pb:pe], partial[pb:pe])
         seen[pb:pe] += 1
         rows_seen[r0:r0 + nr] += 1

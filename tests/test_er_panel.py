@@ -32,7 +32,7 @@ def test_panel_form_walks_to_the_reference_product(E, O, name, kind, args, kw):
     u1 = plan.array("pb_units1").reshape(-1, 4)
     u2 = plan.array("pb_units2").reshape(-1, 4)
     assert np.all(u1[:, 1] <= cfg.er_panel_cols) and np.all(u1[:, 0] % cfg.er_panel_cols == 0)
-    assert np.all(u2[:, 3] <= cfg.er_block_rows)
+    assert np.all(np.abs(u2[:, 3]) <= cfg.er_block_rows)   # (negative: a block that assigns y, pb_assign)
     # bytes: both passes streamed -- entries at 10 B (value, column word with the two slot flags) plus the jump
     # list, partials at 18 B, plus panels and y; the jump list holds at most one slot per partial
     er_bytes = st["bytes_format"] - st["bytes_format_ell"]
@@ -113,3 +113,34 @@ def test_windows_that_do_not_pay_go_to_the_residual(E, O):
             assert hn == 0 and not (meta[s0:s1, 3] >> 16).any()
     y, written = O.walk_plan(pruned, c.xp)
     assert written[:c.n].min() == 1 and c.check(y)[0] == 0
+
+
+@pytest.mark.parametrize("kw,mixed", [(dict(er_mode=2, lds_doubles=4096), True), (dict(er_mode=2), False)], ids=["some_windows_kept", "no_window_kept"])
+def test_rows_of_partitions_without_a_window_are_assigned_by_pass_2(E, O, kw, mixed):
+    """A partition whose window does not pay goes to the panel residual whole (plan.cpp).  Its rows then get y from
+    pass 2 alone: row blocks that ASSIGN (rows stored negative), present also where no partial arrives; the ELL
+    launch skips the partition and its slabs cost the work items nothing.  No block mixes both kinds of rows."""
+    cfg = E.make_config(partitioner=E.EHYB_PART_CONTIGUOUS, **kw)
+    c = Case(E, O, "rmat", (18, 1 << 21, 1), cfg)
+    plan = E.Plan(c.m, cfg, upload=False)
+    st = plan.stats
+    wl, pb = plan.array("win_len"), plan.array("part_boundary")
+    u2 = plan.array("pb_units2").reshape(-1, 4)
+    windowless = wl == 0
+    assert windowless.any() and (not windowless.all()) == mixed and st["er_partials"] > 0
+    row_kind = np.repeat(windowless, np.diff(pb))                     # per row: its partition has no window
+    for first, end, r0, rows in u2:
+        kinds = row_kind[r0:r0 + abs(rows)]
+        assert np.all(kinds == (rows < 0)), "a row block mixes assigned and accumulated rows"
+    covered = np.zeros(c.n, dtype=int)
+    for first, end, r0, rows in u2[u2[:, 3] < 0]:
+        covered[r0:r0 - rows] += 1
+    assert np.array_equal(covered == 1, row_kind), "every row without a window belongs to exactly one assigning block"
+    y, written = O.walk_plan(plan, c.xp)
+    assert written[:c.n].min() == 1 and written[:c.n].max() == 1
+    assert c.check(y)[0] == 0
+    # the work items carry the kept windows only
+    if mixed:
+        assert st["n_items"] > 1
+    else:
+        assert st["nnz_ell"] == 0 and st["n_items"] == 1

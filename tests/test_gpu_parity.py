@@ -185,3 +185,23 @@ def test_direct_shape(E, O, gpu, name, kind, args):
         plan.spmv(dx.ptr, dy.ptr, phase=1)
     y1, it = E.spmv_gpu_ehyb(c.m, c.xp, 3)
     assert it == 3 and c.check(y1)[0] == 0
+
+
+@pytest.mark.parametrize("kw", [dict(er_mode=2, lds_doubles=4096), dict(er_mode=2)], ids=["some_windows_kept", "no_window_kept"])
+def test_pass_2_assigns_rows_of_partitions_without_a_window(E, O, gpu, kw):
+    """Pruned windows (plan.cpp): the ELL launch skips those partitions and pass 2 of the panel residual is the
+    only writer of their rows -- y is filled with NaN before every multiply, so a row nobody writes shows."""
+    cfg = E.make_config(partitioner=E.EHYB_PART_CONTIGUOUS, **kw)
+    c = Case(E, O, "rmat", (18, 1 << 21, 1), cfg)
+    plan = E.Plan(c.m, cfg)
+    u2 = plan.array("pb_units2").reshape(-1, 4)
+    assert np.any(u2[:, 3] < 0)
+    dx, dy = E.DeviceBuffer(c.n).upload(c.xp), E.DeviceBuffer(c.n)
+    for phases in ((0,), (1, 2), (0,)):
+        dy.upload(np.full(c.n, np.nan))
+        for ph in phases:
+            plan.spmv(dx.ptr, dy.ptr, phase=ph)
+        y = dy.download()
+        assert np.isfinite(y).all(), f"{int(np.isnan(y).sum())} rows were never written (phases {phases})"
+        bad, worst = c.check(y)
+        assert bad == 0, f"phases {phases}: worst {worst:.3e}"
