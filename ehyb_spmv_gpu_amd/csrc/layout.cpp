@@ -749,20 +749,41 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         L->items.clear();
         L->segs.clear();
         int64_t window_loads = 0;
+        // assign_mode: partitions without a window have no segment at all (the kernel would only walk past them:
+        // 1400 such records in one item cost R-MAT 2^24 70 us); a cut range left without a segment joins the item
+        // before it (the first ones: the item after them), so the items still tile the slab sequence
+        int64_t carry_lo = -1;
         for (size_t i = 0; i < cut_lo.size(); ++i) {
-            const int32_t item = (int32_t)i;
+            const int32_t item = (int32_t)(L->items.size() / 8);
             const int32_t seg_begin = (int32_t)(L->segs.size() / 8);
             for (int64_t c = cut_lo[i]; c < cut_hi[i];) {
                 const int p = L->slab_part[c];
                 const int64_t e = std::min<int64_t>(cut_hi[i], slab_base[p + 1]);
-                const int32_t hb = L->halo_ptr[p], hn = L->halo_ptr[p + 1] - L->halo_ptr[p];
-                const int32_t seg[8] = {p, (int32_t)c, (int32_t)e, hn, pb[p], pb[p + 1], L->win_len[p], hb};
-                L->segs.insert(L->segs.end(), seg, seg + 8);
-                window_loads += L->win_len[p] + hn;
-                for (int64_t t = c; t < e; ++t) item_of_slab[t] = item;
+                if (!(assign_mode && L->part_windowless[p])) {
+                    const int32_t hb = L->halo_ptr[p], hn = L->halo_ptr[p + 1] - L->halo_ptr[p];
+                    const int32_t seg[8] = {p, (int32_t)c, (int32_t)e, hn, pb[p], pb[p + 1], L->win_len[p], hb};
+                    L->segs.insert(L->segs.end(), seg, seg + 8);
+                    window_loads += L->win_len[p] + hn;
+                }
                 c = e;
             }
-            const int32_t rec[8] = {seg_begin, (int32_t)(L->segs.size() / 8), (int32_t)cut_lo[i], (int32_t)cut_hi[i], 0, 0, 0, 0};
+            const bool empty = (int32_t)(L->segs.size() / 8) == seg_begin;
+            if (assign_mode && empty) {
+                if (!L->items.empty()) {
+                    L->items[L->items.size() - 8 + 3] = (int32_t)cut_hi[i];  // the item before takes these slabs
+                    for (int64_t t = cut_lo[i]; t < cut_hi[i]; ++t) item_of_slab[t] = item - 1;
+                    continue;
+                }
+                if (i + 1 < cut_lo.size()) {
+                    if (carry_lo < 0) carry_lo = cut_lo[i];
+                    continue;
+                }
+                // no partition has a window: one item without segments (the launch does nothing)
+            }
+            const int64_t lo = carry_lo >= 0 ? carry_lo : cut_lo[i];
+            carry_lo = -1;
+            for (int64_t t = lo; t < cut_hi[i]; ++t) item_of_slab[t] = item;
+            const int32_t rec[8] = {seg_begin, (int32_t)(L->segs.size() / 8), (int32_t)lo, (int32_t)cut_hi[i], 0, 0, 0, 0};
             L->items.insert(L->items.end(), rec, rec + 8);
         }
         L->stats.window_loads = window_loads;

@@ -189,8 +189,17 @@ def walk_plan(plan, x):
         # an item = consecutive segments covering the consecutive slabs [is0, is1); items follow each other
         # in slab order -- except with symmetric pairs, where an item is a partition and the items are
         # sorted heaviest first (every slab still belongs to exactly one item: `written` checks it)
-        assert g0 == next_seg and g1 > g0 and is1 > is0 and (sym or is0 == next_slab)
-        assert segs[g0, 1] == is0 and segs[g1 - 1, 2] == is1
+        assert g0 == next_seg and (g1 > g0 or pb_assign) and is1 > is0 and (sym or is0 == next_slab)
+        if pb_assign:
+            # partitions without a window have no segment: the item's segments lie inside its slab range, in
+            # order, and every slab of the range that no segment covers belongs to such a partition
+            cov = np.zeros(is1 - is0, dtype=bool)
+            for g in range(g0, g1):
+                assert is0 <= segs[g, 1] < segs[g, 2] <= is1 and (g == g0 or segs[g, 1] >= segs[g - 1, 2])
+                cov[segs[g, 1] - is0:segs[g, 2] - is0] = True
+            assert np.all(win_len[slab_part[is0:is1][~cov]] == 0) and np.all(win_len[slab_part[is0:is1][cov]] > 0)
+        else:
+            assert segs[g0, 1] == is0 and segs[g1 - 1, 2] == is1
         next_seg, next_slab = g1, is1
         # the item's residual segments: rows inside the item's slab range, bins by length
         assert e0 <= e64 <= e16 <= e1
@@ -199,22 +208,19 @@ def walk_plan(plan, x):
             assert np.all(lens[:e64 - e0] >= 128) and np.all((lens[e64 - e0:e16 - e0] > 16) & (lens[e64 - e0:e16 - e0] < 128))
             assert np.all(lens[e16 - e0:] <= 16) and np.all(lens >= 0)
             rows = seg_row[e0:e1] & 0x7FFFFFFF
-            last_p = segs[g1 - 1, 0]
+            last_p = slab_part[is1 - 1]   # (= the partition of the item's last segment, where it has segments)
             assert rows.min() >= slab_row[is0] and rows.max() < min(int(slab_row[is1 - 1]) + 64, int(pb[last_p + 1]))
             seg_done[e0:e1] += 1
         for g in range(g0, g1):
             p, s0, s1, hn, ps, pe, wl, hb = (int(v) for v in segs[g])
             if g > g0:
-                assert s0 == segs[g - 1, 2] and p > segs[g - 1, 0], "segments of an item are consecutive and cut at partition boundaries"
+                assert (s0 == segs[g - 1, 2] or pb_assign) and p > segs[g - 1, 0], "segments of an item are consecutive and cut at partition boundaries"
             assert np.all(slab_part[s0:s1] == p) and s1 > s0
             # the partition scalars carried by the segment record are the partition arrays' values
             assert (ps, pe, wl, hb, hn) == (int(pb[p]), int(pb[p + 1]), int(win_len[p]), int(halo_ptr[p]), int(halo_ptr[p + 1] - halo_ptr[p]))
             base = ps & ~1  # the LDS image starts at the even row at or below the partition start
             win = np.concatenate([x[base:ps + wl], x[halo_cols[hb:hb + hn]]])
-            if pb_assign and wl == 0 and hn == 0:
-                # ehyb_ell_kernel returns at once for such a segment: nothing stored, nothing written
-                assert not np.any(meta[s0:s1, 3] >> 8), "a partition without a window holds ELL or inline entries"
-                continue
+            assert not (pb_assign and wl == 0 and hn == 0), "a partition without a window has a segment"
             for s in range(s0, s1):
                 # record word 3: ELL pairs << 16 | inline residual pairs << 8 | column groups - 1
                 npairs, ner, G = int(meta[s, 3] >> 16), int(meta[s, 3] >> 8) & 0xFF, int(meta[s, 3] & 0x3F) + 1
