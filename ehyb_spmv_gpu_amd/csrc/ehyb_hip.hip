@@ -599,6 +599,7 @@ static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t
     const HostLayout& H = P->host;
     const int n_items = (int)(H.items.size() / 8);
     if (n_items == 0 || H.direct) return EHYB_OK;  // direct shape: the row-segment kernel does everything
+    if (H.pb_assign && H.segs.empty()) return EHYB_OK;  // no partition kept its window: pass 2 of the panel residual assigns every row
     const size_t lds = ell_lds_bytes(H);
     const bool dyn = P->cfg.ell_variant != 3;
     const EllArgs A = ell_args(P, x, y, stamps);

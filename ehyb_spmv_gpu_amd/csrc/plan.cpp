@@ -40,7 +40,7 @@ int windows_that_do_not_pay(const HostLayout& H, std::vector<uint8_t>* to_er, in
         if (entries == 0) continue;
         const int64_t halo = H.halo_ptr[p + 1] - H.halo_ptr[p];
         const int64_t window = 8 * stored[p] + 4 * words[p] + 8 * (int64_t)H.win_len[p] + 64 * halo;
-        static const int64_t pct = [] { const char* e = getenv("EHYB_PRUNE_PCT"); return e ? atoll(e) : 110ll; }();  // tuning sweeps only
+        const int64_t pct = [] { const char* e = getenv("EHYB_PRUNE_PCT"); return e ? atoll(e) : 110ll; }();  // tuning sweeps only
         if (window * 100 > 30 * entries * pct) {  // more than 10 % dearer than the panel form
             (*to_er)[p] = 1;
             ++count;
@@ -109,6 +109,17 @@ int ehyb_plan_create_host(const matrixCOO* m, int row_begin, int row_end, const 
             std::vector<uint8_t> to_er;
             int64_t moved = 0;
             if (windows_that_do_not_pay(P->host, &to_er, &moved) > 0) {
+                // The windows that are left must carry the ELL launch: its staging of 160 KiB windows with thousands
+                // of gathered halo columns, for a few partitions on a few CUs, is a fixed cost.  Measured on R-MAT
+                // (tools/panel_sweep.py --prune-pct): 2^22 with 18 % of the entries left in windows 216 us, with none
+                // 194 us; 2^24 with 8 % left 859 us, with none 859 us; partial pruning in between was never better
+                // than either end.  Below a quarter of the entries the rest goes to the panel form as well.
+                const int64_t kept = P->host.stats.nnz_ell - moved;
+                if (kept * 4 < P->host.stats.nnz) {
+                    for (int p = 0; p < P->host.n_parts; ++p)
+                        if (P->host.part_nnz_ell[p] > 0) to_er[(size_t)p] = 1;
+                    moved = P->host.stats.nnz_ell;
+                }
                 if (P->cfg.verbose) printf("%lld ELL entries sit in windows that cost more than the panel residual: rebuilt with those partitions in the residual\n", (long long)moved);
                 HostLayout again;
                 rc = build_layout(m, row_begin, row_end, P->cfg, &again, &to_er);

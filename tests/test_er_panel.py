@@ -5,7 +5,7 @@ the same residual and against the reference CPU product."""
 import numpy as np
 import pytest
 
-from util import Case
+from util import Case, fem_plus_rmat
 
 CASES = [
     ("rmat_s14", "rmat", (14, 1 << 17, 1), dict(lds_doubles=512, er_panel_cols=512, er_block_rows=300)),
@@ -115,13 +115,17 @@ def test_windows_that_do_not_pay_go_to_the_residual(E, O):
     assert written[:c.n].min() == 1 and c.check(y)[0] == 0
 
 
-@pytest.mark.parametrize("kw,mixed", [(dict(er_mode=2, lds_doubles=4096), True), (dict(er_mode=2), False)], ids=["some_windows_kept", "no_window_kept"])
-def test_rows_of_partitions_without_a_window_are_assigned_by_pass_2(E, O, kw, mixed):
-    """A partition whose window does not pay goes to the panel residual whole (plan.cpp).  Its rows then get y from
-    pass 2 alone: row blocks that ASSIGN (rows stored negative), present also where no partial arrives; the ELL
-    launch skips the partition and its slabs cost the work items nothing.  No block mixes both kinds of rows."""
-    cfg = E.make_config(partitioner=E.EHYB_PART_CONTIGUOUS, **kw)
-    c = Case(E, O, "rmat", (18, 1 << 21, 1), cfg)
+@pytest.mark.parametrize("mixed", [True, False], ids=["some_windows_kept", "no_window_kept"])
+def test_rows_of_partitions_without_a_window_are_assigned_by_pass_2(E, O, mixed):
+    """A partition whose window does not pay goes to the panel residual whole (plan.cpp); where less than a quarter
+    of the entries would be left in windows, all of them go.  The rows of such partitions get y from pass 2 alone:
+    row blocks that ASSIGN (rows stored negative), present also where no partial arrives; the ELL launch has no
+    segment for them and its work items carry the kept windows only.  No block mixes both kinds of rows."""
+    cfg = E.make_config(partitioner=E.EHYB_PART_CONTIGUOUS, er_mode=2, lds_doubles=4096)
+    if mixed:
+        c = Case(E, O, None, None, cfg, matrix=fem_plus_rmat(E, cfg))
+    else:
+        c = Case(E, O, "rmat", (18, 1 << 21, 1), cfg)   # a fifth of the entries in windows that pay: all given up
     plan = E.Plan(c.m, cfg, upload=False)
     st = plan.stats
     wl, pb = plan.array("win_len"), plan.array("part_boundary")
@@ -139,8 +143,8 @@ def test_rows_of_partitions_without_a_window_are_assigned_by_pass_2(E, O, kw, mi
     y, written = O.walk_plan(plan, c.xp)
     assert written[:c.n].min() == 1 and written[:c.n].max() == 1
     assert c.check(y)[0] == 0
-    # the work items carry the kept windows only
+    segs = plan.array("segs").reshape(-1, 8)
     if mixed:
-        assert st["n_items"] > 1
+        assert st["n_items"] > 1 and len(segs) > 0 and np.all(wl[segs[:, 0]] > 0) and st["nnz_ell"] * 4 >= st["nnz"]
     else:
-        assert st["nnz_ell"] == 0 and st["n_items"] == 1
+        assert st["nnz_ell"] == 0 and st["n_items"] == 1 and len(segs) == 0

@@ -9,7 +9,7 @@ row-ordered CPU sum is not expected; the reference's own check is 1 % relative
 import numpy as np
 import pytest
 
-from util import SMALL_CASES, Case
+from util import SMALL_CASES, Case, fem_plus_rmat
 
 pytestmark = pytest.mark.gpu
 
@@ -187,15 +187,15 @@ def test_direct_shape(E, O, gpu, name, kind, args):
     assert it == 3 and c.check(y1)[0] == 0
 
 
-@pytest.mark.parametrize("kw", [dict(er_mode=2, lds_doubles=4096), dict(er_mode=2)], ids=["some_windows_kept", "no_window_kept"])
-def test_pass_2_assigns_rows_of_partitions_without_a_window(E, O, gpu, kw):
-    """Pruned windows (plan.cpp): the ELL launch skips those partitions and pass 2 of the panel residual is the
-    only writer of their rows -- y is filled with NaN before every multiply, so a row nobody writes shows."""
-    cfg = E.make_config(partitioner=E.EHYB_PART_CONTIGUOUS, **kw)
-    c = Case(E, O, "rmat", (18, 1 << 21, 1), cfg)
+@pytest.mark.parametrize("mixed", [True, False], ids=["some_windows_kept", "no_window_kept"])
+def test_pass_2_assigns_rows_of_partitions_without_a_window(E, O, gpu, mixed):
+    """Pruned windows (plan.cpp): the ELL launch has no segment for those partitions and pass 2 of the panel residual
+    is the only writer of their rows -- y is filled with NaN before every multiply, so a row nobody writes shows."""
+    cfg = E.make_config(partitioner=E.EHYB_PART_CONTIGUOUS, er_mode=2, lds_doubles=4096)
+    c = Case(E, O, None, None, cfg, matrix=fem_plus_rmat(E, cfg)) if mixed else Case(E, O, "rmat", (18, 1 << 21, 1), cfg)
     plan = E.Plan(c.m, cfg)
     u2 = plan.array("pb_units2").reshape(-1, 4)
-    assert np.any(u2[:, 3] < 0)
+    assert np.any(u2[:, 3] < 0) and (plan.stats["nnz_ell"] > 0) == mixed
     dx, dy = E.DeviceBuffer(c.n).upload(c.xp), E.DeviceBuffer(c.n)
     for phases in ((0,), (1, 2), (0,)):
         dy.upload(np.full(c.n, np.nan))

@@ -5,9 +5,9 @@ import numpy as np
 class Case:
     """read/generate -> x -> CPU reference y -> reorder -> P*x (solver_test.c:350-376)."""
 
-    def __init__(self, E, O, kind, args, cfg, reorder=True):
+    def __init__(self, E, O, kind, args, cfg, reorder=True, matrix=None):
         self.E, self.O, self.cfg = E, O, cfg
-        m = E.Matrix.generate(kind, *args, cfg=cfg)
+        m = matrix if matrix is not None else E.Matrix.generate(kind, *args, cfg=cfg)
         self.m = m
         self.n = m.n
         self.x = O.x_glibc(m.n)                                   # solver_test.c:89-92
@@ -41,3 +41,15 @@ SMALL_CASES = [
     ("banded_16k", "banded", (1 << 14, 32, 1024)),
     ("kkt3d_12", "kkt3d", (12,)),
 ]
+
+
+def fem_plus_rmat(E, cfg, fem_rows=30000, rmat_scale=15, rmat_edges=1 << 19):
+    """Block-diagonal [FEM-like | R-MAT]: the FEM partitions' LDS windows pay, the R-MAT partitions' do not --
+    the input on which only SOME windows are given up to the panel residual (plan.cpp)."""
+    a = E.Matrix.generate("fem3d", fem_rows, 3, 22, 22, 13500, 1, 1, cfg=cfg)
+    b = E.Matrix.generate("rmat", rmat_scale, rmat_edges, 5, cfg=cfg)
+    rp = np.concatenate([a.row_idx.astype(np.int64), a.nnz + b.row_idx.astype(np.int64)[1:]])
+    J = np.concatenate([a.J, b.J + a.n])
+    V = np.concatenate([a.V, b.V])
+    a.free(), b.free()
+    return E.Matrix.from_csr(rp, J, V, cfg)

@@ -24,6 +24,7 @@ def main():
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--probes", default="0,2")
     ap.add_argument("--units2", default="0", help="EHYB_PB_UNITS2 values (row blocks aimed at; 0 = default 2048)")
+    ap.add_argument("--prune-pct", default="110", help="EHYB_PRUNE_PCT values: a window is given up when it costs more than this share of the panel form")
     args = ap.parse_args()
     import bench as B
     import ehyb_spmv_gpu_amd as E
@@ -45,8 +46,10 @@ def main():
     lib.ehyb_debug_panel_times.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_int, C.POINTER(C.c_double), C.POINTER(C.c_double)]
     for pc in [int(v) for v in args.panel_cols.split(",")]:
       for br in [int(v) for v in args.block_rows.split(",")]:
-        for u2 in [int(v) for v in args.units2.split(",")]:
+       for u2 in [int(v) for v in args.units2.split(",")]:
+        for pct in [int(v) for v in args.prune_pct.split(",")]:
             os.environ["EHYB_PB_UNITS2"] = str(u2)
+            os.environ["EHYB_PRUNE_PCT"] = str(pct)
             cfg = E.make_config(partitioner=part, fuse_er=2, er_mode=2, er_panel_cols=pc, er_block_rows=br)
             t0 = time.time()
             plan = E.Plan(m, cfg)
@@ -54,7 +57,7 @@ def main():
             st = plan.stats
             r = plan.bench(xd.ptr, yd.ptr, warmup=5, iters=args.iters)
             bad, worst = O.check_tolerance(E.vector_recover(yd.download(), perm), y_ref, scale)
-            out = {"workload": args.workload, "panel_cols": pc, "block_rows": br, "units2_aim": u2, "nnz_er": st["nnz_er"], "partials": st["er_partials"],
+            out = {"workload": args.workload, "panel_cols": pc, "block_rows": br, "units2_aim": u2, "prune_pct": pct, "nnz_ell": st["nnz_ell"], "nnz_er": st["nnz_er"], "partials": st["er_partials"],
                    "units1": len(plan.array("pb_units1")) // 4, "units2": len(plan.array("pb_units2")) // 4,
                    "us_spmv": round(r["ms_total"] / args.iters * 1e3, 1), "us_ell": round(r["ms_ell_avg"] * 1e3, 1), "us_er": round(r["ms_er_avg"] * 1e3, 1),
                    "er_format_MB": round((st["bytes_format"] - st["bytes_format_ell"]) / 1e6, 1), "rows_over_tol": bad, "plan_s": round(t_plan, 1)}

@@ -7,7 +7,9 @@ export TMPDIR=/tmp
 TAG=${1:?tag}
 O=gpurun_out
 cp profiles/pmc_traffic.json $O/pmc_traffic.json
-for W in audikw_1-graded banded-4M kkt3d-110 kkt3d-200 rmat-24 small bcsstk17-like; do
+# usage (inside gpurun): bash tools/pmc_all.sh <tag> ["workload ..."]
+LIST=${2:-"audikw_1-graded banded-4M kkt3d-110 kkt3d-200 rmat-22 rmat-24 small bcsstk17-like"}
+for W in $LIST; do
   STORAGE=$(python - "$W" <<'PY'
 import sys
 sys.path.insert(0, ".")
