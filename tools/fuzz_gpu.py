@@ -21,11 +21,16 @@ def main():
     kinds = {"direct": 0, "panel": 0, "inline": 0, "csr": 0, "sym": 0, "empty_residual": 0}
     for seed in range(first, first + count):
         m, cfg, kw, x, y_ref, scale = build(E, O, seed)
+        cfg.value_map = 1   # slot maps, for the refill below
         plan = E.Plan(m, cfg)
         st = plan.stats
         xp = E.vector_reorder(x, m.reorder_list)
         y = E.vector_recover(plan.spmv_host(xp, iters=2), m.reorder_list)
         bad, worst = O.check_tolerance(y, y_ref, scale)
+        # numeric phase on the device: A -> -2 A on the same pattern (exact), the multiply again
+        plan.set_values(-2.0 * m.V)
+        bad3, worst3 = O.check_tolerance(E.vector_recover(plan.spmv_host(xp), m.reorder_list), -2.0 * y_ref, 2.0 * scale)
+        bad, worst = bad + bad3, max(worst, worst3)
         direct = st["nnz_ell"] == 0 and st["nnz_er"] == st["nnz"] and st["er_segments"] == m.n
         kinds["direct"] += direct
         kinds["panel"] += st["er_partials"] > 0

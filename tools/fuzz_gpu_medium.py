@@ -64,6 +64,7 @@ def main():
         scale = O.abs_rowsum(n, m.I, m.J, m.V, x)
         m.reorder(cfg)
         perm = m.reorder_list.copy()
+        cfg.value_map = 1   # slot maps, for the refill at the end
         plan = E.Plan(m, cfg)
         st = plan.stats
         y = E.vector_recover(plan.spmv_host(E.vector_reorder(x, perm), iters=2), perm)
@@ -81,6 +82,11 @@ def main():
             sc2 = O.abs_rowsum(n, mI, mJ, mV, E.vector_reorder(x2, perm))
             bad2, _ = O.check_tolerance(dy.download(), ref2, sc2)
             dx.free(), dy.free()
+        # numeric phase on the device: A -> -2 A on the same pattern (exact), the multiply again
+        plan.set_values(-2.0 * m.V)
+        y3 = E.vector_recover(plan.spmv_host(E.vector_reorder(x, perm)), perm)
+        bad3, _ = O.check_tolerance(y3, -2.0 * y_ref, 2.0 * scale)
+        bad2 += bad3
         form = ("direct" if st["nnz_ell"] == 0 and st["er_segments"] == n else "panel" if st["er_partials"] else
                 "inline" if st["er_inline"] else "csr" if st["nnz_er"] else "pure-ell") + ("+sym" if st["sym_pairs"] else "")
         print(f"seed {seed:4d} {kind:12s} n={n:8d} nnz={m.nnz:10d} {form:12s} bad={bad} bad2={bad2} worst={worst:.1e} {time.time() - t0:5.1f}s {kw}", flush=True)
