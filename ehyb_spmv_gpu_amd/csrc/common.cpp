@@ -80,14 +80,19 @@ Config resolve_config(const ehyb_config* in)
     c.n_top = z.n_top > 1 ? z.n_top : 1;
     // Symmetric pair storage: the window also holds one accumulator per own row, so a partition gets
     // at most 30 % of the budget as rows (x: own + halo, y: own), and one workgroup owns a partition.
-    // Measured best (tools/sweep.py --sym 1): 256 partitions, one 1024-thread workgroup per CU, which
-    // a 112 KiB budget gives; two per CU (80 KiB, 512 partitions) is 7 % slower.
+    // Measured best (tools/sweep.py --sym 1): 256 partitions, one 1024-thread workgroup per CU; two per CU
+    // (80 KiB, 512 partitions) is 7 % slower.  One workgroup per CU leaves the whole 160 KiB of LDS to it, so
+    // the budget is all of it (until the end of round 2: 112 KiB, which is what 256 partitions of the bench
+    // matrix need): matrices that take several rounds of workgroups get fewer, larger partitions -- KKT 110^3
+    // 768 -> 511 partitions, 96.6 -> 91.5 us; 200^3 4087 -> 2816, 538 -> 518 us -- and the row-limited
+    // partitions of a graded mesh are bisected less often (304 -> 257 items, 107.8 -> 100.5 us); the bench
+    // matrix and a 120 k-row one are unchanged (same partitions).
     c.sym_pairs = (z.sym_pairs == 1 && c.window_mode == EHYB_WINDOW_HALO) ? 1 : 2;
     // Plain storage: the whole 160 KiB of a CU as one window, one workgroup per CU, 256 equal-cost work
     // items -- fewer, larger partitions mean fewer halo columns to stage and less padding (audikw_1-like:
     // 136 us against 153 us with two 80 KiB workgroups per CU on the same box; banded +4 %, KKT and
     // R-MAT unchanged).
-    c.lds_doubles = z.lds_doubles > 0 ? std::min(z.lds_doubles, EHYB_LDS_MAX_DOUBLES) : (c.sym_pairs == 1 ? 14336 : EHYB_LDS_MAX_DOUBLES);
+    c.lds_doubles = z.lds_doubles > 0 ? std::min(z.lds_doubles, EHYB_LDS_MAX_DOUBLES) : EHYB_LDS_MAX_DOUBLES;
     c.lds_doubles = std::max(kSlabRows, round_down(c.lds_doubles, 2));
     // Rows per partition: the whole window in reference mode (convert.c:247 tests against
     // partStart + vectorCacheSize); 55 % of it in halo mode (measured best), the rest holds gathered columns.

@@ -206,6 +206,7 @@ int ehyb_plan_load(const char* path, uint64_t expect_key, ehyb_plan** plan, int*
         panel_consistent(H);
     if (!consistent) EHYB_FAIL(EHYB_ERR_FORMAT, "ehyb_plan_load: %s holds inconsistent array sizes", path);
     if (H.er_panel) encode_panel_slots(&H);  // what pass 1 streams is derived from pb_col + pb_dst, not stored
+    P->cfg.value_map = 0;  // the slot maps are not part of the file: a loaded plan cannot be refilled
     if (reorder_list) {
         if (perm.empty()) EHYB_FAIL(EHYB_ERR_FORMAT, "ehyb_plan_load: %s holds no permutation", path);
         std::copy(perm.begin(), perm.end(), reorder_list);

@@ -112,7 +112,7 @@ typedef struct ehyb_config {
                               once; the owning lane adds a_ij*x_j to its own row and a_ij*x_i to row j's
                               accumulator in LDS (ds_add_f64), so one value read serves two entries.  One
                               workgroup per partition; ehyb_sizing makes nParts a multiple of 256 and the
-                              window 112 KiB.  Set it BEFORE reading/generating/reordering the matrix (the
+                              window the whole 160 KiB (own rows twice -- x image and accumulators -- plus halo).  Set it BEFORE reading/generating/reordering the matrix (the
                               partition sizes depend on it).  Results do not depend on the matrix being
                               symmetric (entries without an equal partner stay as they are), but the order
                               of the LDS adds varies from run to run (last-bit differences).
