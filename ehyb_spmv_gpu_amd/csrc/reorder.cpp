@@ -261,6 +261,28 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                 if (weighted) {
                     int maxw = 1;
                     for (int i = 0; i < n; ++i) maxw = std::max(maxw, rowlen[i]);
+                    // Entry-balanced partitions of the SPARSE regions need more rows than a window holds and are
+                    // bisected below, so the launch ends up with more items than asked for -- and one item more than
+                    // a whole number of rounds of 256 workgroups costs a round (graded audikw_1 stand-in: 257 items).
+                    // Ask for fewer: the entry budget W per partition at which the expected count
+                    //     sum over rows of max(row length / W, 1 / rows a window holds)
+                    // is the number wanted less a margin of 1/64 for the pieces a bisection leaves over.
+                    if (nparts >= kNumCU) {
+                        const double rows_cap = std::max(64, c.part_rows);
+                        const double target = nparts - std::max(2, nparts / 64);
+                        if ((double)n / rows_cap < target) {
+                            double lo = sum / nparts, hi = sum;
+                            for (int it = 0; it < 60; ++it) {
+                                const double W = 0.5 * (lo + hi);
+                                double cnt = 0;
+                                for (int i = 0; i < n; ++i) cnt += std::max(rowlen[i] / W, 1.0 / rows_cap);
+                                (cnt > target ? lo : hi) = W;
+                            }
+                            const int want = (int)std::min<double>(nparts, std::max(1.0, std::floor(sum / hi)));
+                            if (c.verbose && want != nparts) printf("sparse regions will be bisected: asking for %d partitions instead of %d\n", want, nparts);
+                            nparts = want;
+                        }
+                    }
                     const int64_t wcap = (int64_t)(sum / nparts * 1.03) + maxw;
                     if (c.verbose) printf("row lengths vary (mean %.1f, sigma %.1f): partitions balanced on entries\n", mean, std::sqrt(var));
                     rc = partition_graph(n, xadj.data(), adj.data(), rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut);
@@ -355,6 +377,7 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
             printf("partition time is %ld us, edge cut %lld\n", (long)((wall_seconds() - t0) * 1e6), (long long)cut);
     }
 
+    m->nParts = nparts;  // (may have grown by capacity splits, or shrunk: entry-balanced request for a graded mesh)
     // ---- partition-contiguous numbering in old order (reordering.c:301-321)
     const double t_sort = wall_seconds();
     std::vector<int> part_size(nparts, 0);
