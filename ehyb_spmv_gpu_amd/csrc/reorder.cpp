@@ -269,7 +269,8 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                     // is the number wanted less a margin of 1/64 for the pieces a bisection leaves over.
                     if (nparts >= kNumCU) {
                         const double rows_cap = std::max(64, c.part_rows);
-                        const double target = nparts - std::max(2, nparts / 64);
+                        const int margin = [&] { const char* e = getenv("EHYB_REQ_MARGIN"); return e ? atoi(e) : std::max(2, nparts / 64); }();  // env: tuning sweeps only
+                        const double target = nparts - margin;
                         if ((double)n / rows_cap < target) {
                             double lo = sum / nparts, hi = sum;
                             for (int it = 0; it < 60; ++it) {
