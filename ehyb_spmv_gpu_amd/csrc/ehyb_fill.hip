@@ -98,7 +98,14 @@ int to_device(T** dst, const T* src, size_t n)
 {
     *dst = nullptr;
     HIP_TRY(hipMalloc((void**)dst, std::max<size_t>(n, 1) * sizeof(T)));
-    if (n) HIP_TRY(hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice));
+    if (n) {
+        const hipError_t e = hipMemcpy(*dst, src, n * sizeof(T), hipMemcpyHostToDevice);
+        if (e != hipSuccess) {  // never leave a half-filled array behind a non-null pointer
+            (void)hipFree(*dst);
+            *dst = nullptr;
+            HIP_TRY(e);
+        }
+    }
     return EHYB_OK;
 }
 
