@@ -121,6 +121,82 @@ static void build_adjacency(const matrixCOO* m, bool symmetric_pattern, std::vec
     }
 }
 
+// k-way partition of the graph of a symmetric-pattern matrix through its COMPRESSED graph, where that pays: the
+// unknowns of one finite-element node have the same column list (the closed neighbourhoods of their vertices are
+// equal -- what the layout builder shares column words for, and what METIS calls graph compression), so they are
+// one vertex of weight d with 1/d^2 of the edges; a partition never separates them, and the multilevel scheme
+// works on a ninth of the edges for 3 unknowns per node (audikw_1).  row_w (may be null): per-row weights to
+// balance (entry-balanced partitions); cap in the same unit.  *used = false: no structure to compress (fewer than
+// a third of the rows have a twin in the row above), nothing was done.
+static int partition_compressed(const matrixCOO* m, const std::vector<int64_t>& xadj, const std::vector<int>& adj, const int* row_w,
+                                int nparts, int cap, const Config& c, int* part, int64_t* cut, bool* used)
+{
+    const int n = m->dimension;
+    const int* rp = m->rowIdx;
+    *used = false;
+    std::vector<int> group(n);
+    std::vector<int> first;  // first row of every group
+    int run = 0;
+    for (int v = 0; v < n; ++v) {
+        const int len = rp[v + 1] - rp[v];
+        const bool twin = v > 0 && run < 16 && len > 0 && len == rp[v] - rp[v - 1] && memcmp(m->J + rp[v], m->J + rp[v - 1], sizeof(int) * (size_t)len) == 0;
+        if (!twin) {
+            first.push_back(v);
+            run = 0;
+        }
+        ++run;
+        group[v] = (int)first.size() - 1;
+    }
+    const int ng = (int)first.size();
+    if ((int64_t)ng * 3 > (int64_t)n * 2 || ng < 2 * nparts) return EHYB_OK;
+    std::vector<int64_t> cx((size_t)ng + 1, 0);
+    std::vector<int> cw((size_t)ng, 0);
+    for (int v = 0; v < n; ++v) cw[group[v]] += row_w ? row_w[v] : 1;
+#pragma omp parallel
+    {
+        std::vector<int> seen((size_t)ng, -1);
+#pragma omp for schedule(dynamic, 2048)
+        for (int g = 0; g < ng; ++g) {
+            const int r = first[g];
+            int64_t deg = 0;
+            for (int64_t e = xadj[r]; e < xadj[r + 1]; ++e) {
+                const int h = group[adj[e]];
+                if (h != g && seen[h] != g) {
+                    seen[h] = g;
+                    ++deg;
+                }
+            }
+            cx[(size_t)g + 1] = deg;
+        }
+    }
+    for (int g = 0; g < ng; ++g) cx[(size_t)g + 1] += cx[g];
+    std::vector<int> ca((size_t)cx[ng]);
+#pragma omp parallel
+    {
+        std::vector<int> seen((size_t)ng, -1);
+#pragma omp for schedule(dynamic, 2048)
+        for (int g = 0; g < ng; ++g) {
+            const int r = first[g];
+            int64_t at = cx[g];
+            for (int64_t e = xadj[r]; e < xadj[r + 1]; ++e) {
+                const int h = group[adj[e]];
+                if (h != g && seen[h] != g) {
+                    seen[h] = g;
+                    ca[(size_t)at++] = h;
+                }
+            }
+        }
+    }
+    if (c.verbose) printf("compressed graph: %d vertices for %d rows, %lld of %lld edges\n", ng, n, (long long)cx[ng], (long long)xadj[n]);
+    std::vector<int> cpart((size_t)ng, 0);
+    const int rc = partition_graph(ng, cx.data(), ca.data(), cw.data(), nparts, cap, c, cpart.data(), cut);
+    if (rc != EHYB_OK) return rc;
+#pragma omp parallel for schedule(static)
+    for (int v = 0; v < n; ++v) part[v] = cpart[group[v]];
+    *used = true;
+    return EHYB_OK;
+}
+
 }  // namespace ehyb
 
 using namespace ehyb;
@@ -248,6 +324,8 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
             // by the capacity split below.
             std::vector<int> rowlen;
             bool weighted = false;
+            // the multilevel scheme on the compressed graph where the rows come in groups with one column list
+            const bool compress = symmetric_pattern != 0 && (c.partitioner == EHYB_PART_AUTO || c.partitioner == EHYB_PART_MULTILEVEL) && n >= 4096;
             if (c.sym_pairs == 1 && n >= 4 * nparts) {
                 rowlen.resize(n);
                 double sum = 0, sq = 0;
@@ -286,10 +364,19 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                     }
                     const int64_t wcap = (int64_t)(sum / nparts * 1.03) + maxw;
                     if (c.verbose) printf("row lengths vary (mean %.1f, sigma %.1f): partitions balanced on entries\n", mean, std::sqrt(var));
-                    rc = partition_graph(n, xadj.data(), adj.data(), rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut);
+                    bool done = false;
+                    rc = EHYB_OK;
+                    if (compress) rc = partition_compressed(m, xadj, adj, rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut, &done);
+                    if (rc == EHYB_OK && !done)
+                        rc = partition_graph(n, xadj.data(), adj.data(), rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut);
                 }
             }
-            if (!weighted) rc = partition_graph(n, xadj.data(), adj.data(), nullptr, nparts, cap, c, part.data(), &cut);
+            if (!weighted) {
+                bool done = false;
+                rc = EHYB_OK;
+                if (compress) rc = partition_compressed(m, xadj, adj, nullptr, nparts, cap, c, part.data(), &cut, &done);
+                if (rc == EHYB_OK && !done) rc = partition_graph(n, xadj.data(), adj.data(), nullptr, nparts, cap, c, part.data(), &cut);
+            }
             if (c.verbose) printf("k-way partition time is %ld us\n", (long)((wall_seconds() - t0) * 1e6));
             // Capacity-aware refinement (halo window only): a partition whose own rows plus the
             // distinct outside columns it references do not fit the LDS window would spill
