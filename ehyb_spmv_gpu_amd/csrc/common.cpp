@@ -237,7 +237,8 @@ int ehyb_sizing(int dimension, const ehyb_config* cfg, int* nParts, int* vectorC
         // one workgroup per partition, all of equal size: whole rounds of 256 workgroups, and a cap
         // just above the mean so that the partitioner keeps them equal
         parts = (parts + kNumCU - 1) / kNumCU * kNumCU;
-        cache = (int)std::min<int64_t>(cache, (int64_t)((double)dimension / parts * 1.03) + 2);
+        const double slack = [] { const char* e = getenv("EHYB_SYM_SLACK_PERMILLE"); return e ? atof(e) / 1000.0 : 0.03; }();  // env: tuning sweeps only
+        cache = (int)std::min<int64_t>(cache, (int64_t)((double)dimension / parts * (1.0 + slack)) + 2);
     }
     int64_t items = (int64_t)c.items_per_cu * kNumCU;
     int kpp = (int)std::max<int64_t>(1, (items + parts - 1) / parts);

@@ -336,6 +336,7 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                 }
                 const double mean = sum / n, var = sq / n - mean * mean;
                 weighted = var > 0.09 * mean * mean;  // sigma above 30 % of the mean (uniform stand-in: 15 %)
+                if (const char* e = getenv("EHYB_FORCE_WEIGHTED")) weighted = atoi(e) != 0;  // env: tuning sweeps only
                 if (weighted) {
                     int maxw = 1;
                     for (int i = 0; i < n; ++i) maxw = std::max(maxw, rowlen[i]);
