@@ -129,7 +129,7 @@ static void build_adjacency(const matrixCOO* m, bool symmetric_pattern, std::vec
 // balance (entry-balanced partitions); cap in the same unit.  *used = false: no structure to compress (fewer than
 // a third of the rows have a twin in the row above), nothing was done.
 static int partition_compressed(const matrixCOO* m, const std::vector<int64_t>& xadj, const std::vector<int>& adj, const int* row_w,
-                                int nparts, int cap, const Config& c, int* part, int64_t* cut, bool* used)
+                                int nparts, int cap, const Config& c, int* part, int64_t* cut, bool* used, std::vector<int>* group_out)
 {
     const int n = m->dimension;
     const int* rp = m->rowIdx;
@@ -193,6 +193,7 @@ static int partition_compressed(const matrixCOO* m, const std::vector<int64_t>& 
     if (rc != EHYB_OK) return rc;
 #pragma omp parallel for schedule(static)
     for (int v = 0; v < n; ++v) part[v] = cpart[group[v]];
+    if (group_out) group_out->swap(group);
     *used = true;
     return EHYB_OK;
 }
@@ -323,6 +324,7 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
             // length); partitions of the sparse regions that outgrow the LDS window in rows are bisected
             // by the capacity split below.
             std::vector<int> rowlen;
+            std::vector<int> twin_group;  // compressed graph used: the group (node) of every row
             bool weighted = false;
             // the multilevel scheme on the compressed graph where the rows come in groups with one column list
             const bool compress = symmetric_pattern != 0 && (c.partitioner == EHYB_PART_AUTO || c.partitioner == EHYB_PART_MULTILEVEL) && n >= 4096;
@@ -367,7 +369,7 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                     if (c.verbose) printf("row lengths vary (mean %.1f, sigma %.1f): partitions balanced on entries\n", mean, std::sqrt(var));
                     bool done = false;
                     rc = EHYB_OK;
-                    if (compress) rc = partition_compressed(m, xadj, adj, rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut, &done);
+                    if (compress) rc = partition_compressed(m, xadj, adj, rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut, &done, &twin_group);
                     if (rc == EHYB_OK && !done)
                         rc = partition_graph(n, xadj.data(), adj.data(), rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut);
                 }
@@ -375,7 +377,7 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
             if (!weighted) {
                 bool done = false;
                 rc = EHYB_OK;
-                if (compress) rc = partition_compressed(m, xadj, adj, nullptr, nparts, cap, c, part.data(), &cut, &done);
+                if (compress) rc = partition_compressed(m, xadj, adj, nullptr, nparts, cap, c, part.data(), &cut, &done, &twin_group);
                 if (rc == EHYB_OK && !done) rc = partition_graph(n, xadj.data(), adj.data(), nullptr, nparts, cap, c, part.data(), &cut);
             }
             if (c.verbose) printf("k-way partition time is %ld us\n", (long)((wall_seconds() - t0) * 1e6));
@@ -448,6 +450,10 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
 #pragma omp critical
                                 rc_any = r2;
                             }
+                            // the bisection works on the rows themselves: the unknowns of a node follow its first one
+                            if (!twin_group.empty())
+                                for (int q = 1; q < nb; ++q)
+                                    if (twin_group[verts[q]] == twin_group[verts[q - 1]]) halves[oi][q] = halves[oi][q - 1];
                         }
                     }
                     if (rc_any != EHYB_OK) return rc_any;

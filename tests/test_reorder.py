@@ -166,3 +166,54 @@ def test_partition_does_not_depend_on_the_thread_count(E):
     assert np.bincount(part_many, minlength=48).max() <= cap
     ideal = 4 * np.sqrt(n / 48) * 48 / 2
     assert cut_many < 1.5 * ideal + 40, (cut_many, ideal)
+
+
+def test_unknowns_of_a_node_stay_together(E):
+    """The k-way partition runs on the compressed graph where rows share their column lists (reorder.cpp,
+    partition_compressed): the three unknowns of a finite-element node -- rows with one column list -- are one
+    vertex there, so no partition separates them; sizes stay under the cap; deterministic."""
+    cfg = E.make_config(lds_doubles=4096, partitioner=E.EHYB_PART_MULTILEVEL)
+    m = E.Matrix.generate("fem3d", 30000, 3, 22, 22, 13500, 1, 1, cfg=cfg)
+    rp, J = m.row_idx.astype(np.int64).copy(), m.J.copy()
+    n = m.n
+    twin = np.zeros(n, dtype=bool)       # row has the column list of the row above
+    for r in range(1, n):
+        a, b, c = rp[r - 1], rp[r], rp[r + 1]
+        twin[r] = (c - b == b - a) and np.array_equal(J[a:b], J[b:c])
+    assert twin.mean() > 0.6             # 3 unknowns per node: two of three rows
+    m.reorder(cfg)
+    lst = m.reorder_list
+    pb = m.part_boundary[:m.c.nParts + 1]
+    assert pb[0] == 0 and pb[-1] == n and np.all(np.diff(pb) >= 0)
+    part_of_new = np.searchsorted(pb, np.arange(n), side="right") - 1
+    part_of_old = part_of_new[lst]
+    assert np.all(part_of_old[1:][twin[1:]] == part_of_old[:-1][twin[1:]]), "a node's unknowns were separated"
+    assert np.diff(pb).max() <= max(int(m.c.vectorCacheSize), -(-n // m.c.nParts))
+    m2 = E.Matrix.generate("fem3d", 30000, 3, 22, 22, 13500, 1, 1, cfg=cfg)
+    m2.reorder(cfg)
+    assert np.array_equal(m2.reorder_list, lst)
+
+
+def test_graded_mesh_asks_for_fewer_partitions(E, O):
+    """Symmetric pair storage on a matrix whose rows differ a lot in length: entry-balanced partitions, the
+    row-limited ones bisected -- and fewer asked for up front, so that the launch ends at one round of 256
+    workgroups (reorder.cpp).  nParts is written back whichever way the count moved."""
+    cfg = E.make_config(sym_pairs=1)
+    m = E.Matrix.generate("fem3d_graded", 300000, 3, 46, 46, 100000, 705000, 1, 1, cfg=cfg)
+    asked = int(m.c.nParts)
+    assert asked == 256
+    x = O.x_glibc(m.n)
+    y_ref = O.spmv_coo(m.n, m.I, m.J, m.V, x)
+    scale = O.abs_rowsum(m.n, m.I, m.J, m.V, x)
+    m.reorder(cfg)
+    got = int(m.c.nParts)
+    pb = m.part_boundary[:got + 1]
+    assert 200 <= got <= 256, got
+    assert pb[0] == 0 and pb[-1] == m.n and np.all(np.diff(pb) >= 0)
+    plan = E.Plan(m, cfg, upload=False)
+    st = plan.stats
+    assert st["n_items"] <= 256 and st["sym_pairs"] > 0
+    y, written = O.walk_plan(plan, E.vector_reorder(x, m.reorder_list))
+    assert written[:m.n].min() == 1 and written[:m.n].max() == 1
+    bad, worst = O.check_tolerance(E.vector_recover(y, m.reorder_list), y_ref, scale)
+    assert bad == 0, worst
