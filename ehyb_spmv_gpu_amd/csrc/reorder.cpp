@@ -327,7 +327,8 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
             std::vector<int> twin_group;  // compressed graph used: the group (node) of every row
             bool weighted = false;
             // the multilevel scheme on the compressed graph where the rows come in groups with one column list
-            const bool compress = symmetric_pattern != 0 && (c.partitioner == EHYB_PART_AUTO || c.partitioner == EHYB_PART_MULTILEVEL) && n >= 4096;
+            static const bool compress_env = [] { const char* e = getenv("EHYB_COMPRESS"); return !e || atoi(e) != 0; }();  // env: A/B only
+            const bool compress = compress_env && symmetric_pattern != 0 && (c.partitioner == EHYB_PART_AUTO || c.partitioner == EHYB_PART_MULTILEVEL) && n >= 4096;
             if (c.sym_pairs == 1 && n >= 4 * nparts) {
                 rowlen.resize(n);
                 double sum = 0, sq = 0;
