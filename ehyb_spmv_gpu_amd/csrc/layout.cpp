@@ -128,7 +128,8 @@ void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64
         int q = ip_ptr[r - s];
         for (int k = rp[r]; k < rp[r + 1]; ++k)
             if (J[k] >= s && J[k] < e) ip[q++] = {J[k], k};
-        std::sort(ip.begin() + ip_ptr[r - s], ip.begin() + ip_ptr[r - s + 1]);
+        // (rows of a reader or generator arrive column-sorted, mirrored symmetric files almost: test first)
+        if (!std::is_sorted(ip.begin() + ip_ptr[r - s], ip.begin() + ip_ptr[r - s + 1])) std::sort(ip.begin() + ip_ptr[r - s], ip.begin() + ip_ptr[r - s + 1]);
     }
     for (int i = s; i < e; ++i) {
         const int g = grp[i - s];
@@ -183,6 +184,13 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                         (cfg.direct == 1 || (cfg.direct == 0 && n <= EHYB_DIRECT_MAX_ROWS && cfg.window_mode != EHYB_WINDOW_REFERENCE && cfg.fuse_er != 1));
     L->direct = direct;
 
+    // (cfg.verbose: where the build spends its time)
+    double t_lap = wall_seconds();
+    auto lap = [&](const char* what) {
+        const double now = wall_seconds();
+        if (cfg.verbose) printf("layout: %-28s %7.1f ms\n", what, (now - t_lap) * 1e3);
+        t_lap = now;
+    };
     // ---- partitions: the caller's, cut down to the window capacity where needed
     std::vector<int32_t>& pb = L->part_boundary;
     pb.clear();
@@ -236,6 +244,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     L->row_end = row_end;
     const int nrows = row_end - row_begin;
 
+    lap("partitions");
     // ---- symmetric pair storage (cfg.sym_pairs): which entries carry their partner, which are dropped
     const int64_t k0 = rp[row_begin];
     std::vector<uint8_t> state;       // per entry: 0 as it is, 1 kept + scatter, 2 dropped
@@ -259,6 +268,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     L->sym = sym;
     L->yacc_doubles = 0;
 
+    lap("pair orientation");
     // ---- pass 1: window contents, per-row ELL counts, slab widths
     std::vector<PartScratch> ps(np);
     std::vector<int32_t> cnt_ell(nrows, 0);
@@ -481,6 +491,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     if (sym)
         for (uint8_t st8 : state) sym_kept += st8 == 1;
 
+    lap("pass 1 (windows, widths)");
     // ---- inline form of a tiny residual.  The residual entries of a slab's rows are stored as
     // extra pairs behind the slab's ELL pairs -- values in the same stream, columns as two global
     // 32-bit indices per lane and pair -- and the ELL lanes multiply them straight from global x
@@ -567,6 +578,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     const int64_t size_stream = (int64_t)L->slab_pair_ptr[nslabs] * 2 * kSlabRows;  // + inline residual pairs
     const int64_t col_words = (int64_t)L->slab_col_ptr[nslabs];
 
+    lap("inline form + prefix sums");
     // ---- pass 3: fill
     L->ell_val.assign((size_t)size_stream, 0.0);
     L->ell_col.assign((size_t)col_words, 0);
@@ -686,6 +698,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     }
     if (overflow) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: entry counts changed between passes");
 
+    lap("pass 3 (fill)");
     // ---- work items: contiguous slab ranges of roughly equal cost = the bytes the ELL launch streams
     // for them.  (An inline residual is part of `pairs`; a residual with a launch of its own costs
     // this one nothing -- charging it here made the ELL phase of R-MAT twice as long: 198 vs 94 us.)
@@ -790,6 +803,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     }
     const int64_t n_items = (int64_t)L->items.size() / 8;
 
+    lap("work items");
     // ---- pass 4: residual segments, grouped by work item, longest first inside an item
     struct Seg {
         int32_t row;
@@ -868,6 +882,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             }
         }
     }
+    lap("pass 4 (residual segments)");
     // ---- a large residual also gets its panel form (er_panel.cpp): what the residual launch then runs
     ehyb_stats& st = L->stats;
     st.rows_er = rows_er;
@@ -900,6 +915,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         if (!L->er_panel) L->pb_assign = false;
     }
     if (assign_mode && !L->pb_assign) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: partitions were given up but the residual did not end in panel form");
+    lap("panel form");
     // ---- statistics (convert.c:140,310; spmv.cu:82)
     st.nnz = nnz;
     st.nnz_ell = nnz_ell;
