@@ -38,6 +38,9 @@ def check_rank(tag, I, J, V, cuts, rank, world, cfg, symmetric):
     x_ext[:L.n_loc] = torch.from_numpy(L.x_to_plan(x[r0:r1]))
     D.HaloExchange(L, x_ext).run()
     assert np.array_equal(x_ext[L.n_loc:].numpy(), x[L.ghost_cols]), "ghost slots do not hold the owners' x entries"
+    if tag == "rmat-rows-panel" and world > 1:
+        u2 = plan.array("pb_units2").reshape(-1, 4)
+        assert st["er_partials"] > 0 and np.any(u2[:, 3] < 0), "the panel case should run in assign mode"
     y_plan, written = O.walk_plan(plan, x_ext.numpy())
     assert written[:L.n_loc].min() == 1 and written.sum() == L.n_loc
     y = L.y_from_plan(y_plan[:L.n_loc])
@@ -86,6 +89,10 @@ def main():
     rp = g.row_idx
     a, b = int(rp[base[rank]]), int(rp[base[rank + 1]])
     bad += check_rank("rmat-rows", g.I[a:b].copy(), g.J[a:b].copy(), g.V[a:b].copy(), base, rank, world, cfg, symmetric=False)
+    # 2b. the same rows with the residual in panel form: what `bench.py --gpus N` runs on R-MAT 2^24 -- no window of such a
+    # rank pays, every partition is given up, phase 1 is empty and pass 2 of the panel residual assigns every row
+    cfgp = E.make_config(lds_doubles=256, er_mode=2, er_panel_cols=512, er_block_rows=300)
+    bad += check_rank("rmat-rows-panel", g.I[a:b].copy(), g.J[a:b].copy(), g.V[a:b].copy(), base, rank, world, cfgp, symmetric=False)
     # 3. block diagonal: no ghosts at all, the exchange is empty
     cfg = E.make_config(lds_doubles=1024, window_mode=1, partitioner=1)
     g = E.Matrix.generate("banded", 2048, 16, 1024, cfg=cfg)
