@@ -97,3 +97,26 @@ def test_entry_order_is_the_scatter_of_the_reorder_step(E, O, kind, args, kw):
 def test_entry_order_refuses_a_non_permutation(E):
     with pytest.raises(E.EhybError):
         E.entry_order(np.array([0, 1, 2, 3], dtype=np.int32), np.array([0, 0, 1], dtype=np.int32))
+
+
+@pytest.mark.parametrize("seed", range(500, 560))
+def test_maps_on_random_plans(E, O, seed):
+    """The slot maps under the random matrices and plan configurations of the layout fuzz (tests/fuzz_cases.py): every
+    value stream is the matrix's values gathered through its map, whatever shape the plan took."""
+    from fuzz_cases import build
+
+    m, cfg, kw, x, y_ref, scale = build(E, O, seed)
+    cfg.value_map = 1
+    plan = E.Plan(m, cfg, upload=False)
+    V = m.V.copy() if m.nnz else np.zeros(0)
+    for val, src in (("ell_val", "ell_src"), ("er_val", "er_src"), ("pb_val", "pb_src")):
+        v, s = plan.array(val), plan.array(src)
+        assert v.shape == s.shape, (val, kw)
+        assert np.array_equal(gather(V, s).view(np.int64), v.view(np.int64)), (val, kw)
+    st = plan.stats
+    s2 = plan.array("ell_src2")
+    assert int((s2 >= 0).sum()) == st["sym_pairs"]
+    if st["sym_pairs"]:
+        es = plan.array("ell_src")
+        both = s2 >= 0
+        assert np.array_equal(V[s2[both]].view(np.int64), V[es[both]].view(np.int64))
