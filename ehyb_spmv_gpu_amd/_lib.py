@@ -62,6 +62,17 @@ class Config(C.Structure):
         ("direct", C.c_int32),
         ("ell_prune", C.c_int32),
         ("value_map", C.c_int32),
+        ("prune_pct", C.c_int32),
+        ("er_units1", C.c_int32),
+        ("er_units2", C.c_int32),
+        ("graph_compress", C.c_int32),
+        ("balance", C.c_int32),
+        ("req_margin", C.c_int32),
+        ("sym_slack_permille", C.c_int32),
+        ("xcd_map", C.c_int32),
+        ("graphs", C.c_int32),
+        ("er_sums", C.c_int32),
+        ("reserved", C.c_int32 * 30),
     ]
 
 

@@ -125,6 +125,16 @@ Config resolve_config(const ehyb_config* in)
     c.direct = (z.direct == 1 || z.direct == 2) ? z.direct : 0;
     c.ell_prune = z.ell_prune == 2 ? 2 : 1;
     c.value_map = z.value_map == 1 ? 1 : 0;
+    c.prune_pct = z.prune_pct > 0 ? z.prune_pct : 110;
+    c.er_units1 = z.er_units1 > 0 ? z.er_units1 : 2048;
+    c.er_units2 = z.er_units2 > 0 ? z.er_units2 : 2048;
+    c.graph_compress = z.graph_compress == 2 ? 2 : 1;
+    c.balance = (z.balance == 1 || z.balance == 2) ? z.balance : 0;
+    c.req_margin = z.req_margin;
+    c.sym_slack_permille = z.sym_slack_permille > 0 ? z.sym_slack_permille : 30;
+    c.xcd_map = z.xcd_map == 2 ? 2 : 1;
+    c.graphs = z.graphs == 2 ? 2 : 1;
+    c.er_sums = z.er_sums == 2 ? 2 : 1;
     // the automatic choice of the direct shape is for callers that left the window sizing alone: a caller
     // that names a window (lds_doubles / part_rows other than the defaults) gets that window
     if (c.direct == 0 && (c.lds_doubles != EHYB_LDS_MAX_DOUBLES || c.part_rows != round_down(EHYB_LDS_MAX_DOUBLES * 11 / 20, kSlabRows) ||
@@ -182,6 +192,16 @@ void ehyb_config_resolve(const ehyb_config* in, ehyb_config* out)
     r.direct = c.direct;
     r.ell_prune = c.ell_prune;
     r.value_map = c.value_map;
+    r.prune_pct = c.prune_pct;
+    r.er_units1 = c.er_units1;
+    r.er_units2 = c.er_units2;
+    r.graph_compress = c.graph_compress;
+    r.balance = c.balance;
+    r.req_margin = c.req_margin;
+    r.sym_slack_permille = c.sym_slack_permille;
+    r.xcd_map = c.xcd_map;
+    r.graphs = c.graphs;
+    r.er_sums = c.er_sums;
     *out = r;
 }
 
@@ -237,7 +257,7 @@ int ehyb_sizing(int dimension, const ehyb_config* cfg, int* nParts, int* vectorC
         // one workgroup per partition, all of equal size: whole rounds of 256 workgroups, and a cap
         // just above the mean so that the partitioner keeps them equal
         parts = (parts + kNumCU - 1) / kNumCU * kNumCU;
-        const double slack = [] { const char* e = getenv("EHYB_SYM_SLACK_PERMILLE"); return e ? atof(e) / 1000.0 : 0.03; }();  // env: tuning sweeps only
+        const double slack = c.sym_slack_permille / 1000.0;
         cache = (int)std::min<int64_t>(cache, (int64_t)((double)dimension / parts * (1.0 + slack)) + 2);
     }
     int64_t items = (int64_t)c.items_per_cu * kNumCU;

@@ -214,9 +214,8 @@ extern "C" int ehyb_pcg(ehyb_plan* P, const double* dinv, const double* b, doubl
         return EHYB_OK;
     };
     // An even and an odd iteration, captured once and replayed: one submission per two iterations
-    // instead of eight or ten launches.  EHYB_CG_GRAPH=0 keeps the plain launches (A/B, debugging).
-    const char* genv = getenv("EHYB_CG_GRAPH");
-    if (!(genv && genv[0] == '0') && max_iter >= 2 &&
+    // instead of eight or ten launches.  cfg.graphs = 2 keeps the plain launches (A/B, debugging).
+    if (P->cfg.graphs != 2 && max_iter >= 2 &&
         hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         int erc = enqueue_iteration(0);
         if (erc == EHYB_OK) erc = enqueue_iteration(1);

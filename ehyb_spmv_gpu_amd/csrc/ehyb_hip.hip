@@ -373,20 +373,66 @@ __global__ __launch_bounds__(THREADS) void ehyb_er_kernel(const int4* __restrict
 // chunk), bit 14 = the piece's slot is not the previous piece's + 1: a "jump", with an entry in the jump list
 // from which every lane behind it (up to the next jump) gets its slot by adding the pieces begun before its own.
 // The products of a piece are summed in the wave's LDS words and its first lane stores the partial.
-template <int THREADS>
+// One step of a segmented inclusive scan over the 64 lanes of a wave, in registers (DPP moves, no LDS): every lane takes
+// (sum, flag) of the lane CTRL names -- row_shr:d inside the rows of 16 lanes, row_bcast15 / row_bcast31 across them --
+// and adds the sum unless a piece has begun between that lane and itself (flag).  Lanes without a source read zeros.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ void seg_scan_step(double& v, uint32_t& f)
+{
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, ROW_MASK, 0xf, true);
+    const int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, ROW_MASK, 0xf, true);
+    const uint32_t fp = (uint32_t)__builtin_amdgcn_update_dpp(0, (int)f, CTRL, ROW_MASK, 0xf, true);
+    v += f ? 0.0 : __hiloint2double(hi, lo);
+    f |= fp;
+}
+
+// Sums of the pieces of one 64-entry chunk: afterwards the LAST lane of every piece holds the piece's sum.  `heads` =
+// ballot of the first lanes of the pieces (bit 0 always set).  Only the steps the chunk needs are run (wave-uniform
+// branches on the ballot): none when every lane is its own piece -- most chunks of the sparse panels --, row_shr:1 alone
+// when no piece is longer than two lanes, and so on; a hub row's 64-lane piece takes all six.
+__device__ __forceinline__ double piece_sums(double prod, unsigned long long heads, bool head)
+{
+    const unsigned long long nh = ~heads;  // lanes that continue a piece
+    if (nh == 0ull) return prod;
+    double v = prod;
+    uint32_t f = head ? 1u : 0u;
+    seg_scan_step<0x111, 0xf>(v, f);  // row_shr:1
+    const unsigned long long r2 = nh & (nh >> 1);
+    if (r2 != 0ull) {  // a piece of three lanes or more
+        seg_scan_step<0x112, 0xf>(v, f);  // row_shr:2
+        const unsigned long long r4 = r2 & (r2 >> 2);
+        if (r4 != 0ull) {  // five or more
+            seg_scan_step<0x114, 0xf>(v, f);  // row_shr:4
+            const unsigned long long r8 = r4 & (r4 >> 4);
+            if (r8 != 0ull) seg_scan_step<0x118, 0xf>(v, f);  // nine or more: row_shr:8
+        }
+    }
+    if (nh & 0x0001000100010000ull) {  // a piece crosses from one row of 16 lanes into the next
+        seg_scan_step<0x142, 0xa>(v, f);  // row_bcast15: lane 15 -> row 1, lane 47 -> row 3
+        seg_scan_step<0x143, 0xc>(v, f);  // row_bcast31: lane 31 -> rows 2 and 3
+    }
+    return v;
+}
+
+// SUMS_DPP (cfg.er_sums, the default): the products of a piece are added by the register scan above and the piece's
+// LAST lane stores the partial; false = round 2's way: ds_add_f64 into 64 LDS words per wave, the FIRST lane reads the
+// sum back and stores it (kept as the A/B arm: the LDS pipe of a CU was what bound pass 1 -- DESIGN.md 3.2).
+// xcd_map: workgroup b takes unit xcd_item(b): the units of one panel (neighbours in the unit list) then run on ONE XCD at
+// about the same time and stage their panel from its L2 instead of each from the fabric.
+template <int THREADS, bool SUMS_DPP>
 __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __restrict__ units,
                                                                 const double* __restrict__ val,
                                                                 const uint16_t* __restrict__ colf,
                                                                 const uint32_t* __restrict__ chunk,
                                                                 const uint32_t* __restrict__ jump,
                                                                 const double* __restrict__ x,
-                                                                double* __restrict__ partial, int panel_cols, int probe)
+                                                                double* __restrict__ partial, int panel_cols, int probe, int xcd_map)
 {
     // probe (tools/panel_sweep.py, timing diagnostics only, results wrong): 1 no lane sums, 2 no stores,
     // 4 no LDS gather, 8 no panel staging
     extern __shared__ __attribute__((aligned(16))) double win[];
     constexpr int WAVES = THREADS / 64;
-    const int4 u = units[blockIdx.x];
+    const int4 u = units[xcd_map ? xcd_item(blockIdx.x, gridDim.x) : (int)blockIdx.x];
     // stage the panel: all of a thread's loads in flight before the first store (a 64 KiB panel is 16
     // double2 loads per thread; one load per loop trip would pay the memory latency 16 times)
     if (!(probe & 8)) {
@@ -411,8 +457,8 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
     __syncthreads();
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* scr = win + panel_cols + 64 * wave;  // this wave's 64 piece accumulators, behind the panel
-    scr[lane] = 0.0;
+    double* scr = win + panel_cols + 64 * wave;  // this wave's 64 piece accumulators, behind the panel (!SUMS_DPP only)
+    if (!SUMS_DPP) scr[lane] = 0.0;
     const int c0 = u.z >> 6, c1 = u.w >> 6;  // chunks of 64 entries
     constexpr int K = 8;  // chunks per wave and step: 24 independent vector loads in flight per lane
     // The jump-list range of a chunk is known from the chunk records alone (wave-uniform, scalar loads): they are
@@ -444,6 +490,7 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
             gn[j] = chunk[cj + 1] - g0[j];
         }
         uint32_t slot[K], piece[K];
+        unsigned long long hd[K];
         double xw[K];
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -455,17 +502,23 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
             // the entry of the last jump at or below this lane sits in lane jc - 1 (lane 0 is always a jump)
             const uint32_t base = (uint32_t)__builtin_amdgcn_ds_bpermute((int)((jc - 1u) << 2), (int)jv[j]);
             piece[j] = hc - 1u;
-            slot[j] = head ? base + hc - 1u : 0xFFFFFFFFu;  // 0xFFFFFFFF: nothing to store (also what the padding piece yields)
+            // who stores the partial: the piece's last lane (register scan) or its first (LDS sums); every lane of a piece
+            // computes the same slot.  0xFFFFFFFF: nothing to store (also what the padding piece yields)
+            const bool stores = SUMS_DPP ? (lane == 63 || ((heads >> (lane + 1)) & 1ull)) : head;
+            slot[j] = stores ? base + hc - 1u : 0xFFFFFFFFu;
+            hd[j] = heads;
             const uint32_t cl = cw[j] & 0x3FFFu;
             xw[j] = (probe & 4) ? (double)cl : win[cl];
-            cw[j] = heads == ~0ull ? 1u : 0u;  // every lane its own piece: no sums needed
+            cw[j] = (heads == ~0ull ? 1u : 0u) | (head ? 2u : 0u);  // bit 0: every lane its own piece, no sums needed
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
             if (c + j < c1) {  // wave-uniform
                 const double prod = v[j] * xw[j];
                 double sum = prod;
-                if (!cw[j] && !(probe & 1)) {
+                if (SUMS_DPP) {
+                    if (!(probe & 1)) sum = piece_sums(prod, hd[j], (cw[j] & 2u) != 0);
+                } else if (!(cw[j] & 1u) && !(probe & 1)) {
                     // Some lanes share a slot: the piece sums are formed in this wave's 64 LDS words (zero between
                     // uses), one ds_add_f64 per lane, one read + one store of zero per piece.  (Shuffle trees --
                     // six ds_bpermute rounds per chunk -- cost 17 us of a 127 us launch here and 17 of 80 in pass 2.)
@@ -584,9 +637,8 @@ static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long 
     A.y = y;
     A.win_cap = ell_win_cap(P->host);
     A.stamps = stamps;
-    // on by default: plain storage 143 -> 134 us on the audikw_1-like matrix; EHYB_XCD_MAP=0 for the A/B
-    static const int xcd_env = [] { const char* e = getenv("EHYB_XCD_MAP"); return e ? atoi(e) : 1; }();
-    A.xcd_map = P->host.sym ? 0 : xcd_env;  // symmetric pairs: items are sorted heaviest first, dispatched in that order
+    // on by default: plain storage 143 -> 134 us on the audikw_1-like matrix; cfg.xcd_map = 2 for the A/B
+    A.xcd_map = P->host.sym ? 0 : (P->cfg.xcd_map != 2 ? 1 : 0);  // symmetric pairs: items are sorted heaviest first, dispatched in that order
     A.windowless_zero = P->host.pb_assign ? 0 : 1;
     return A;
 }
@@ -643,9 +695,22 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
 {
     const HostLayout& H = P->host;
     const int u1 = (int)(H.pb_units1.size() / 4), u2 = (int)(H.pb_units2.size() / 4);
-    if (which & 1)
-        hipLaunchKernelGGL(ehyb_pb_scale_kernel<512>, dim3(u1), dim3(512), (size_t)(H.pb_panel_cols + 512) * 8, st, (const int4*)P->d_pb_units1,
-                           P->d_pb_val, P->d_pb_colf, P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, probe);
+    if (which & 1) {
+        // panels of up to 9,728 columns: two 512-thread workgroups per CU (one stages while the other streams); wider
+        // panels leave room for one workgroup only, which then gets the CU's 16 waves
+        const bool wide = H.pb_panel_cols > 9728;
+        const bool dpp = P->cfg.er_sums != 2;
+        const int xcd = P->cfg.xcd_map != 2 ? 1 : 0;
+#define PB_SCALE(T, D)                                                                                                          \
+    hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D>), dim3(u1), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T))) * 8, st, (const int4*)P->d_pb_units1, \
+                       P->d_pb_val, P->d_pb_colf, P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, probe, xcd)
+        if (wide) {
+            if (dpp) PB_SCALE(1024, true); else PB_SCALE(1024, false);
+        } else {
+            if (dpp) PB_SCALE(512, true); else PB_SCALE(512, false);
+        }
+#undef PB_SCALE
+    }
     if (which & 2)
         hipLaunchKernelGGL(ehyb_pb_reduce_kernel<512>, dim3(u2), dim3(512), (size_t)H.pb_rows_max * 8, st, (const int4*)P->d_pb_units2,
                            P->d_pb_partial, P->d_pb_row, y, probe);
@@ -658,8 +723,7 @@ static int launch_er(ehyb_plan* P, const double* x, double* y, hipStream_t st)
     const HostLayout& H = P->host;
     if (H.er_bins[3] == 0) return EHYB_OK;
     if (H.er_panel) {  // panel form: scale (x panels in LDS) then reduce (y blocks in LDS)
-        static const int pb_probe = [] { const char* e = getenv("EHYB_PB_PROBE"); return e ? atoi(e) : 0; }();  // timing diagnostics only
-        return launch_panel(P, x, y, st, pb_probe, 3);
+        return launch_panel(P, x, y, st, 0, 3);  // (probe arms only through ehyb_debug_panel_times)
     }
     const int n_blocks = (int)(H.er_blocks.size() / 4);
     if (P->cfg.er_threads != 256) EHYB_FAIL(EHYB_ERR_ARG, "residual workgroup size %d not built (256)", P->cfg.er_threads);
@@ -803,11 +867,11 @@ int ehyb_debug_ell_stamps(ehyb_plan* P, const double* x, double* y, unsigned lon
     HIP_TRY(hipMalloc((void**)&d, (size_t)n_items * 32));
     HIP_TRY(hipMemset(d, 0, (size_t)n_items * 32));
     int rc = launch_ell_impl<true>(P, x, y, nullptr, P->host.inline_er, d);
-    if (rc != EHYB_OK) return rc;
-    HIP_TRY(hipDeviceSynchronize());
-    HIP_TRY(hipMemcpy(out_host, d, (size_t)n_items * 32, hipMemcpyDeviceToHost));
+    if (rc == EHYB_OK && hipDeviceSynchronize() != hipSuccess) rc = EHYB_ERR_HIP;
+    if (rc == EHYB_OK && hipMemcpy(out_host, d, (size_t)n_items * 32, hipMemcpyDeviceToHost) != hipSuccess) rc = EHYB_ERR_HIP;
+    if (rc == EHYB_ERR_HIP) set_error("ehyb_debug_ell_stamps: %s", hipGetErrorString(hipGetLastError()));
     (void)hipFree(d);
-    return EHYB_OK;
+    return rc;
 }
 
 // Diagnostic (tools/panel_sweep.py): mean time of each pass of the panel residual alone, `iters` launches each
@@ -896,7 +960,10 @@ int ehyb_plan_upload(ehyb_plan* P)
     LDS_ATTR_T(256)
     LDS_ATTR_T(512)
     LDS_ATTR_T(1024)
-    LDS_ATTR(ehyb_pb_scale_kernel<512>)
+    LDS_ATTR((ehyb_pb_scale_kernel<512, true>))
+    LDS_ATTR((ehyb_pb_scale_kernel<512, false>))
+    LDS_ATTR((ehyb_pb_scale_kernel<1024, true>))
+    LDS_ATTR((ehyb_pb_scale_kernel<1024, false>))
     LDS_ATTR(ehyb_pb_reduce_kernel<512>)
 #undef LDS_ATTR_T
 #undef LDS_ATTR_S
@@ -964,8 +1031,7 @@ int ehyb_spmv_bench(ehyb_plan* P, const double* x, double* y, void* stream, int 
     int rc;
     for (int i = 0; i < warmup; ++i)
         if ((rc = ehyb_spmv(P, x, y, stream)) != EHYB_OK) return rc;
-    static const bool graph_env = [] { const char* e = getenv("EHYB_BENCH_GRAPH"); return !e || atoi(e) != 0; }();
-    if (graph_env && iters >= 2 * kBatch && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+    if (P->cfg.graphs != 2 && iters >= 2 * kBatch && hipStreamBeginCapture(st, hipStreamCaptureModeThreadLocal) == hipSuccess) {
         int erc = EHYB_OK;
         for (int i = 0; i < kBatch && erc == EHYB_OK; ++i) erc = ehyb_spmv(P, x, y, stream);
         const hipError_t eend = hipStreamEndCapture(st, &L.graph);

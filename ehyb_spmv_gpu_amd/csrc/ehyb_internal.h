@@ -50,6 +50,16 @@ struct Config {
     int direct;             // 0 automatic, 1 on, 2 off
     int ell_prune;          // 0/1: windows that cost more than the panel residual are given up, 2 = never
     int value_map;          // 1: keep the slot maps of the value streams (ehyb_plan_set_values)
+    int prune_pct;          // ell_prune threshold in per cent of the panel form's cost (110)
+    int er_units1;          // panel form: work units aimed at, pass 1 / pass 2 (2048)
+    int er_units2;
+    int graph_compress;     // 1 on, 2 off
+    int balance;            // 0 automatic, 1 entries, 2 rows
+    int req_margin;         // 0 default, -1 none, > 0 as given
+    int sym_slack_permille; // 30
+    int xcd_map;            // 1 on, 2 off
+    int graphs;             // 1 on, 2 off
+    int er_sums;            // 1 DPP scan, 2 LDS words
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -148,12 +158,15 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                  const std::vector<uint8_t>* part_to_er = nullptr);
 int build_panel_residual(const Config& cfg, HostLayout* L);  // er_panel.cpp; reads the CSR residual of *L
 void encode_panel_slots(HostLayout* L);                      // er_panel.cpp; pb_col + pb_dst -> pb_colf, pb_chunk, pb_jump
-bool sym_storage_suits(const matrixCOO* m);
-int windows_that_do_not_pay(const HostLayout& H, std::vector<uint8_t>* to_er, int64_t* entries_moved);  // plan.cpp  // spmvGPuEHYB's own choice of the storage (plan.cpp)
+bool sym_storage_suits(const matrixCOO* m);  // spmvGPuEHYB's own choice of the storage (plan.cpp)
+int windows_that_do_not_pay(const HostLayout& H, int pct, std::vector<uint8_t>* to_er, int64_t* entries_moved);  // plan.cpp
 
 // ---------------------------------------------------------------- partitioner
+// *by_degree (may be null) = true: the parts are blocks of the degree order (EHYB_PART_DEGREE, or EHYB_PART_AUTO on a
+// graph that does not coarsen) -- the caller should number the rows of a part in that order (degree_order)
 int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vwgt, int nparts,
-                    int max_part_w, const Config& cfg, int* part, int64_t* edgecut);
+                    int max_part_w, const Config& cfg, int* part, int64_t* edgecut, bool* by_degree = nullptr);
+void degree_order(int n, const int64_t* xadj, std::vector<int>* order);
 
 // Optional mt-metis backend: resolved at run time from the process image (weak symbol) --
 // see INTEGRATION.md.  Returns false when not linked.

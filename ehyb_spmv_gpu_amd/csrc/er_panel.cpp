@@ -129,10 +129,8 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
         if ((unsigned)r >= (unsigned)nrows) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_panel_residual: residual row outside the plan's rows");
         ++cnt_row[r];
     }
-    // (tuning knobs for tools/er_ab.py only: EHYB_PB_UNITS1 / EHYB_PB_UNITS2 = work units aimed at per pass)
-    const int64_t env_u1 = [] { const char* e = getenv("EHYB_PB_UNITS1"); return e ? atoll(e) : 0ll; }();
-    const int64_t env_u2 = [] { const char* e = getenv("EHYB_PB_UNITS2"); return e ? atoll(e) : 0ll; }();
-    const int64_t target = std::min<int64_t>(std::max<int64_t>(nnz_er / (env_u2 > 0 ? env_u2 : 2048), 4096), 1 << 20);
+    // (cfg.er_units1 / er_units2 = work units aimed at per pass: tools/panel_sweep.py)
+    const int64_t target = std::min<int64_t>(std::max<int64_t>(nnz_er / cfg.er_units2, 4096), 1 << 20);
     std::vector<int32_t> rb_first;  // first row (plan numbering) of every block, + end
     std::vector<int32_t> rb_of_row((size_t)nrows);
     // pb_assign: rows of partitions without a window get y from pass 2 alone, so a block never mixes them with
@@ -247,7 +245,7 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
 
     // ---- work units
     // pass 1: {first column, columns, first entry, end entry} -- chunks of a panel, multiples of 64 entries
-    const int64_t c1 = std::min<int64_t>(std::max<int64_t>((padded / (env_u1 > 0 ? env_u1 : 2048) + 63) / 64 * 64, 8192), 1 << 20);
+    const int64_t c1 = std::min<int64_t>(std::max<int64_t>((padded / cfg.er_units1 + 63) / 64 * 64, 8192), 1 << 20);
     L->pb_units1.clear();
     int64_t staged = 0;
     for (int p = 0; p < n_panels; ++p)

@@ -24,7 +24,7 @@ namespace ehyb {
 // R-MAT 2^22: the ELL launch took 100 us for 9.6 M entries (10.4 ns each: 40 % padding, 3.3 M halo
 // gathers) while the panel residual did 23.3 M in 142-155 us (6.4 ns each).  -> number of partitions
 // to move, flags per partition of the layout.
-int windows_that_do_not_pay(const HostLayout& H, std::vector<uint8_t>* to_er, int64_t* entries_moved)
+int windows_that_do_not_pay(const HostLayout& H, int pct, std::vector<uint8_t>* to_er, int64_t* entries_moved)
 {
     const int np = H.n_parts;
     to_er->assign((size_t)np, 0);
@@ -40,7 +40,6 @@ int windows_that_do_not_pay(const HostLayout& H, std::vector<uint8_t>* to_er, in
         if (entries == 0) continue;
         const int64_t halo = H.halo_ptr[p + 1] - H.halo_ptr[p];
         const int64_t window = 8 * stored[p] + 4 * words[p] + 8 * (int64_t)H.win_len[p] + 64 * halo;
-        const int64_t pct = [] { const char* e = getenv("EHYB_PRUNE_PCT"); return e ? atoll(e) : 110ll; }();  // tuning sweeps only
         if (window * 100 > 30 * entries * pct) {  // more than 10 % dearer than the panel form
             (*to_er)[p] = 1;
             ++count;
@@ -108,7 +107,7 @@ int ehyb_plan_create_host(const matrixCOO* m, int row_begin, int row_end, const 
         if (rc == EHYB_OK && P->host.er_panel && !P->host.sym && P->cfg.er_mode != 1 && P->cfg.ell_prune != 2) {
             std::vector<uint8_t> to_er;
             int64_t moved = 0;
-            if (windows_that_do_not_pay(P->host, &to_er, &moved) > 0) {
+            if (windows_that_do_not_pay(P->host, P->cfg.prune_pct, &to_er, &moved) > 0) {
                 // The windows that are left must carry the ELL launch: its staging of 160 KiB windows with thousands
                 // of gathered halo columns, for a few partitions on a few CUs, is a fixed cost.  Measured on R-MAT
                 // (tools/panel_sweep.py --prune-pct): 2^22 with 18 % of the entries left in windows 216 us, with none

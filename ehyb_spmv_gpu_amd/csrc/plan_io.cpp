@@ -17,7 +17,7 @@ using namespace ehyb;
 
 namespace {
 
-const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '8'};
+const char kMagic[8] = {'E', 'H', 'Y', 'B', 'P', 'L', 'N', '9'};
 const char kEnd[8] = {'E', 'H', 'Y', 'B', 'E', 'N', 'D', '4'};
 
 struct FileCloser {

@@ -247,6 +247,7 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
 
     // ---- partition (reordering.c:116-139 / 270-293)
     std::vector<int> part(n, 0);
+    std::vector<int> row_order;  // non-empty: the order the rows of a partition are numbered in (degree order)
     {
         std::vector<int64_t> xadj;
         std::vector<int> adj;
@@ -325,10 +326,9 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
             // by the capacity split below.
             std::vector<int> rowlen;
             std::vector<int> twin_group;  // compressed graph used: the group (node) of every row
-            bool weighted = false;
+            bool weighted = false, by_degree = false;
             // the multilevel scheme on the compressed graph where the rows come in groups with one column list
-            static const bool compress_env = [] { const char* e = getenv("EHYB_COMPRESS"); return !e || atoi(e) != 0; }();  // env: A/B only
-            const bool compress = compress_env && symmetric_pattern != 0 && (c.partitioner == EHYB_PART_AUTO || c.partitioner == EHYB_PART_MULTILEVEL) && n >= 4096;
+            const bool compress = c.graph_compress != 2 && symmetric_pattern != 0 && (c.partitioner == EHYB_PART_AUTO || c.partitioner == EHYB_PART_MULTILEVEL) && n >= 4096;
             if (c.sym_pairs == 1 && n >= 4 * nparts) {
                 rowlen.resize(n);
                 double sum = 0, sq = 0;
@@ -339,7 +339,7 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                 }
                 const double mean = sum / n, var = sq / n - mean * mean;
                 weighted = var > 0.09 * mean * mean;  // sigma above 30 % of the mean (uniform stand-in: 15 %)
-                if (const char* e = getenv("EHYB_FORCE_WEIGHTED")) weighted = atoi(e) != 0;  // env: tuning sweeps only
+                if (c.balance != 0) weighted = c.balance == 1;  // tuning sweeps
                 if (weighted) {
                     int maxw = 1;
                     for (int i = 0; i < n; ++i) maxw = std::max(maxw, rowlen[i]);
@@ -351,7 +351,7 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                     // is the number wanted less a margin of 1/64 for the pieces a bisection leaves over.
                     if (nparts >= kNumCU) {
                         const double rows_cap = std::max(64, c.part_rows);
-                        const int margin = [&] { const char* e = getenv("EHYB_REQ_MARGIN"); return e ? atoi(e) : std::max(2, nparts / 64); }();  // env: tuning sweeps only
+                        const int margin = c.req_margin > 0 ? c.req_margin : (c.req_margin < 0 ? 0 : std::max(2, nparts / 64));
                         const double target = nparts - margin;
                         if ((double)n / rows_cap < target) {
                             double lo = sum / nparts, hi = sum;
@@ -372,15 +372,16 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                     rc = EHYB_OK;
                     if (compress) rc = partition_compressed(m, xadj, adj, rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut, &done, &twin_group);
                     if (rc == EHYB_OK && !done)
-                        rc = partition_graph(n, xadj.data(), adj.data(), rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut);
+                        rc = partition_graph(n, xadj.data(), adj.data(), rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut, &by_degree);
                 }
             }
             if (!weighted) {
                 bool done = false;
                 rc = EHYB_OK;
                 if (compress) rc = partition_compressed(m, xadj, adj, nullptr, nparts, cap, c, part.data(), &cut, &done, &twin_group);
-                if (rc == EHYB_OK && !done) rc = partition_graph(n, xadj.data(), adj.data(), nullptr, nparts, cap, c, part.data(), &cut);
+                if (rc == EHYB_OK && !done) rc = partition_graph(n, xadj.data(), adj.data(), nullptr, nparts, cap, c, part.data(), &cut, &by_degree);
             }
+            if (rc == EHYB_OK && by_degree) degree_order(n, xadj.data(), &row_order);
             if (c.verbose) printf("k-way partition time is %ld us\n", (long)((wall_seconds() - t0) * 1e6));
             // Capacity-aware refinement (halo window only): a partition whose own rows plus the
             // distinct outside columns it references do not fit the LDS window would spill
@@ -504,7 +505,10 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
     std::vector<int> rows_of(n);
     {
         std::vector<int> fill(pb, pb + nparts);
-        for (int i = 0; i < n; ++i) rows_of[fill[part[i]]++] = i;
+        if (row_order.empty())
+            for (int i = 0; i < n; ++i) rows_of[fill[part[i]]++] = i;
+        else  // blocks of the degree order: the hubs first inside every block too
+            for (int r = 0; r < n; ++r) rows_of[fill[part[row_order[r]]]++] = row_order[r];
     }
     if (c.window_mode == EHYB_WINDOW_HALO) {
         // The sort key is "entries the ELL kernel will take".  With a halo window that is the

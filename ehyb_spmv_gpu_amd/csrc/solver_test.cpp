@@ -60,7 +60,8 @@ static std::vector<long long> split_numbers(const char* s)
 
 static void usage()
 {
-    printf("usage: solver_test -i <iters> (-m <name> | -g <spec>) [-w 1|2] [-l lds_doubles] [-T threads] [-c plan.cache] [-S 0|1] [-v]\n"
+    printf("usage: solver_test -i <iters> (-m <name> | -g <spec>) [-w 1|2] [-l lds_doubles] [-T threads] [-c plan.cache] [-S 0|1] [-X 0|1] [-I items_per_cu] [-v]\n"
+           "  -X 0|1    work items in blockIdx order / one contiguous run of items per XCD (default)\n"
            "  -S 0|1    symmetric pair storage off / on (default: on for symmetric matrices of >= 45056 rows --\n"
            "            each in-partition pair a_ij == a_ji is stored once)\n"
            "  -c file   plan cache: reuse the permutation + layout saved by an earlier run on the same matrix,\n"
@@ -85,7 +86,7 @@ int main(int argc, char* argv[])
 
     int oc;
     std::string cache;
-    while ((oc = getopt(argc, argv, "m:i:r:t:f:p:g:w:l:T:c:S:vh")) != -1) {
+    while ((oc = getopt(argc, argv, "m:i:r:t:f:p:g:w:l:T:c:S:X:I:vh")) != -1) {
         switch (oc) {
             case 'c': cache = optarg; break;
             case 'S': sym_opt = atoi(optarg); break;
@@ -106,6 +107,8 @@ int main(int argc, char* argv[])
             case 'w': cfg.window_mode = atoi(optarg); break;
             case 'l': cfg.lds_doubles = atoi(optarg); cfg.part_rows = 0; break;
             case 'T': cfg.threads = atoi(optarg); break;
+            case 'X': cfg.xcd_map = atoi(optarg) ? 1 : 2; break;
+            case 'I': cfg.items_per_cu = atoi(optarg); break;
             case 'v': cfg.verbose = 1; break;
             case 'h': usage(); return 0;
             default: printf("option/arguments error!\n"); usage(); return 2;

@@ -14,7 +14,7 @@ from ._lib import Config, MatrixCOO, Stats
 
 EHYB_WINDOW_REFERENCE = 1
 EHYB_WINDOW_HALO = 2
-EHYB_PART_AUTO, EHYB_PART_CONTIGUOUS, EHYB_PART_MULTILEVEL, EHYB_PART_MTMETIS = 0, 1, 2, 3
+EHYB_PART_AUTO, EHYB_PART_CONTIGUOUS, EHYB_PART_MULTILEVEL, EHYB_PART_MTMETIS, EHYB_PART_DEGREE = 0, 1, 2, 3, 4
 
 ARRAYS = {
     "part_boundary": (0, np.int32), "win_len": (1, np.int32), "halo_ptr": (2, np.int32),

@@ -58,7 +58,11 @@ const char* ehyb_version(void);
 
 /* ------------------------------------------------------------------ config */
 enum { EHYB_WINDOW_DEFAULT = 0, EHYB_WINDOW_REFERENCE = 1, EHYB_WINDOW_HALO = 2 };
-enum { EHYB_PART_AUTO = 0, EHYB_PART_CONTIGUOUS = 1, EHYB_PART_MULTILEVEL = 2, EHYB_PART_MTMETIS = 3 };
+enum { EHYB_PART_AUTO = 0, EHYB_PART_CONTIGUOUS = 1, EHYB_PART_MULTILEVEL = 2, EHYB_PART_MTMETIS = 3,
+       EHYB_PART_DEGREE = 4 /* rows in order of falling degree (row + column entries), cut into equal blocks: what
+                               EHYB_PART_AUTO falls back to on graphs a k-way partitioner finds nothing to cut in
+                               (power-law: R-MAT) -- the hub columns then share x panels and the hub rows share row
+                               blocks of the panel-form residual (er_panel.cpp) */ };
 
 #define EHYB_LDS_MAX_DOUBLES 20480   /* 160 KiB of LDS per workgroup on gfx950 */
 #define EHYB_SLAB_ROWS       64      /* one row per lane of a wave64           */
@@ -148,6 +152,30 @@ typedef struct ehyb_config {
                               was filled from (4 B per stored value on the host, and on the device from the first
                               ehyb_plan_set_values on): the NUMERIC phase of the build can then be repeated on the
                               GPU for new values on the same pattern.  0 = off                                 */
+    /* ---- tuning knobs of the A/B tools (tools/); every one of them used to be an environment variable of
+       the library.  The library reads NO tuning variable from the environment any more (the one variable left,
+       EHYB_MTMETIS_LIB, names a shared object to load the optional mt-metis backend from). */
+    int32_t prune_pct;     /* ell_prune: a window is given up when it costs more than this share (per cent) of what
+                              the panel form would cost for its entries; 0 = 110                                */
+    int32_t er_units1;     /* panel form: work units pass 1 aims at (0 = 2048)                                 */
+    int32_t er_units2;     /* panel form: row blocks pass 2 aims at (0 = 2048)                                 */
+    int32_t graph_compress;/* 0/1 = the k-way partitioner works on the compressed graph where rows come in groups with one
+                              column list (the unknowns of a node), 2 = never.  Plain storage (sym_pairs off) ignores it
+                              by default: see reorder.cpp                                                        */
+    int32_t balance;       /* symmetric pair storage, what the partitions are balanced on: 0 = rows unless the row lengths
+                              vary by more than 30 % (sigma/mean), 1 = entries, 2 = rows                         */
+    int32_t req_margin;    /* entry-balanced partitions of a graded mesh: partitions asked for = nParts - margin; 0 =
+                              max(2, nParts/64), -1 = no margin                                                   */
+    int32_t sym_slack_permille; /* ehyb_sizing, symmetric pair storage: rows a partition may hold above the mean, in
+                              1/1000 (0 = 30)                                                                     */
+    int32_t xcd_map;       /* 0/1 = workgroup b takes the work item that gives every XCD one contiguous run of items
+                              (plain storage; the panel form's pass 1: the units of one x panel on one XCD), 2 = items
+                              in blockIdx order                                                                   */
+    int32_t graphs;        /* 0/1 = the timed loop of ehyb_spmv_bench and the iterations of ehyb_cg/ehyb_pcg are replayed
+                              from hipGraphs, 2 = plain launches (A/B, debugging)                                */
+    int32_t er_sums;       /* panel form, pass 1: how the products of one row inside a 64-entry chunk are added up: 0/1 =
+                              segmented DPP scan in registers, 2 = ds_add_f64 into per-wave LDS words (round 2's way) */
+    int32_t reserved[30];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);

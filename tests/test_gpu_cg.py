@@ -136,7 +136,7 @@ def test_cg_stops_at_max_iter_and_reports_breakdown(E, O, gpu):
 def test_cg_is_reproducible_and_graph_replay_changes_nothing(E, O, gpu, monkeypatch):
     """The dot products are summed in a fixed order (per-workgroup partials, no atomics), so with
     plain storage two solves agree bit for bit -- and so does a solve issued launch by launch
-    (EHYB_CG_GRAPH=0) instead of replaying the captured pair of iterations."""
+    (cfg.graphs = 2) instead of replaying the captured pair of iterations."""
     A = spd_matrix(110, 90, 2500, 4)
     cfg = E.make_config(lds_doubles=2048, sym_pairs=0)
     m = E.Matrix.from_csr(A.indptr, A.indices, A.data, cfg, symmetric=True)
@@ -145,8 +145,8 @@ def test_cg_is_reproducible_and_graph_replay_changes_nothing(E, O, gpu, monkeypa
     b = E.vector_reorder(O.x_glibc(A.shape[0]) + 0.1, m.reorder_list)
     x1, it1, rel1 = plan.cg(b, max_iter=41, rtol=1e-30, check_every=8)
     x2, it2, rel2 = plan.cg(b, max_iter=41, rtol=1e-30, check_every=8)
-    monkeypatch.setenv("EHYB_CG_GRAPH", "0")
-    x3, it3, rel3 = plan.cg(b, max_iter=41, rtol=1e-30, check_every=8)
+    plain = E.Plan(m, E.make_config(lds_doubles=2048, sym_pairs=0, graphs=2))
+    x3, it3, rel3 = plain.cg(b, max_iter=41, rtol=1e-30, check_every=8)
     assert it1 == it2 == it3 == 41
     assert np.array_equal(x1, x2) and rel1 == rel2
     assert np.array_equal(x1, x3) and rel1 == rel3

@@ -67,13 +67,12 @@ def test_cli_plan_cache_miss_then_hit(E, gpu, tmp_path):
 @pytest.mark.parametrize("gen,items", [("fem3d:99000:3:30:30:13500:1", 700), ("rmat:15:300000", 13)],
                          ids=["fem3d-many-items", "rmat-odd-items"])
 def test_cli_item_order_switch(gpu, tmp_path, gen, items):
-    """EHYB_XCD_MAP=0/1: workgroups take the work items in blockIdx order or one contiguous run per
+    """solver_test -X 0/1 (cfg.xcd_map): workgroups take the work items in blockIdx order or one contiguous run per
     XCD (the default).  Either way every item is taken exactly once -- including item counts that
     are not a multiple of 8 -- so both runs pass the harness's comparison with the CPU product."""
     for xcd in ("0", "1"):
-        env = dict(os.environ, EHYB_XCD_MAP=xcd, EHYB_ITEMS_PER_CU=str(max(1, items // 256)))
-        p = subprocess.run([BIN, "-i", "5", "-g", gen, "-l", "2048"], cwd=tmp_path, capture_output=True, text=True,
-                           timeout=600, env=env)
+        p = subprocess.run([BIN, "-i", "5", "-g", gen, "-l", "2048", "-X", xcd, "-I", str(max(1, items // 256))], cwd=tmp_path,
+                           capture_output=True, text=True, timeout=600)
         assert p.returncode == 0 and "PASSED" in p.stdout, (xcd, p.stdout[-1500:] + p.stderr[-1500:])
 
 

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Time per iteration of the device-resident CG (ehyb_pcg) on a bench workload made positive
 definite (the generator's diagonal is replaced by row sum of |a_ij| + 1), with the iteration
-replayed from a hipGraph and with plain launches (EHYB_CG_GRAPH=0), beside the SpMV alone.
+replayed from a hipGraph and with plain launches (cfg.graphs = 2), beside the SpMV alone.
 
 usage: python tools/cg_time.py [--workload audikw_1-like] [--iters 20,120] [--sym-pairs 1]
 """
@@ -44,8 +44,9 @@ def main():
     print(f"# {args.workload}: n={m.n} nnz={m.nnz} sym_pairs={st['sym_pairs']}; SpMV alone {spmv_us:.1f} us")
     lo, hi = [int(v) for v in args.iters.split(",")]
     inv = 1.0 / diag if args.jacobi else None
+    plans = {"1": plan, "0": E.Plan(m, E.make_config(sym_pairs=args.sym_pairs, graphs=2))}
     for graph in ("1", "0"):
-        os.environ["EHYB_CG_GRAPH"] = graph
+        plan = plans[graph]
         plan.cg(b, max_iter=10, rtol=0.0, check_every=10, inv_diag=inv)  # warm
         t = {}
         for it in (lo, hi):

@@ -23,8 +23,8 @@ def main():
     ap.add_argument("--block-rows", default="2048,4096,8192")
     ap.add_argument("--iters", type=int, default=20)
     ap.add_argument("--probes", default="0,2")
-    ap.add_argument("--units2", default="0", help="EHYB_PB_UNITS2 values (row blocks aimed at; 0 = default 2048)")
-    ap.add_argument("--prune-pct", default="110", help="EHYB_PRUNE_PCT values: a window is given up when it costs more than this share of the panel form")
+    ap.add_argument("--units2", default="0", help="cfg.er_units2 values (row blocks aimed at; 0 = default 2048)")
+    ap.add_argument("--prune-pct", default="110", help="cfg.prune_pct values: a window is given up when it costs more than this share of the panel form")
     args = ap.parse_args()
     import bench as B
     import ehyb_spmv_gpu_amd as E
@@ -48,9 +48,7 @@ def main():
       for br in [int(v) for v in args.block_rows.split(",")]:
        for u2 in [int(v) for v in args.units2.split(",")]:
         for pct in [int(v) for v in args.prune_pct.split(",")]:
-            os.environ["EHYB_PB_UNITS2"] = str(u2)
-            os.environ["EHYB_PRUNE_PCT"] = str(pct)
-            cfg = E.make_config(partitioner=part, fuse_er=2, er_mode=2, er_panel_cols=pc, er_block_rows=br)
+            cfg = E.make_config(partitioner=part, fuse_er=2, er_mode=2, er_panel_cols=pc, er_block_rows=br, er_units2=u2, prune_pct=pct)
             t0 = time.time()
             plan = E.Plan(m, cfg)
             t_plan = time.time() - t0

@@ -22,6 +22,7 @@ def main():
     ap.add_argument("--threads", type=int, default=1024)
     ap.add_argument("--items", type=int, default=2)
     ap.add_argument("--variant", type=int, default=0, help="0/1 LDS slab counter, 3 static round-robin")
+    ap.add_argument("--xcd-map", type=int, default=1, help="1 = every XCD takes one contiguous run of items (default), 2 = blockIdx order")
     args = ap.parse_args()
     import numpy as np
 
@@ -36,7 +37,7 @@ def main():
         print(f"streaming read of {mb} MiB: {bw.value:.0f} GB/s")
 
     gen, gargs, _ = B.WORKLOADS[args.workload]
-    kw = dict(lds_doubles=args.lds, threads=args.threads, items_per_cu=args.items, ell_variant=args.variant, sym_pairs=args.sym)
+    kw = dict(lds_doubles=args.lds, threads=args.threads, items_per_cu=args.items, ell_variant=args.variant, sym_pairs=args.sym, xcd_map=args.xcd_map)
     if args.part_rows:
         kw["part_rows"] = args.part_rows
     cfg = E.make_config(**kw)
@@ -62,7 +63,7 @@ def main():
     start, staged, end, xcc = (s[:, 0] - t0) / 100.0, (s[:, 1] - t0) / 100.0, (s[:, 2] - t0) / 100.0, s[:, 3]
     items = plan.array("items").reshape(-1, 8)
     # plain storage: workgroup b took item xcd_item(b) (ehyb_hip.hip); symmetric pairs: item b (heaviest first)
-    if os.environ.get("EHYB_XCD_MAP", "1") != "0" and st["sym_pairs"] == 0:
+    if args.xcd_map != 2 and st["sym_pairs"] == 0:
         b = np.arange(n_items)
         k, j, chunk, rem = b & 7, b >> 3, n_items >> 3, n_items & 7
         items = items[k * chunk + np.minimum(k, rem) + j]
