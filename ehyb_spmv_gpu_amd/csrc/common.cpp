@@ -321,22 +321,29 @@ void vectorRecover(const int dimension, const double* v_rodr, double* v, const i
 // reference's own reorder step rewrites the arrays it is handed.  matrixReorder is only ever called
 // for matrices read from a symmetric file (solver_test.c:369-370), so it sizes the partitions for
 // symmetric pair storage (from EHYB_SYM_MIN_ROWS rows up) -- spmvGPuEHYB then recognises them.
-// partBoundary: the driver callocs `dimension` ints (solver_test.c:42,146).
+// partBoundary: allocated HERE, as the reference's own matrixReorder[_unsym] does (reordering.c:44,234: malloc of
+// `dimension` ints over whatever the caller left in the field -- its driver's calloc, solver_test.c:43,144, is simply
+// dropped; NULL is legal).  The partition count written back may exceed the caller's nParts, so the caller's own
+// array, whatever its size, is never written to.  dimension + 1 ints: room for one partition per row.
 static void reorder_dropin(matrixCOO* m, int symmetric, const char* who)
 {
     if (!m || m->dimension <= 0) {
         fprintf(stderr, "%s: null or empty matrix\n", who);
         exit(1);
     }
+    m->partBoundary = (int*)malloc(sizeof(int) * ((size_t)m->dimension + 1));
+    if (!m->partBoundary) {
+        fprintf(stderr, "%s: out of memory\n", who);
+        exit(1);
+    }
     ehyb_config cfg;
     memset(&cfg, 0, sizeof cfg);
     cfg.sym_pairs = (symmetric && m->dimension >= EHYB_SYM_MIN_ROWS) ? 1 : 0;
-    cfg.part_boundary_cap = m->dimension;
+    cfg.part_boundary_cap = m->dimension + 1;
     int np = 1, cache = 0, kpp = 1;
     int rc = ehyb_sizing(m->dimension, &cfg, &np, &cache, &kpp);
     if (rc == EHYB_OK) {
-        // tiny matrices: the boundaries must fit the driver's array
-        m->nParts = std::min(np, std::max(1, m->dimension - 1));
+        m->nParts = std::min(np, m->dimension);
         m->vectorCacheSize = (uint16_t)std::min(cache, 65535);
         m->kernelPerPart = (int16_t)kpp;
         rc = ehyb_matrix_reorder(m, symmetric, &cfg);

@@ -16,7 +16,7 @@
 //                           `order` composes the caller's entry order before ehyb_matrix_reorder with the
 //                           permuted one, so the V scatter of the reorder step is folded into the same gather.
 //   ehyb_fill_check_kernel  before anything is written: every order[] value in range, and with symmetric
-//                           pair storage V[a_ij] bitwise equal to V[a_ji] wherever one slot stands for both.
+//                           pair storage V[a_ij] == V[a_ji] wherever one slot stands for both.
 //
 // HBM-bound and trivially so: 4 B (map) + 8 B gathered (the layout follows the permuted row order, so the
 // gathers of a wave fall into a few lines) + 8 B written per slot.
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(kFillThreads) void ehyb_fill_kernel(double* __restr
     }
 }
 
-// bad[0] += order values outside [0, count);  bad[1] += slots whose two entries differ bitwise
+// bad[0] += order values outside [0, count);  bad[1] += slots whose two entries differ (a_ij == a_ji is the test the layout builder paired them with)
 __global__ __launch_bounds__(kFillThreads) void ehyb_fill_check_kernel(const int32_t* __restrict__ src, const int32_t* __restrict__ src2, long long n,
                                                                        const double* __restrict__ V, const int32_t* __restrict__ order, long long n_order,
                                                                        long long count, unsigned long long* __restrict__ bad)
@@ -87,7 +87,7 @@ __global__ __launch_bounds__(kFillThreads) void ehyb_fill_check_kernel(const int
                 a = order[a], b = order[b];
                 if ((unsigned long long)(long long)a >= (unsigned long long)count || (unsigned long long)(long long)b >= (unsigned long long)count) continue;  // counted above
             }
-            pairs += __double_as_longlong(V[a]) != __double_as_longlong(V[b]);
+            pairs += !(V[a] == V[b]);  // the builder's own predicate (sym_orient_partition): +0.0 and -0.0 form a pair
         }
     if (range) atomicAdd(&bad[0], range);
     if (pairs) atomicAdd(&bad[1], pairs);

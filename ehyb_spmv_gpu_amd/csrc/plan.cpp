@@ -120,9 +120,20 @@ int ehyb_plan_create_host(const matrixCOO* m, int row_begin, int row_end, const 
                     moved = P->host.stats.nnz_ell;
                 }
                 if (P->cfg.verbose) printf("%lld ELL entries sit in windows that cost more than the panel residual: rebuilt with those partitions in the residual\n", (long long)moved);
+                // A failure of the rebuild (memory: both layouts are alive here; the 32-bit limits of the panel builder once
+                // every ELL entry has moved) is not a failure of the plan: the first layout is complete and valid.
                 HostLayout again;
-                rc = build_layout(m, row_begin, row_end, P->cfg, &again, &to_er);
-                if (rc == EHYB_OK && again.er_panel) P->host = std::move(again);
+                int rc2;
+                try {
+                    rc2 = build_layout(m, row_begin, row_end, P->cfg, &again, &to_er);
+                } catch (const std::bad_alloc&) {
+                    rc2 = EHYB_ERR_ALLOC;
+                }
+                if (rc2 == EHYB_OK && again.er_panel)
+                    P->host = std::move(again);
+                else if (P->cfg.verbose)
+                    printf("rebuild without those windows failed (%d): keeping the first layout\n", rc2);
+                clear_error();
             }
         }
     } catch (const std::bad_alloc&) {

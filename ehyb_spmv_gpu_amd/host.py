@@ -224,7 +224,14 @@ class Matrix:
         (solver_test.c:369-374; the C++-linkage symbols of include/reordering.h): no configuration,
         nParts / vectorCacheSize as the caller left them are only hints."""
         name = "_Z13matrixReorderP10_matrixCOO" if self.symmetric else "_Z19matrixReorder_unsymP10_matrixCOO"
+        old = C.cast(self.c.partBoundary, C.c_void_p).value
+        if not hasattr(self, "_lib_part_boundary"):
+            self._lib_part_boundary = old          # first call: what the reader / generator allocated
         getattr(self.lib, name)(C.byref(self.c))
+        # like the reference (reordering.c:44,234) the call mallocs a new partBoundary over the field; the array this
+        # library's reader/generator had put there is ours to release
+        if old and old == getattr(self, "_lib_part_boundary", None) and old != C.cast(self.c.partBoundary, C.c_void_p).value:
+            C.CDLL(None).free(C.c_void_p(old))
         return self
 
     def key(self):

@@ -418,7 +418,7 @@ int spmvGPuEHYB_cfg(matrixCOO* localMatrix, const double* vectorIn, double* vect
  *                ehyb_matrix_reorder with entry_order[k] = place of reordered entry k in `values`
  *                (ehyb_entry_order computes it).
  *   on_device    0: values / entry_order are host arrays (uploaded for the call);  1: both are device pointers.
- * With symmetric pair storage a slot stands for a_ij AND a_ji: the new values must be bitwise equal there; they
+ * With symmetric pair storage a slot stands for a_ij AND a_ji: the new values must be equal there (a_ij == a_ji, the test the builder paired them with); they
  * are checked on the device first and the plan is left untouched (EHYB_ERR_ARG) if any pair differs.
  * After a successful call the HOST copy of the value arrays (ehyb_plan_host_array, ehyb_plan_save) is stale:
  * ehyb_plan_save refuses such a plan.  Synchronous with respect to `stream` when on_device = 0.

@@ -11,7 +11,9 @@
 #include "spmv.h"
 
 #ifdef __cplusplus
-/* P*A*P^T for a symmetric-pattern matrix (reordering.c:231-378). */
+/* P*A*P^T for a symmetric-pattern matrix (reordering.c:231-378).  Like the reference, both calls replace
+ * m->partBoundary by a fresh malloc() (dimension + 1 ints here, dimension there: reordering.c:44,234) -- the
+ * caller's pointer, NULL included, is never written through -- and exit(1) on failure. */
 void matrixReorder(matrixCOO* localMatrixCOO);
 /* Same after symmetrising the pattern (reordering.c:41-228). */
 void matrixReorder_unsym(matrixCOO* localMatrixCOO);

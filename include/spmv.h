@@ -56,7 +56,10 @@ typedef struct _cb {
  *  numInRow2[n]    entries per row whose column falls inside the row's partition window
  *  I,J,V           row, column, value (0-based, permuted numbering)
  *  diag            diagonal (symmetric reader only; unused by the callee)
- *  partBoundary    first permuted row of each partition
+ *  partBoundary    first permuted row of each partition.  matrixReorder / matrixReorder_unsym ALLOCATE it
+ *                  (malloc, dimension + 1 ints) over whatever the field held, as reordering.c:44,234 do, and
+ *                  may write back a larger nParts than they were handed (sized for 256 CUs);
+ *                  ehyb_matrix_reorder writes into the caller's array (see ehyb_config.part_boundary_cap)
  *  reorderList     reorderList[old] = new
  */
 typedef struct _matrixCOO {
@@ -111,7 +114,9 @@ void spmvGPuEHYB(matrixCOO* localMatrix,
                  const double* vectorIn, double* vectorOut,
                  const int MAXIter, int* realIter);
 
-/* Additive variant with a status code (0 = ok, non-zero = ehyb_status of ehyb.h). */
+/* Additive variant with a status code (0 = ok, non-zero = ehyb_status of ehyb.h; text via ehyb_last_error).
+ * PREFER THIS ONE in a solver: spmvGPuEHYB keeps the reference's void signature and therefore can only
+ * exit() the caller's process when something fails (as the reference's converter does, convert.c:122-125). */
 int spmvGPuEHYB_status(matrixCOO* localMatrix,
                        const double* vectorIn, double* vectorOut,
                        const int MAXIter, int* realIter);

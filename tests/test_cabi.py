@@ -153,3 +153,63 @@ def test_product_does_not_touch_the_oracle():
                 assert "oracle" not in text.lower(), f"{f} mentions the oracle"
     out = subprocess.run(["ldd", os.path.join(pkg, "libehyb.so")], capture_output=True, text=True).stdout
     assert "oracle" not in out
+
+
+_ENV_KNOBS = {"EHYB_PB_PROBE": "3", "EHYB_PRUNE_PCT": "50", "EHYB_PB_UNITS1": "7", "EHYB_PB_UNITS2": "5", "EHYB_COMPRESS": "0",
+              "EHYB_FORCE_WEIGHTED": "1", "EHYB_REQ_MARGIN": "9", "EHYB_SYM_SLACK_PERMILLE": "200", "EHYB_XCD_MAP": "0",
+              "EHYB_BENCH_GRAPH": "0", "EHYB_CG_GRAPH": "0", "EHYB_ER_SUMS": "2", "EHYB_PARTITIONER": "1"}
+
+_DIGEST_SNIPPET = r"""
+import hashlib, sys
+sys.path.insert(0, %r)
+import ehyb_spmv_gpu_amd as E
+h = hashlib.sha256()
+for gen, kw in ((("fem3d", 60000, 3, 28, 28, 13500, 1, 1), dict(sym_pairs=1)), (("rmat", 16, 1 << 19, 3), dict(lds_doubles=2048, er_mode=2))):
+    cfg = E.make_config(**kw)
+    m = E.Matrix.generate(*gen, cfg=cfg)
+    m.reorder(cfg)
+    h.update(m.reorder_list.tobytes())
+    plan = E.Plan(m, cfg, upload=False)
+    for name in sorted(E.host.ARRAYS):
+        h.update(plan.array(name).tobytes())
+print(h.hexdigest())
+"""
+
+
+def test_no_tuning_variable_is_read_from_the_environment():
+    """Every tuning knob is an ehyb_config field: the only getenv left in the library names the optional mt-metis
+    shared object, and the permutation and every array of a plan come out the same whatever EHYB_* variables
+    the process carries (round 2 read twelve of them; one -- EHYB_PB_PROBE -- made the multiply wrong on purpose)."""
+    import re
+    import sys
+
+    src = os.path.join(ROOT, "ehyb_spmv_gpu_amd", "csrc")
+    hits = []
+    for f in sorted(os.listdir(src)):
+        if f.endswith((".cpp", ".hip", ".h")):
+            hits += [(f, m) for m in re.findall(r'getenv\("([A-Z_]+)"\)', open(os.path.join(src, f)).read())]
+    assert hits == [("reorder.cpp", "EHYB_MTMETIS_LIB")], hits
+    code = _DIGEST_SNIPPET % ROOT
+    clean = {k: v for k, v in os.environ.items() if not k.startswith("EHYB_")}
+    a = subprocess.run([sys.executable, "-c", code], env=clean, capture_output=True, text=True, timeout=600)
+    b = subprocess.run([sys.executable, "-c", code], env=dict(clean, **_ENV_KNOBS), capture_output=True, text=True, timeout=600)
+    assert a.returncode == 0 and b.returncode == 0, a.stderr[-800:] + b.stderr[-800:]
+    assert a.stdout.strip() == b.stdout.strip() and len(a.stdout.strip()) == 64
+
+
+@pytest.mark.gpu
+def test_multiply_ignores_the_environment(E, O, gpu, monkeypatch):
+    """The panel-form multiply with round 2's probe variable (and the rest) set in the environment: still right."""
+    for k, v in _ENV_KNOBS.items():
+        monkeypatch.setenv(k, v)
+    cfg = E.make_config(lds_doubles=2048, er_mode=2, fuse_er=2)
+    m = E.Matrix.generate("rmat", 16, 1 << 19, 3, cfg=cfg)
+    x = O.x_glibc(m.n)
+    y_ref = O.spmv_coo(m.n, m.I, m.J, m.V, x)
+    scale = O.abs_rowsum(m.n, m.I, m.J, m.V, x)
+    m.reorder(cfg)
+    plan = E.Plan(m, cfg)
+    assert plan.stats["er_partials"] > 0
+    y = E.vector_recover(plan.spmv_host(E.vector_reorder(x, m.reorder_list)), m.reorder_list)
+    bad, worst = O.check_tolerance(y, y_ref, scale)
+    assert bad == 0, worst

@@ -92,6 +92,32 @@ def test_matrix_reorder_resizes_the_reference_hints(E):
     del lib
 
 
+def test_matrix_reorder_allocates_part_boundary_like_the_reference(E):
+    """matrixReorder / matrixReorder_unsym malloc m->partBoundary themselves (reordering.c:44,234): a caller that
+    sized its own array for ITS nParts (the driver's 10 partitions) or passes NULL must not see a write through its
+    pointer, whatever partition count comes back."""
+    for gen, sym in ((("fem3d", 60000, 3, 28, 28, 13500, 1, 1), True), (("rmat", 15, 1 << 18, 3), False)):
+        m = E.Matrix.generate(*gen)
+        m.symmetric = sym
+        lib_owned = m._lib_part_boundary = C.cast(m.c.partBoundary, C.c_void_p).value
+        small = (C.c_int * 16)(*([-7] * 16))          # 10 partitions + 1, plus guard words
+        m.c.nParts, m.c.vectorCacheSize, m.c.kernelPerPart = 10, 8192, 8
+        m.c.partBoundary = C.cast(small, C.POINTER(C.c_int))
+        m.reorder_dropin()
+        assert list(small) == [-7] * 16
+        assert C.cast(m.c.partBoundary, C.c_void_p).value != C.addressof(small)
+        pb = m.part_boundary
+        assert m.c.nParts >= 1 and pb[0] == 0 and pb[-1] == m.n and np.all(np.diff(pb) >= 0)
+        C.CDLL(None).free(C.c_void_p(lib_owned))      # the generator's array, replaced above by `small`
+        # NULL is legal too
+        m2 = E.Matrix.generate(*gen)
+        m2.symmetric = sym
+        C.CDLL(None).free(C.cast(m2.c.partBoundary, C.c_void_p))
+        m2.c.partBoundary = C.cast(None, C.POINTER(C.c_int))
+        m2.reorder_dropin()
+        assert m2.part_boundary[-1] == m2.n
+
+
 def test_part_boundary_capacity_is_respected(E):
     """A C caller that holds exactly nParts+1 boundaries (the reference contract, spmv.h:31) and does
     not say otherwise never gets more partitions back; with a stated capacity the capacity split may
