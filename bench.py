@@ -132,15 +132,17 @@ def timed_steps(step, args, torch, dist, world, dev):
     t_start = time.perf_counter()
     for _ in range(args.steps):
         step()
+    t_issued = time.perf_counter()   # the host has ENQUEUED every step (it runs ahead of the device unless it is the slower one)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t_start
+    args.host_us_per_step = (t_issued - t_start) / args.steps * 1e6
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        t = torch.tensor([elapsed, args.host_us_per_step], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        elapsed, args.host_us_per_step = float(t[0].item()), float(t[1].item())
     return elapsed
 
 
@@ -194,7 +196,7 @@ def run_weak(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     sh.set_x_local(x[r0:r1])
     st = sh.plan.stats
     log(f"[bench] rank 0: reorder + plan in {time.time() - t0:.1f}s: ell {st['nnz_ell']} residual {st['nnz_er']} "
-        f"ghost slots {L.n_ghost} (receives from {int((L.recv_counts > 0).sum())} ranks)")
+        f"ghost slots {L.n_ghost} (receives from {int((L.recv_counts.sum(axis=0) > 0).sum())} ranks)")
     elapsed = timed_steps(sh.step, args, torch, dist, world, dev)
     # parity of what was just timed, every rank on its own rows
     bad, worst = O.check_tolerance(sh.y_local(), y_cpu, scale)
@@ -277,10 +279,11 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     y_cpu = O.spmv_coo(n, I, J, V, x)[r0:r1]      # checker (not timed): the oracle on this rank's rows
     scale = O.abs_rowsum(n, I, J, V, x)[r0:r1]
     t0 = time.time()
-    L = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, symmetric=symmetric, exchange=args.exchange)
+    shares = [float(v) for v in args.chunk_shares.split(",")] if args.chunk_shares else None
+    L = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, symmetric=symmetric, exchange=args.exchange, chunks=args.chunks, chunk_shares=shares)
     del I, J
     if args.exchange == "halo":
-        sh = D.HaloSpmv(L, dev, overlap=not args.no_overlap, stage_on_cpu=stage_on_cpu)
+        sh = D.HaloSpmv(L, dev, overlap=not args.no_overlap, stage_on_cpu=stage_on_cpu, mode=args.exchange_mode)
     else:
         sh = D.GatherSpmv(L, dev, overlap=not args.no_overlap, stage_on_cpu=stage_on_cpu)
     sh.set_x_local(x[r0:r1])
@@ -291,11 +294,18 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     bad, worst = O.check_tolerance(sh.y_local(), y_cpu, scale)
     bad, worst = all_ranks_agree_or_exit(bad, worst, torch, dist, world, dev, "strong scaling")
     # per-rank time of the local multiply alone (no exchange), max over ranks: what is left is the exchange
-    sh_local_ms = sh.time_local(args.steps)
-    stats = torch.tensor([float(L.n_ghost), float(sh_local_ms), float(len(V))], dtype=torch.float64, device=dev)
+    if args.exchange == "halo":
+        own_ms, sh_local_ms = sh.time_parts(args.steps)   # the part that needs the rank's own columns only, and the whole
+    else:
+        own_ms, sh_local_ms = 0.0, sh.time_local(args.steps)
+    stats = torch.tensor([float(L.n_ghost), float(sh_local_ms), float(len(V)), float(own_ms), float(L.nnz_own_cols)], dtype=torch.float64, device=dev)
     mx = stats.clone()
     dist.all_reduce(stats)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+    # who receives how much from whom, per exchange step: rows = receiving rank, chunks x peers doubles each
+    vol = torch.zeros(world, L.chunks * world, dtype=torch.float64, device=dev)
+    vol[rank] = torch.from_numpy(L.recv_counts.astype(np.float64).reshape(-1)).to(dev)
+    dist.all_reduce(vol)
     log(f"[bench] parity vs CPU oracle (all ranks, own rows): {bad} rows over 1e-12, worst {worst:.3e}")
     if rank == 0:
         ms = elapsed / args.steps * 1e3
@@ -310,11 +320,21 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
                        "lds_doubles": int(cfg.lds_doubles), "part_rows": int(cfg.part_rows), "threads": int(cfg.threads),
                        "exchange": ("RCCL all_gather_into_tensor of the x segments (padded to %d doubles each), overlapped with the ELL phase" % sh.seg_len)
                        if args.exchange == "allgather" else
-                       "halo: gather of the requested x entries + RCCL all_to_all_single into the ghost slots, overlapped with the ELL phase",
+                       "halo: gather of the requested x entries + one RCCL all_to_all_single per exchange step straight into the ghost "
+                       "columns; own-column panels and the panels of the chunks already delivered multiply while the next chunk travels",
                        "exchange_doubles_received_all_gpus": words,
+                       "exchange_steps": L.chunks, "exchange_mode": args.exchange_mode if args.exchange == "halo" else "all_gather_into_tensor",
+                       "pipelined": bool(args.exchange == "halo" and not args.no_overlap),
+                       "recv_doubles_by_rank_step_peer": [[[int(v) for v in row.reshape(L.chunks, world)[k].tolist()] for k in range(L.chunks)]
+                                                          for row in vol.cpu().numpy()] if world <= 8 else None,
                        "ghost_columns_per_gpu_max": int(mx[0].item()),
                        "functional_mode": "gloo, host-staged" if stage_on_cpu else None},
             "local_multiply_ms_max_over_ranks": round(float(mx[1].item()), 5),
+            # what can run while the first exchange step is on the wire: the ELL launch + the panels of the rank's own columns
+            "own_columns_part_ms_max_over_ranks": round(float(mx[3].item()), 5),
+            "phase1_share_of_local_ms": round(float(mx[3].item()) / max(float(mx[1].item()), 1e-9), 4),
+            "own_columns_share_of_entries": round(float(stats[4].item()) / max(float(stats[2].item()), 1.0), 4),
+            "host_us_per_step": round(args.host_us_per_step, 1),
             "n1_equivalent": ("the N = 1 line's scaling_anchor (same matrix, one GPU)" if args.workload == "rmat-24" else
                               "the N = 1 line's value (same matrix, one GPU)" if args.workload == "audikw_1-like" else
                               f"bench.py --workload {args.workload} (N = 1)"),
@@ -445,8 +465,15 @@ def main():
     ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
                     help="N>1 strong: halo = only the x entries a rank's rows reference (one all_to_all_single); "
                          "allgather = every x segment to everyone, padded to equal length (one all_gather_into_tensor)")
+    ap.add_argument("--chunks", type=int, default=2,
+                    help="N>1 halo: exchange steps per multiply -- every owner's ghost columns, hottest first, are cut into this many "
+                         "chunks; the panels of chunk k are multiplied while chunk k+1 is on the wire")
+    ap.add_argument("--chunk-shares", default="", help="N>1 halo: share of every owner's ghost columns per chunk, e.g. 0.3,0.7 (default: equal)")
+    ap.add_argument("--exchange-mode", default="a2a", choices=["a2a", "p2p"],
+                    help="N>1 halo: a2a = one all_to_all_single per exchange step; p2p = grouped isend/irecv pairs (explicit, never a fallback)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()
+    args.host_us_per_step = 0.0
 
     world_env = os.environ.get("WORLD_SIZE")
     if args.gpus > 1 and world_env is None:

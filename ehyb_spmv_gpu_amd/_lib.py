@@ -118,6 +118,7 @@ SIGNATURES = {
     "ehyb_vector_recover": (None, [C.c_int, _dp, _dp, _ip]),
     "ehyb_top_boundary": (C.c_int, [_mp, _cfgp, C.c_int, _ip]),
     "ehyb_plan_create_host": (C.c_int, [_mp, C.c_int, C.c_int, _cfgp, _P(_vp)]),
+    "ehyb_plan_create_host_segs": (C.c_int, [_mp, C.c_int, C.c_int, _cfgp, C.c_int, _ip, _P(_vp)]),
     "ehyb_plan_upload": (C.c_int, [_vp]),
     "ehyb_plan_create": (C.c_int, [_mp, _cfgp, _P(_vp)]),
     "ehyb_plan_destroy": (None, [_vp]),
@@ -128,6 +129,11 @@ SIGNATURES = {
     "ehyb_plan_host_array": (C.c_int, [_vp, C.c_int, _P(_vp), _i64p]),
     "ehyb_spmv": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ehyb_spmv_phase": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
+    "ehyb_spmv_part": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
+    "ehyb_plan_col_segs": (C.c_int, [_vp, _ip]),
+    "ehyb_gather": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
+    "ehyb_step_pack": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp]),
+    "ehyb_step_part": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ehyb_spmv_bench": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _dp, _dp, _dp]),
     "ehyb_spmv_host": (C.c_int, [_vp, _dp, _dp, C.c_int]),
     "ehyb_plan_set_values": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, _vp]),

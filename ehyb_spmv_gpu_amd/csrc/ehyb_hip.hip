@@ -606,6 +606,21 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_reduce_kernel(const int4* __r
     }
 }
 
+// dst[i] = src[idx[i]]: the send list of a halo exchange (multi-GPU), four gathers per thread in flight
+__global__ __launch_bounds__(256) void ehyb_gather_kernel(const double* __restrict__ src, const int32_t* __restrict__ idx, double* __restrict__ dst, long long n)
+{
+    const long long base = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    int32_t k[4];
+    double v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[j] = base + j < n ? idx[base + j] : 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = base + j < n ? src[k[j]] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (base + j < n) dst[base + j] = v[j];
+}
+
 // streaming-read probe for the on-box bandwidth ceiling
 __global__ __launch_bounds__(256) void ehyb_read_kernel(const double2* __restrict__ src, size_t n2, double* sink)
 {
@@ -690,19 +705,22 @@ static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st, 
     return launch_ell_impl<false>(P, x, y, st, inl, nullptr);
 }
 
-// which: 1 = pass 1 (scale), 2 = pass 2 (reduce), 3 = both
-static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st, int probe, int which)
+// which: 1 = pass 1 (scale), 2 = pass 2 (reduce), 3 = both; pass 1 over the units [unit_begin, unit_end) (-1: all)
+static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st, int probe, int which, int unit_begin = 0, int unit_end = -1)
 {
     const HostLayout& H = P->host;
-    const int u1 = (int)(H.pb_units1.size() / 4), u2 = (int)(H.pb_units2.size() / 4);
-    if (which & 1) {
+    const int u_all = (int)(H.pb_units1.size() / 4), u2 = (int)(H.pb_units2.size() / 4);
+    if (unit_end < 0) unit_end = u_all;
+    if (unit_begin < 0 || unit_end > u_all || unit_begin > unit_end) EHYB_FAIL(EHYB_ERR_ARG, "launch_panel: units [%d, %d) of %d", unit_begin, unit_end, u_all);
+    const int u1 = unit_end - unit_begin;
+    if ((which & 1) && u1 > 0) {
         // panels of up to 9,728 columns: two 512-thread workgroups per CU (one stages while the other streams); wider
         // panels leave room for one workgroup only, which then gets the CU's 16 waves
         const bool wide = H.pb_panel_cols > 9728;
         const bool dpp = P->cfg.er_sums != 2;
         const int xcd = P->cfg.xcd_map != 2 ? 1 : 0;
 #define PB_SCALE(T, D)                                                                                                          \
-    hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D>), dim3(u1), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T))) * 8, st, (const int4*)P->d_pb_units1, \
+    hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D>), dim3(u1), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T))) * 8, st, (const int4*)P->d_pb_units1 + unit_begin, \
                        P->d_pb_val, P->d_pb_colf, P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, probe, xcd)
         if (wide) {
             if (dpp) PB_SCALE(1024, true); else PB_SCALE(1024, false);
@@ -711,7 +729,7 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
         }
 #undef PB_SCALE
     }
-    if (which & 2)
+    if ((which & 2) && u2 > 0)
         hipLaunchKernelGGL(ehyb_pb_reduce_kernel<512>, dim3(u2), dim3(512), (size_t)H.pb_rows_max * 8, st, (const int4*)P->d_pb_units2,
                            P->d_pb_partial, P->d_pb_row, y, probe);
     HIP_TRY(hipGetLastError());
@@ -995,6 +1013,79 @@ int ehyb_spmv_phase(ehyb_plan* P, const double* x, double* y, void* stream, int 
 int ehyb_spmv(ehyb_plan* P, const double* x, double* y, void* stream)
 {
     return ehyb_spmv_phase(P, x, y, stream, 0);
+}
+
+int ehyb_plan_col_segs(const ehyb_plan* P, int* n_col_segs)
+{
+    if (!P || !n_col_segs) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_col_segs: null argument");
+    *n_col_segs = P->host.col_seg_first.size() >= 2 ? (int)P->host.col_seg_first.size() - 1 : 1;
+    return EHYB_OK;
+}
+
+// The multiply in parts (multi-GPU: x arrives column segment by column segment).
+int ehyb_spmv_part(ehyb_plan* P, const double* x, double* y, void* stream, int seg_begin, int seg_end, int flags)
+{
+    if (!P || !x || !y) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_spmv_part: null argument");
+    if (!P->uploaded) EHYB_FAIL(EHYB_ERR_STATE, "ehyb_spmv_part: plan not uploaded (no CPU fallback exists)");
+    const HostLayout& H = P->host;
+    int n_segs = 1;
+    (void)ehyb_plan_col_segs(P, &n_segs);
+    if (seg_begin < 0 || seg_end > n_segs || seg_begin > seg_end) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_spmv_part: column segments [%d, %d) of %d", seg_begin, seg_end, n_segs);
+    if (H.direct || fuse_residual(P)) EHYB_FAIL(EHYB_ERR_STATE, "ehyb_spmv_part: this plan multiplies in one launch (direct shape or inline residual): it has no parts");
+    hipStream_t st = (hipStream_t)stream;
+    int rc = EHYB_OK;
+    if (flags & EHYB_PART_FIRST) rc = launch_ell(P, x, y, st, false);
+    if (rc != EHYB_OK || H.er_bins[3] == 0) return rc;
+    if (!H.er_panel) return (flags & EHYB_PART_LAST) ? launch_er(P, x, y, st) : EHYB_OK;  // CSR residual: one launch, needs all of x
+    if (seg_end > seg_begin) {
+        const int ub = H.pb_seg_unit.empty() ? 0 : H.pb_seg_unit[(size_t)seg_begin];
+        const int ue = H.pb_seg_unit.empty() ? -1 : H.pb_seg_unit[(size_t)seg_end];
+        rc = launch_panel(P, x, y, st, 0, 1, ub, ue);
+    }
+    if (rc == EHYB_OK && (flags & EHYB_PART_LAST)) rc = launch_panel(P, x, y, st, 0, 2);
+    return rc;
+}
+
+int ehyb_gather(const double* src, const int32_t* idx, double* dst, int64_t n, void* stream)
+{
+    if (n < 0 || (n > 0 && (!src || !idx || !dst))) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gather: bad arguments");
+    if (n == 0) return EHYB_OK;
+    hipLaunchKernelGGL(ehyb_gather_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, (long long)n);
+    HIP_TRY(hipGetLastError());
+    return EHYB_OK;
+}
+
+// "`waiter` waits for everything enqueued on `on` so far": an event record + a stream wait.  The events are a small
+// per-thread ring, made once and reused (recording an event again while an earlier wait on it is pending is well defined:
+// a wait refers to the record that preceded it).
+static int stream_wait_stream(hipStream_t waiter, hipStream_t on)
+{
+    constexpr int kRing = 16;
+    static thread_local hipEvent_t ring[kRing] = {};
+    static thread_local int next = 0;
+    hipEvent_t& e = ring[next];
+    next = (next + 1) % kRing;
+    if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    HIP_TRY(hipEventRecord(e, on));
+    HIP_TRY(hipStreamWaitEvent(waiter, e, 0));
+    return EHYB_OK;
+}
+
+int ehyb_step_pack(const double* x, const int32_t* idx, double* send_buf, int64_t n, void* compute_stream, void* comm_stream)
+{
+    int rc = ehyb_gather(x, idx, send_buf, n, compute_stream);
+    if (rc == EHYB_OK && comm_stream != compute_stream) rc = stream_wait_stream((hipStream_t)comm_stream, (hipStream_t)compute_stream);
+    return rc;
+}
+
+int ehyb_step_part(ehyb_plan* P, const double* x, double* y, void* compute_stream, void* comm_stream, int wait_comm, int seg_begin, int seg_end,
+                   int flags)
+{
+    if (wait_comm && comm_stream != compute_stream) {
+        const int rc = stream_wait_stream((hipStream_t)compute_stream, (hipStream_t)comm_stream);
+        if (rc != EHYB_OK) return rc;
+    }
+    return ehyb_spmv_part(P, x, y, compute_stream, seg_begin, seg_end, flags);
 }
 
 int ehyb_spmv_bench(ehyb_plan* P, const double* x, double* y, void* stream, int warmup, int iters,

@@ -139,6 +139,11 @@ struct HostLayout {
     // partial arrives), the ELL launch skips them, and their slabs cost its work items nothing.
     bool pb_assign = false;
     std::vector<uint8_t> part_windowless;  // [n_parts] host only
+    // Column segments (multi-GPU, ehyb_plan_create_host_segs): [0] = 0 < ... < [n] = n_cols; a panel never straddles a
+    // boundary, and the pass-1 units of segment s are pb_seg_unit[s] .. pb_seg_unit[s+1] -- the multiply can then run
+    // segment by segment as the x entries of each arrive (ehyb_spmv_part).  Empty = one segment.
+    std::vector<int32_t> col_seg_first;
+    std::vector<int32_t> pb_seg_unit;
     // what pass 1 streams in place of pb_col + pb_dst (derived from them by encode_panel_slots, not stored in plan files)
     std::vector<uint16_t> pb_colf;    // column | head flag (bit 15) | jump flag (bit 14)
     std::vector<uint32_t> pb_chunk;   // per 64-entry chunk: its first jump

@@ -108,7 +108,7 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     const int rows_max = cfg.er_block_rows;
     L->er_panel = false;
     if (nnz_er == 0) return EHYB_OK;
-    if (nnz_er + 64 * ((int64_t)n_cols / W + 2) >= 0x7FFFFF00ll)
+    if (nnz_er + 64 * ((int64_t)n_cols / W + 2 + (int64_t)L->col_seg_first.size()) >= 0x7FFFFF00ll)
         EHYB_FAIL(EHYB_ERR_ARG, "build_panel_residual: residual of %lld entries too large for 32-bit offsets", (long long)nnz_er);
 
     // ---- (row, column, value) of every residual entry, from the CSR segments
@@ -158,19 +158,48 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     }
     const int n_rb = (int)rb_first.size() - 1;
 
-    // ---- pass-1 order: by panel (counting sort), inside a panel by (row, column)
-    const int n_panels = (n_cols + W - 1) / W;
-    std::vector<int64_t> pcount((size_t)n_panels + 1, 0);
-    for (int64_t k = 0; k < nnz_er; ++k) {
-        if ((unsigned)ecol[k] >= (unsigned)n_cols) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_panel_residual: column outside the matrix");
-        ++pcount[(size_t)(ecol[k] / W) + 1];
+    // ---- panels: W columns each, starting afresh at every column segment (one segment = the whole matrix unless the
+    // caller named more: multi-GPU, the x entries of a segment arrive together)
+    std::vector<int32_t> seg_first = L->col_seg_first;
+    if (seg_first.size() < 2) seg_first = {0, n_cols};
+    const int n_segs = (int)seg_first.size() - 1;
+    if (seg_first[0] != 0 || seg_first[n_segs] != n_cols) EHYB_FAIL(EHYB_ERR_ARG, "build_panel_residual: column segments must span [0, %d)", n_cols);
+    std::vector<int32_t> seg_panel0((size_t)n_segs + 1, 0), panel_first;
+    for (int s = 0; s < n_segs; ++s) {
+        if (seg_first[s + 1] < seg_first[s] || (s > 0 && (seg_first[s] & 1)))
+            EHYB_FAIL(EHYB_ERR_ARG, "build_panel_residual: column segment %d starts at %d (segments ascend and start on even columns)", s, seg_first[s]);
+        for (int c = seg_first[s]; c < seg_first[s + 1]; c += W) panel_first.push_back(c);
+        seg_panel0[s + 1] = (int32_t)panel_first.size();
     }
+    const int n_panels = (int)panel_first.size();
+    panel_first.push_back(n_cols);
+    auto panel_of = [&](int c) {
+        int s = 0;
+        while (c >= seg_first[s + 1]) ++s;  // a handful of segments
+        return seg_panel0[s] + (c - seg_first[s]) / W;
+    };
+    // ---- pass-1 order: by panel (counting sort), inside a panel by (row, column)
+    std::vector<int64_t> pcount((size_t)n_panels + 1, 0);
+    std::vector<int32_t> epanel((size_t)nnz_er);
+    bool bad_col = false;
+#pragma omp parallel for schedule(static, 65536) reduction(|| : bad_col)
+    for (int64_t k = 0; k < nnz_er; ++k) {
+        if ((unsigned)ecol[k] >= (unsigned)n_cols) {
+            bad_col = true;
+            epanel[(size_t)k] = 0;
+        } else {
+            epanel[(size_t)k] = panel_of(ecol[k]);
+        }
+    }
+    if (bad_col) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_panel_residual: column outside the matrix");
+    for (int64_t k = 0; k < nnz_er; ++k) ++pcount[(size_t)epanel[(size_t)k] + 1];
     for (int p = 0; p < n_panels; ++p) pcount[p + 1] += pcount[p];
     std::vector<uint32_t> order((size_t)nnz_er);
     {
         std::vector<int64_t> fill(pcount.begin(), pcount.end() - 1);
-        for (int64_t k = 0; k < nnz_er; ++k) order[(size_t)fill[ecol[k] / W]++] = (uint32_t)k;
+        for (int64_t k = 0; k < nnz_er; ++k) order[(size_t)fill[epanel[(size_t)k]]++] = (uint32_t)k;
     }
+    std::vector<int32_t>().swap(epanel);
 #pragma omp parallel for schedule(dynamic, 1)
     for (int p = 0; p < n_panels; ++p)
         std::sort(order.begin() + pcount[p], order.begin() + pcount[p + 1], [&](uint32_t a, uint32_t b) {
@@ -216,7 +245,7 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
                 const int64_t pos = pstart[p] + (k - b);
                 L->pb_val[(size_t)pos] = evalv[src];
                 if (vmap) L->pb_src[(size_t)pos] = L->er_src[src];
-                L->pb_col[(size_t)pos] = (uint16_t)(ecol[src] - p * W);
+                L->pb_col[(size_t)pos] = (uint16_t)(ecol[src] - panel_first[p]);
                 L->pb_dst[(size_t)pos] = (uint32_t)piece;
             }
         }
@@ -247,13 +276,17 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     // pass 1: {first column, columns, first entry, end entry} -- chunks of a panel, multiples of 64 entries
     const int64_t c1 = std::min<int64_t>(std::max<int64_t>((padded / cfg.er_units1 + 63) / 64 * 64, 8192), 1 << 20);
     L->pb_units1.clear();
+    L->pb_seg_unit.assign((size_t)n_segs + 1, 0);
     int64_t staged = 0;
-    for (int p = 0; p < n_panels; ++p)
-        for (int64_t b = pstart[p]; b < pstart[p + 1]; b += c1) {
-            const int32_t u[4] = {p * W, std::min(W, n_cols - p * W), (int32_t)b, (int32_t)std::min(b + c1, pstart[p + 1])};
-            L->pb_units1.insert(L->pb_units1.end(), u, u + 4);
-            staged += u[1];
-        }
+    for (int s = 0; s < n_segs; ++s) {
+        for (int p = seg_panel0[s]; p < seg_panel0[s + 1]; ++p)
+            for (int64_t b = pstart[p]; b < pstart[p + 1]; b += c1) {
+                const int32_t u[4] = {panel_first[p], std::min(W, seg_first[s + 1] - panel_first[p]), (int32_t)b, (int32_t)std::min(b + c1, pstart[p + 1])};
+                L->pb_units1.insert(L->pb_units1.end(), u, u + 4);
+                staged += u[1];
+            }
+        L->pb_seg_unit[(size_t)s + 1] = (int32_t)(L->pb_units1.size() / 4);
+    }
     // pass 2: {first slot, end slot, first row, rows}; blocks without partials are skipped -- unless the block
     // ASSIGNS y (rows stored negative): then it is the only writer of its rows
     L->pb_units2.clear();

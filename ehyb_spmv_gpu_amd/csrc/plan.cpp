@@ -92,13 +92,26 @@ extern "C" {
 int ehyb_plan_create_host(const matrixCOO* m, int row_begin, int row_end, const ehyb_config* cfg,
                           ehyb_plan** plan)
 {
+    return ehyb_plan_create_host_segs(m, row_begin, row_end, cfg, 0, nullptr, plan);
+}
+
+int ehyb_plan_create_host_segs(const matrixCOO* m, int row_begin, int row_end, const ehyb_config* cfg,
+                               int n_col_segs, const int* col_seg_first, ehyb_plan** plan)
+{
     clear_error();
     if (!plan) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_create_host: null output");
     *plan = nullptr;
     if (!m) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_create_host: null matrix");
+    if (n_col_segs < 0 || (n_col_segs > 0 && !col_seg_first)) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_create_host_segs: bad column segments");
+    for (int s = 0; s < n_col_segs; ++s)
+        if (col_seg_first[s + 1] < col_seg_first[s] || (s > 0 && (col_seg_first[s] & 1)))
+            EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_create_host_segs: column segment %d starts at %d (segments ascend and start on even columns)", s, col_seg_first[s]);
+    if (n_col_segs > 0 && (col_seg_first[0] != 0 || col_seg_first[n_col_segs] != m->dimension))
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_create_host_segs: the column segments must span [0, %d)", m->dimension);
     ehyb_plan* P = new (std::nothrow) ehyb_plan();
     if (!P) EHYB_FAIL(EHYB_ERR_ALLOC, "ehyb_plan_create_host: out of memory");
     P->cfg = resolve_config(cfg);
+    if (n_col_segs > 0) P->host.col_seg_first.assign(col_seg_first, col_seg_first + n_col_segs + 1);
     int rc;
     try {
         rc = build_layout(m, row_begin, row_end, P->cfg, &P->host);
@@ -123,6 +136,7 @@ int ehyb_plan_create_host(const matrixCOO* m, int row_begin, int row_end, const 
                 // A failure of the rebuild (memory: both layouts are alive here; the 32-bit limits of the panel builder once
                 // every ELL entry has moved) is not a failure of the plan: the first layout is complete and valid.
                 HostLayout again;
+                again.col_seg_first = P->host.col_seg_first;
                 int rc2;
                 try {
                     rc2 = build_layout(m, row_begin, row_end, P->cfg, &again, &to_er);
@@ -197,6 +211,8 @@ int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int
         case EHYB_ARR_ER_SRC: VIEW(H.er_src);
         case EHYB_ARR_PB_SRC: VIEW(H.pb_src);
         case EHYB_ARR_ELL_SRC2: VIEW(H.ell_src2);
+        case EHYB_ARR_COL_SEG_FIRST: VIEW(H.col_seg_first);
+        case EHYB_ARR_PB_SEG_UNIT: VIEW(H.pb_seg_unit);
         case EHYB_ARR_ER_BINS:
             *ptr = (const void*)H.er_bins;
             *count = 8;

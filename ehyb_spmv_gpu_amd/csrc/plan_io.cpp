@@ -62,7 +62,7 @@ bool each_array(HostLayout& H, F&& io)
            io(H.slab_row) && io(H.slab_part) && io(H.ell_val) && io(H.ell_col) && io(H.slab_col_ptr) && io(H.lane_group) &&
            io(H.slab_meta) && io(H.items) && io(H.segs) && io(H.er_seg_ptr) && io(H.er_seg_row) && io(H.er_col) &&
            io(H.er_val) && io(H.er_blocks) && io(H.slab_lrow) && io(H.pb_val) && io(H.pb_col) && io(H.pb_dst) &&
-           io(H.pb_units1) && io(H.pb_row) && io(H.pb_units2);
+           io(H.pb_units1) && io(H.pb_row) && io(H.pb_units2) && io(H.col_seg_first) && io(H.pb_seg_unit);
 }
 
 struct Scalars {

@@ -140,13 +140,48 @@ def _copy_cfg(cfg, **kw):
     return c
 
 
+def _setup_device(group=None):
+    """Where the tensors of the SETUP collectives live: RCCL moves device tensors, gloo host tensors."""
+    import torch
+    import torch.distributed as dist
+
+    return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
+
+
+def alltoallv(send, send_counts, group=None):
+    """Uneven all-to-all of a 1-D numpy array with TENSOR collectives (the counts first, then the payload in one
+    all_to_all_single): what the ranks tell each other while the send lists are built.  -> (received, recv_counts)"""
+    import torch
+    import torch.distributed as dist
+
+    dev = _setup_device(group)
+    world = dist.get_world_size(group)
+    sc = torch.tensor([int(c) for c in send_counts], dtype=torch.int64, device=dev)
+    rc = torch.empty(world, dtype=torch.int64, device=dev)
+    dist.all_to_all_single(rc, sc, group=group)
+    rc_l = [int(c) for c in rc.cpu().tolist()]
+    send_t = torch.from_numpy(np.ascontiguousarray(send)).to(dev)
+    recv_t = torch.empty(sum(rc_l), dtype=send_t.dtype, device=dev)
+    dist.all_to_all_single(recv_t, send_t, rc_l, [int(c) for c in send_counts], group=group)
+    return recv_t.cpu().numpy(), np.asarray(rc_l, dtype=np.int64)
+
+
+def _even(v):
+    return (int(v) + 1) & ~1
+
+
 class RankLocalMatrix:
-    def __init__(self, I, J, V, cuts, rank, cfg=None, symmetric=False, group=None, exchange="halo"):
+    def __init__(self, I, J, V, cuts, rank, cfg=None, symmetric=False, group=None, exchange="halo", chunks=1, chunk_shares=None):
         """I, J, V: this rank's rows in global labels, row-grouped (I ascending).  cuts: first row of
         every rank, world+1 entries.  Collective: every rank of `group` must call it.
-        exchange = "halo": one ghost slot per distinct remote column, filled by an all_to_all of exactly
-        those entries (HaloSpmv).  exchange = "allgather": the ghost columns are the places of the remote
-        entries inside the buffer an all-gather of the (padded) x segments fills (GatherSpmv):
+        exchange = "halo": one ghost slot per distinct remote column, filled by all_to_all steps of exactly
+        those entries (HaloSpmv).  The slots come in `chunks` CHUNKS = exchange steps: inside every owner's
+        columns the most referenced ones first, chunk k taking chunk_shares[k] of every owner's slots (default: equal
+        shares), so that the multiply over chunk k's columns (ehyb_spmv_part) runs while chunk k+1 is on the wire.
+        Column layout of the rank's matrix and of x: [own columns | chunk 0: owner 0, owner 1, ... | chunk 1: ... ],
+        every part padded to an even length (the column segments of ehyb_plan_create_host_segs).
+        exchange = "allgather": the ghost columns are the places of the remote entries inside the buffer an
+        all-gather of the (padded) x segments fills (GatherSpmv):
         x = [own segment, padded to seg_len | segment of rank 0 | ... | segment of rank world-1], every
         segment in its owner's plan order, so nothing has to be unpacked after the collective."""
         world = len(cuts) - 1
@@ -158,6 +193,15 @@ class RankLocalMatrix:
         V = np.asarray(V, dtype=np.float64)
         if len(I) and (I.min() < r0 or I.max() >= r1 or np.any(np.diff(I) < 0)):
             raise ValueError("RankLocalMatrix: rows must lie in [r0, r1) and be grouped in ascending order")
+        if exchange not in ("halo", "allgather"):
+            raise ValueError(f"RankLocalMatrix: unknown exchange {exchange!r}")
+        if exchange == "allgather" or world == 1:
+            chunks, chunk_shares = 1, None
+        chunks = max(1, int(chunks))
+        shares = np.asarray(chunk_shares if chunk_shares is not None else [1.0 / chunks] * chunks, dtype=np.float64)
+        if len(shares) != chunks or np.any(shares <= 0):
+            raise ValueError("RankLocalMatrix: chunk_shares must hold one positive share per chunk")
+        edges = np.cumsum(shares / shares.sum())[:-1]
         own = (J >= r0) & (J < r1)
         # diagonal block: a masked row-grouped sequence is still row-grouped
         indptr = np.zeros(self.n_loc + 1, dtype=np.int64)
@@ -166,57 +210,75 @@ class RankLocalMatrix:
         self.m = H.Matrix.from_csr(indptr, J[own] - r0, V[own], cfg1, symmetric=symmetric)
         self.m.reorder(cfg1)
         self.perm = self.m.reorder_list[:self.n_loc].copy()  # local row i (unpermuted) -> its place in the plan
-        # ghost slots: distinct remote columns, ascending = grouped by owner
+        # ---- ghost slots: the distinct remote columns, ordered by (chunk, owner, references descending, label)
         off = ~own
         Jg = J[off]
-        gcols = np.unique(Jg)
+        gcols, inv, refs = np.unique(Jg, return_inverse=True, return_counts=True)
         owner = np.searchsorted(np.asarray(self.cuts), gcols, side="right") - 1
         self.n_ghost = len(gcols)
-        self.ghost_cols = gcols
-        self.recv_counts = np.bincount(owner, minlength=world).astype(np.int64)
-        assert self.recv_counts[rank] == 0
-        wants = [gcols[owner == p] for p in range(world)]
-        # what the peers want from me, in their slot order
-        if world > 1:
-            import torch.distributed as dist
-
-            everyone = [None] * world
-            dist.all_gather_object(everyone, wants, group=group)
-        else:
-            everyone = [wants]
-        asked = [np.asarray(everyone[q][rank], dtype=np.int64) for q in range(world)]
-        for a in asked:
-            if len(a) and (a.min() < r0 or a.max() >= r1):
-                raise ValueError("RankLocalMatrix: a peer asked for a column this rank does not own")
-        self.send_counts = np.array([len(a) for a in asked], dtype=np.int64)
-        places = [self.perm[a - r0].astype(np.int64) for a in asked]   # where, in my plan order, what each peer wants sits
-        self.send_idx = np.concatenate(places) if world > 1 else np.zeros(0, np.int64)
+        by_owner = np.lexsort((gcols, -refs, owner))                       # owner, then hot columns first
+        per_owner = np.bincount(owner, minlength=world).astype(np.int64)
+        assert per_owner[rank] == 0
+        first_of = np.concatenate(([0], np.cumsum(per_owner)))[:-1]
+        pos = np.arange(self.n_ghost) - np.repeat(first_of, per_owner)       # rank inside the owner's list
+        frac = (pos + 0.5) / np.maximum(1, np.repeat(per_owner, per_owner))
+        chunk_sorted = np.searchsorted(edges, frac, side="right")            # chunk of every slot, in by_owner order
+        order = by_owner[np.lexsort((np.arange(self.n_ghost), chunk_sorted))]  # stable: chunk major, the rest as it was
+        chunk_of = chunk_sorted[np.lexsort((np.arange(self.n_ghost), chunk_sorted))]
+        self.ghost_cols = gcols[order]                                       # global label of every slot, slot order
+        owner_s = owner[order]
+        self.chunks = chunks
+        # recv_counts[k][p]: slots of chunk k whose owner is p
+        self.recv_counts = np.zeros((chunks, world), dtype=np.int64)
+        np.add.at(self.recv_counts, (chunk_of, owner_s), 1)
+        chunk_len = self.recv_counts.sum(axis=1)
+        # ---- column segments: own columns, then one per chunk, every start even
+        seg = [0, _even(self.n_loc)]
+        for k in range(chunks):
+            seg.append(_even(seg[-1] + int(chunk_len[k])))
         self.exchange = exchange
         self.seg_len = max(self.cuts[b + 1] - self.cuts[b] for b in range(world))
+        chunk_first = np.concatenate(([0], np.cumsum(chunk_len)))[:-1]
+        col_of_slot = np.asarray(seg[1:-1], dtype=np.int64)[chunk_of] + (np.arange(self.n_ghost) - chunk_first[chunk_of])
+        self.ghost_slot_col = col_of_slot                                    # column (in x) of every slot
+        # ---- what the peers want from me, chunk by chunk, in their slot order: tensor collectives
+        self.send_counts = np.zeros((chunks, world), dtype=np.int64)
+        send_idx = []
+        if world > 1:
+            for k in range(chunks):
+                sel = chunk_of == k
+                asked, cnt = alltoallv(self.ghost_cols[sel].astype(np.int64), self.recv_counts[k], group)
+                if len(asked) and (asked.min() < r0 or asked.max() >= r1):
+                    raise ValueError("RankLocalMatrix: a peer asked for a column this rank does not own")
+                self.send_counts[k] = cnt
+                send_idx.append(self.perm[asked - r0].astype(np.int32))       # where, in my plan order, what each peer wants sits
+        self.send_idx = np.concatenate(send_idx) if send_idx else np.zeros(0, np.int32)
+        self.send_first = np.concatenate(([0], np.cumsum(self.send_counts.sum(axis=1))))
+        slot_of_entry = np.empty(self.n_ghost, dtype=np.int64)
+        slot_of_entry[order] = np.arange(self.n_ghost)                       # unique index -> slot
         if exchange == "allgather" and world > 1:
-            import torch.distributed as dist
-
-            told = [None] * world
-            dist.all_gather_object(told, places, group=group)
-            # ghost column of remote entry k of owner p: behind my padded segment, inside p's segment of the gathered buffer
-            slot = np.empty(self.n_ghost, dtype=np.int64)
-            at = 0
-            for p in range(world):
-                pl = np.asarray(told[p][rank], dtype=np.int64)
-                slot[at:at + len(pl)] = (self.seg_len - self.n_loc) + p * self.seg_len + pl
-                at += len(pl)
-            assert at == self.n_ghost
+            # every owner tells me where, in ITS plan order, the columns I asked for sit: the reverse all-to-all
+            places, _ = alltoallv(self.send_idx.astype(np.int64), self.send_counts[0], group)
+            # ghost column of remote entry j of owner p: behind my padded segment, inside p's segment of the gathered buffer
+            own_first = np.concatenate(([0], np.cumsum(self.recv_counts[0])))[:-1]
+            p_of = owner_s
+            slot_col = self.n_loc + (self.seg_len - self.n_loc) + p_of * self.seg_len + places
+            del own_first
             self.n_ext = (self.seg_len - self.n_loc) + world * self.seg_len
-            self.m.append_ghosts(self.n_ext, self.perm[I[off] - r0], slot[np.searchsorted(gcols, Jg)], V[off])
+            self.col_segs = None
+            self.m.append_ghosts(self.n_ext, self.perm[I[off] - r0], (slot_col - self.n_loc)[slot_of_entry[inv]], V[off])
         else:
-            # the coupling entries, rows in plan numbering, columns = ghost slots
-            self.n_ext = self.n_ghost
-            self.m.append_ghosts(self.n_ghost, self.perm[I[off] - r0], np.searchsorted(gcols, Jg), V[off])
+            # the coupling entries, rows in plan numbering, columns = ghost columns behind the own ones
+            self.n_ext = seg[-1] - self.n_loc
+            self.col_segs = np.asarray(seg, dtype=np.int32)
+            self.m.append_ghosts(self.n_ext, self.perm[I[off] - r0], (col_of_slot - self.n_loc)[slot_of_entry[inv]], V[off])
         self.nnz = len(V)
+        self.nnz_own_cols = int(own.sum())
         self.cfg_plan = _copy_cfg(cfg, n_top=2 if world > 1 else 1)
 
     def plan(self, upload=True):
-        return H.Plan(self.m, self.cfg_plan, rows=(0, self.n_loc), upload=upload)
+        return H.Plan(self.m, self.cfg_plan, rows=(0, self.n_loc), upload=upload,
+                      col_segs=self.col_segs if (self.col_segs is not None and self.world > 1) else None)
 
     def x_to_plan(self, x_local):
         """Local x segment (global label order) -> plan order."""
@@ -227,98 +289,124 @@ class RankLocalMatrix:
 
 
 class HaloExchange:
-    """x_ext = [local x (plan order) | ghost slots]; run() refreshes the ghost slots from the peers."""
+    """x_ext = [local x (plan order) | ghost columns, chunk by chunk]; pack() gathers what the peers asked for,
+    transfer(k) fills the ghost columns of chunk k.
+    mode "a2a" (default): ONE all_to_all_single with uneven splits per chunk (RCCL over xGMI: every pair of GPUs has its
+    own link, so the direct all-to-all is link-optimal); "p2p": grouped isend/irecv pairs -- an explicit choice
+    (bench.py --exchange-mode p2p), never a silent fallback: a collective that throws is a fault, not a slow path."""
 
-    def __init__(self, local, x_ext, group=None, stage_on_cpu=False):
+    def __init__(self, local, x_ext, group=None, stage_on_cpu=False, mode="a2a"):
         import torch
         import torch.distributed as dist
 
         self.torch, self.dist = torch, dist
         self.L, self.group, self.x_ext = local, group, x_ext
         dev = x_ext.device
-        self.send_idx = torch.from_numpy(local.send_idx).to(dev)
+        self.send_idx = torch.from_numpy(local.send_idx.astype(np.int32)).to(dev)
         self.send_buf = torch.empty(len(local.send_idx), dtype=torch.float64, device=dev)
-        self.ghosts = x_ext[local.n_loc:]
-        self.send_counts = [int(c) for c in local.send_counts]
-        self.recv_counts = [int(c) for c in local.recv_counts]
-        # RCCL: one all_to_all_single with uneven splits; EHYB_HALO_P2P=1 forces grouped send/recv pairs
-        self.a2a = local.world > 1 and dist.get_backend(group) == "nccl" and os.environ.get("EHYB_HALO_P2P") != "1"
-        self.stage = stage_on_cpu and dev.type != "cpu"  # gloo cannot move GPU tensors point to point
+        self.send_counts = [[int(c) for c in row] for row in local.send_counts]
+        self.recv_counts = [[int(c) for c in row] for row in local.recv_counts]
+        if mode not in ("a2a", "p2p"):
+            raise ValueError(f"HaloExchange: unknown mode {mode!r}")
+        self.mode = mode
+        self.stage = stage_on_cpu and dev.type != "cpu"  # gloo cannot move GPU tensors: through the host (functional mode)
+        segs = local.col_segs
+        self.ghost_views = [x_ext[int(segs[k + 1]):int(segs[k + 1]) + sum(self.recv_counts[k])] for k in range(local.chunks)] if local.world > 1 else []
+        self.send_views = [self.send_buf[int(local.send_first[k]):int(local.send_first[k + 1])] for k in range(local.chunks)] if local.world > 1 else []
+        self.lib = H._lib.load()
 
-    def pack(self):
-        if len(self.send_idx):
-            self.torch.index_select(self.x_ext[:self.L.n_loc], 0, self.send_idx, out=self.send_buf)
+    def pack(self, compute_stream=0, comm_stream=0):
+        """send_buf[i] = x[send_idx[i]] on compute_stream (one launch for all chunks); comm_stream then waits for it."""
+        H._check(self.lib.ehyb_step_pack(C.c_void_p(self.x_ext.data_ptr()), C.c_void_p(self.send_idx.data_ptr()), C.c_void_p(self.send_buf.data_ptr()),
+                                         len(self.L.send_idx), C.c_void_p(compute_stream), C.c_void_p(comm_stream)), "ehyb_step_pack")
 
-    def transfer(self):
+    def transfer(self, k):
         L, dist, torch = self.L, self.dist, self.torch
         if L.world == 1:
             return
-        if self.a2a:
-            try:
-                dist.all_to_all_single(self.ghosts, self.send_buf, self.recv_counts, self.send_counts, group=self.group)
-                return
-            except RuntimeError as err:  # a backend without uneven splits: grouped send/recv pairs from here on
-                import sys
-
-                print(f"[ehyb] all_to_all_single failed ({err}); falling back to batched isend/irecv", file=sys.stderr, flush=True)
-                self.a2a = False
-        send, recv = (self.send_buf.cpu(), torch.empty(L.n_ghost, dtype=torch.float64)) if self.stage else (self.send_buf, self.ghosts)
-        ops, so, ro = [], 0, 0
-        for q in range(L.world):
-            peer = dist.get_global_rank(self.group, q) if self.group else q
-            if self.send_counts[q]:
-                ops.append(dist.P2POp(dist.isend, send[so:so + self.send_counts[q]], peer, group=self.group))
-            if self.recv_counts[q]:
-                ops.append(dist.P2POp(dist.irecv, recv[ro:ro + self.recv_counts[q]], peer, group=self.group))
-            so += self.send_counts[q]
-            ro += self.recv_counts[q]
-        for r in (dist.batch_isend_irecv(ops) if ops else []):
-            r.wait()
+        send, recv = self.send_views[k], self.ghost_views[k]
+        sc, rc = self.send_counts[k], self.recv_counts[k]
         if self.stage:
-            self.ghosts.copy_(recv)
+            send, recv_dev, recv = send.cpu(), recv, torch.empty(sum(rc), dtype=torch.float64)
+        if self.mode == "a2a":
+            dist.all_to_all_single(recv, send, rc, sc, group=self.group)
+        else:
+            ops, so, ro = [], 0, 0
+            for q in range(L.world):
+                peer = dist.get_global_rank(self.group, q) if self.group else q
+                if sc[q]:
+                    ops.append(dist.P2POp(dist.isend, send[so:so + sc[q]], peer, group=self.group))
+                if rc[q]:
+                    ops.append(dist.P2POp(dist.irecv, recv[ro:ro + rc[q]], peer, group=self.group))
+                so += sc[q]
+                ro += rc[q]
+            for r in (dist.batch_isend_irecv(ops) if ops else []):
+                r.wait()
+        if self.stage:
+            recv_dev.copy_(recv)
 
     def run(self):
-        self.pack()
-        self.transfer()
+        cur = self.torch.cuda.current_stream().cuda_stream if self.x_ext.device.type == "cuda" else 0
+        self.pack(cur, cur)
+        for k in range(self.L.chunks):
+            self.transfer(k)
 
 
 class HaloSpmv:
-    """One rank's multiply of a RankLocalMatrix on its GPU: y_loc = A[r0:r1, :] x."""
+    """One rank's multiply of a RankLocalMatrix on its GPU: y_loc = A[r0:r1, :] x.
+    pipelined (default): the step is  pack | own columns (ELL + the panels of the rank's own columns)  ||  chunk 0 on the
+    wire | chunk 0's panels  ||  chunk 1 on the wire | ... | closing pass -- every part one C call (ehyb_step_part), the
+    collectives on a side stream.  pipelined=False: pack, every chunk, then the whole multiply in one call (the plain step
+    the pipelined one is checked against)."""
 
-    def __init__(self, local, device, overlap=True, stage_on_cpu=False):
+    def __init__(self, local, device, overlap=True, stage_on_cpu=False, mode="a2a"):
         import torch
 
         self.torch = torch
         self.L = local
         self.plan = local.plan()
-        self.x = torch.zeros(local.n_loc + local.n_ghost, dtype=torch.float64, device=device)
+        self.x = torch.zeros(local.n_loc + local.n_ext, dtype=torch.float64, device=device)
         self.y = torch.zeros(local.n_loc, dtype=torch.float64, device=device)
-        self.halo = HaloExchange(local, self.x, local.group, stage_on_cpu=stage_on_cpu)
+        self.halo = HaloExchange(local, self.x, local.group, stage_on_cpu=stage_on_cpu, mode=mode)
         self.overlap = overlap and local.world > 1
         self.comm_stream = torch.cuda.Stream(device=device) if self.overlap else None
+        st = self.plan.stats
+        # a plan that multiplies in one launch (inline residual / direct shape) has no parts: plain steps only
+        self.has_parts = not (st["er_inline"] > 0)
+        self.lib = H._lib.load()
 
     def set_x_local(self, x_local):
         """x_local: this rank's x segment in global label order."""
         self.x[:self.L.n_loc].copy_(self.torch.from_numpy(self.L.x_to_plan(x_local)))
 
+    def _part(self, cur, comm, wait, s0, s1, flags):
+        H._check(self.lib.ehyb_step_part(self.plan.h, C.c_void_p(self.x.data_ptr()), C.c_void_p(self.y.data_ptr()), C.c_void_p(cur), C.c_void_p(comm),
+                                         wait, s0, s1, flags), "ehyb_step_part")
+
     def step(self):
         torch = self.torch
-        cur = torch.cuda.current_stream()
+        cur_s = torch.cuda.current_stream()
+        cur = cur_s.cuda_stream
         xp, yp = self.x.data_ptr(), self.y.data_ptr()
-        if self.L.world == 1:
-            self.plan.spmv(xp, yp, cur.cuda_stream)
+        L = self.L
+        if L.world == 1:
+            self.plan.spmv(xp, yp, cur)
             return
-        self.halo.pack()
-        if not self.overlap:
-            self.halo.transfer()
-            self.plan.spmv(xp, yp, cur.cuda_stream)
+        if not (self.overlap and self.has_parts):
+            self.halo.pack(cur, cur)
+            for k in range(L.chunks):
+                self.halo.transfer(k)
+            self.plan.spmv(xp, yp, cur)
             return
-        self.comm_stream.wait_stream(cur)
+        comm = self.comm_stream.cuda_stream
+        K = L.chunks
+        self.halo.pack(cur, comm)                      # comm waits for the packed send buffer
+        self._part(cur, comm, 0, 0, 1, 1)              # own columns: ELL + their panels, while chunk 0 travels
         with torch.cuda.stream(self.comm_stream):
-            self.halo.transfer()
-        self.plan.spmv(xp, yp, cur.cuda_stream, phase=1)  # local columns only
-        cur.wait_stream(self.comm_stream)
-        self.plan.spmv(xp, yp, cur.cuda_stream, phase=2)  # ghost columns
+            for k in range(K):
+                self.halo.transfer(k)                  # enqueued on comm (behind chunk k-1)
+                # compute waits for what comm holds NOW (chunks <= k), then multiplies chunk k's columns
+                self._part(cur, comm, 1, 1 + k, 2 + k, 2 if k == K - 1 else 0)
 
     def y_local(self):
         """This rank's y segment in global label order (host array)."""
@@ -326,6 +414,23 @@ class HaloSpmv:
 
     def time_local(self, iters):
         return _time_local(self, iters)
+
+    def time_parts(self, iters):
+        """Mean milliseconds of (the part that needs own columns only, the whole local multiply): how much of the local
+        work can run while the first chunk is on the wire."""
+        torch = self.torch
+        cur = torch.cuda.current_stream()
+        if not self.has_parts or self.L.world == 1:
+            return 0.0, _time_local(self, iters)
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        for _ in range(3):
+            self._part(cur.cuda_stream, cur.cuda_stream, 0, 0, 1, 1)
+        a.record(cur)
+        for _ in range(iters):
+            self._part(cur.cuda_stream, cur.cuda_stream, 0, 0, 1, 1)
+        b.record(cur)
+        b.synchronize()
+        return a.elapsed_time(b) / iters, _time_local(self, iters)
 
 
 def _time_local(sh, iters):

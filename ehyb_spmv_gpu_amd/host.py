@@ -28,6 +28,7 @@ ARRAYS = {
     "pb_row": (25, np.uint16), "pb_units2": (26, np.int32),
     "pb_colf": (31, np.uint16), "pb_chunk": (32, np.uint32), "pb_jump": (33, np.uint32),
     "ell_src": (27, np.int32), "er_src": (28, np.int32), "pb_src": (29, np.int32), "ell_src2": (30, np.int32),
+    "col_seg_first": (34, np.int32), "pb_seg_unit": (35, np.int32),
 }
 
 
@@ -311,14 +312,21 @@ def partition_graph(indptr, indices, nparts, max_part_rows=0, vwgt=None, cfg=Non
 class Plan:
     """ehyb_plan: the device-resident EHYB layout of one (permuted) matrix."""
 
-    def __init__(self, matrix, cfg=None, rows=None, upload=True):
+    def __init__(self, matrix, cfg=None, rows=None, upload=True, col_segs=None):
+        """col_segs (multi-GPU): first column of every column segment + the dimension (ehyb_plan_create_host_segs);
+        the multiply can then run segment by segment (spmv_part)."""
         self.lib = _lib.load()
         self.h = C.c_void_p()
         self.n = matrix.n
         r0, r1 = (0, matrix.n) if rows is None else rows
         self.rows = (r0, r1)
-        _check(self.lib.ehyb_plan_create_host(C.byref(matrix.c), r0, r1, C.byref(cfg) if cfg else None,
-                                              C.byref(self.h)), "ehyb_plan_create_host")
+        if col_segs is None:
+            _check(self.lib.ehyb_plan_create_host(C.byref(matrix.c), r0, r1, C.byref(cfg) if cfg else None,
+                                                  C.byref(self.h)), "ehyb_plan_create_host")
+        else:
+            segs = np.ascontiguousarray(col_segs, dtype=np.int32)
+            _check(self.lib.ehyb_plan_create_host_segs(C.byref(matrix.c), r0, r1, C.byref(cfg) if cfg else None, len(segs) - 1,
+                                                       _ptr(segs, C.c_int), C.byref(self.h)), "ehyb_plan_create_host_segs")
         if upload:
             self.upload()
 
@@ -371,6 +379,17 @@ class Plan:
         """Asynchronous y = A x on device pointers (ints)."""
         _check(self.lib.ehyb_spmv_phase(self.h, C.c_void_p(x_dev), C.c_void_p(y_dev), C.c_void_p(stream), phase),
                "ehyb_spmv")
+
+    def spmv_part(self, x_dev, y_dev, stream, seg_begin, seg_end, flags):
+        """ehyb_spmv_part: flags 1 = the ELL launch first, 2 = the closing pass (EHYB_PART_FIRST / _LAST)."""
+        _check(self.lib.ehyb_spmv_part(self.h, C.c_void_p(x_dev), C.c_void_p(y_dev), C.c_void_p(stream), seg_begin, seg_end, flags),
+               "ehyb_spmv_part")
+
+    @property
+    def col_segs(self):
+        n = C.c_int(0)
+        _check(self.lib.ehyb_plan_col_segs(self.h, C.byref(n)), "ehyb_plan_col_segs")
+        return n.value
 
     def spmv_host(self, x, iters=1):
         x = np.ascontiguousarray(x, dtype=np.float64)

@@ -245,6 +245,15 @@ typedef struct ehyb_plan ehyb_plan;
  */
 int ehyb_plan_create_host(const matrixCOO* m, int row_begin, int row_end,
                           const ehyb_config* cfg, ehyb_plan** plan);
+/*
+ * The same for a multi-GPU rank (no reference counterpart): the columns come in n_col_segs SEGMENTS,
+ * col_seg_first[0] = 0 < ... <= col_seg_first[n_col_segs] = dimension, every start but the first even -- the rank's
+ * own columns first, then the ghost columns in the order their x entries ARRIVE (one segment per exchange step).
+ * A panel of the panel-form residual never straddles a boundary, so ehyb_spmv_part can multiply segment by segment
+ * while later segments are still on the wire.  n_col_segs = 0: one segment (ehyb_plan_create_host).
+ */
+int ehyb_plan_create_host_segs(const matrixCOO* m, int row_begin, int row_end, const ehyb_config* cfg,
+                               int n_col_segs, const int* col_seg_first, ehyb_plan** plan);
 /* Allocate device arrays and copy the layout (cudaMallocTransDataEHYB, spmv.cu:6-60). */
 int ehyb_plan_upload(ehyb_plan* plan);
 /* create_host + upload */
@@ -356,9 +365,11 @@ enum {
                                    bit 14 = that piece's slot does not follow the previous piece's: a "jump" (the
                                    first entry of a chunk always is one)                                              */
     EHYB_ARR_PB_CHUNK      = 32,/* uint32 [chunks+1] index of the chunk's first jump in PB_JUMP; last = number of jumps */
-    EHYB_ARR_PB_JUMP       = 33 /* uint32 per jump: its slot minus the pieces before it in its chunk (mod 2^32), so that
+    EHYB_ARR_PB_JUMP       = 33,/* uint32 per jump: its slot minus the pieces before it in its chunk (mod 2^32), so that
                                    slot(entry) = PB_JUMP[chunk's first + jumps up to the entry - 1] + pieces before the
                                    entry's; the padding piece of a panel's last chunk yields 0xFFFFFFFF             */
+    EHYB_ARR_COL_SEG_FIRST = 34,/* int32  [segments+1] column segments of ehyb_plan_create_host_segs (empty: one segment)  */
+    EHYB_ARR_PB_SEG_UNIT   = 35 /* int32  [segments+1] panel form: first pass-1 unit of every column segment              */
 };
 int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int64_t* count);
 
@@ -382,6 +393,34 @@ int ehyb_spmv(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream)
  * Phase 2 must follow phase 1 on the same stream before y is read: where partitions were given up to a
  * panel-form residual (their windows did not pay), phase 1 leaves their rows alone and phase 2 ASSIGNS them. */
 int ehyb_spmv_phase(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream, int phase);
+
+/*
+ * The multiply in PARTS, for a caller that receives x segment by segment (multi-GPU, ehyb_plan_create_host_segs):
+ *   flags & EHYB_PART_FIRST   the ELL launch (window columns: all inside column segment 0) runs first;
+ *   column segments [seg_begin, seg_end): pass 1 of the panel-form residual over the panels of those segments
+ *                             (needs x of those columns only);
+ *   flags & EHYB_PART_LAST    pass 2 of the panel form (every pass 1 must have been enqueued on `stream` before) --
+ *                             or, for a plan whose residual is in CSR form, the residual launch (all of x).
+ * ehyb_spmv == one call with every segment and both flags.  Parts of one multiply go to ONE stream, in order.
+ */
+enum { EHYB_PART_FIRST = 1, EHYB_PART_LAST = 2 };
+int ehyb_spmv_part(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream, int seg_begin, int seg_end, int flags);
+/* Column segments of the plan (1 unless made by ehyb_plan_create_host_segs). */
+int ehyb_plan_col_segs(const ehyb_plan* plan, int* n_col_segs);
+/* dst[i] = src[idx[i]], i < n, on `stream`: packs the x entries the other ranks asked for (the send list of a halo
+ * exchange) -- device pointers. */
+int ehyb_gather(const double* src_dev, const int32_t* idx_dev, double* dst_dev, int64_t n, void* stream);
+/*
+ * Stream plumbing of one exchange step, so that the host issues ONE call per part instead of an event record, a stream
+ * wait and a launch each (the host side of a step costs as much as the device side at 8 GPUs: DESIGN.md 5):
+ *   ehyb_step_pack   on compute_stream: ehyb_gather into send_buf; then comm_stream waits for it (the collective that
+ *                    the caller enqueues on comm_stream next reads send_buf);
+ *   ehyb_step_part   wait_comm != 0: compute_stream first waits for everything enqueued on comm_stream so far (the
+ *                    collective that delivers this part's columns); then ehyb_spmv_part on compute_stream.
+ */
+int ehyb_step_pack(const double* x_dev, const int32_t* idx_dev, double* send_buf_dev, int64_t n, void* compute_stream, void* comm_stream);
+int ehyb_step_part(ehyb_plan* plan, const double* x_dev, double* y_dev, void* compute_stream, void* comm_stream, int wait_comm,
+                   int seg_begin, int seg_end, int flags);
 
 /*
  * Timed loop on device-resident vectors: `warmup` untimed multiplies, then `iters`

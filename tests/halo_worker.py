@@ -16,16 +16,33 @@ from ehyb_spmv_gpu_amd import dist as D  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 
-def check_rank(tag, I, J, V, cuts, rank, world, cfg, symmetric):
+def check_rank(tag, I, J, V, cuts, rank, world, cfg, symmetric, chunks=1, shares=None):
     n_glob = cuts[-1]
     r0, r1 = cuts[rank], cuts[rank + 1]
     x = O.x_glibc(n_glob)                       # every rank can compute any x entry: x is a function of the index
     y_ref = O.spmv_coo(n_glob, I, J, V, x)[r0:r1]
     scale = O.abs_rowsum(n_glob, I, J, V, x)[r0:r1]
-    L = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, symmetric=symmetric)
-    assert L.m.n == L.n_loc + L.n_ghost and L.m.nnz == len(V)
-    assert int(L.recv_counts.sum()) == L.n_ghost and L.recv_counts[rank] == 0 and L.send_counts[rank] == 0
+    L = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, symmetric=symmetric, chunks=chunks, chunk_shares=shares)
+    assert L.m.n == L.n_loc + L.n_ext and L.m.nnz == len(V)
+    assert L.recv_counts.shape == (L.chunks, world) and L.send_counts.shape == (L.chunks, world)
+    assert int(L.recv_counts.sum()) == L.n_ghost and not L.recv_counts[:, rank].any() and not L.send_counts[:, rank].any()
+    segs = L.col_segs
+    assert segs[0] == 0 and segs[-1] == L.m.n and len(segs) == L.chunks + 2 and not (segs[1:-1] & 1).any() and segs[1] >= L.n_loc
+    # inside a chunk the slots are grouped by owner, and an owner's columns come hottest first
+    gs, refs = np.unique(J[(J < r0) | (J >= r1)], return_counts=True)
+    assert len(gs) == L.n_ghost and np.array_equal(np.sort(L.ghost_cols), gs)
+    slot_refs = refs[np.searchsorted(gs, L.ghost_cols)]
+    owner = np.searchsorted(np.asarray(cuts), L.ghost_cols, side="right") - 1
+    at = 0
+    for k in range(L.chunks):
+        for p in range(world):
+            c = int(L.recv_counts[k, p])
+            assert np.all(owner[at:at + c] == p) and np.all(np.diff(slot_refs[at:at + c]) <= 0)
+            at += c
+    assert at == L.n_ghost
     plan = L.plan(upload=False)
+    if world > 1:
+        assert plan.col_segs == L.chunks + 1 and np.array_equal(plan.array("col_seg_first"), segs)
     st = plan.stats
     # phase 1 must not touch a ghost slot: window columns are local
     hc = plan.array("halo_cols")
@@ -34,13 +51,26 @@ def check_rank(tag, I, J, V, cuts, rank, world, cfg, symmetric):
     # every entry that references a remote column is in the residual
     remote = int(((J < r0) | (J >= r1)).sum())
     assert st["nnz_er"] >= remote and (world > 1 or remote == 0)
-    x_ext = torch.zeros(L.n_loc + L.n_ghost, dtype=torch.float64)
+    x_ext = torch.zeros(L.n_loc + L.n_ext, dtype=torch.float64)
     x_ext[:L.n_loc] = torch.from_numpy(L.x_to_plan(x[r0:r1]))
-    D.HaloExchange(L, x_ext).run()
-    assert np.array_equal(x_ext[L.n_loc:].numpy(), x[L.ghost_cols]), "ghost slots do not hold the owners' x entries"
+    if world > 1:
+        # pack on the CPU (ehyb_step_pack is a device call): what the peers asked for, in their slot order
+        hx = D.HaloExchange(L, x_ext, mode="p2p" if tag.endswith("-p2p") else "a2a")
+        hx.send_buf.copy_(x_ext[torch.from_numpy(L.send_idx.astype(np.int64))])
+        for k in range(L.chunks):
+            hx.transfer(k)
+    assert np.array_equal(x_ext.numpy()[L.ghost_slot_col], x[L.ghost_cols]), "ghost slots do not hold the owners' x entries"
     if tag == "rmat-rows-panel" and world > 1:
         u2 = plan.array("pb_units2").reshape(-1, 4)
         assert st["er_partials"] > 0 and np.any(u2[:, 3] < 0), "the panel case should run in assign mode"
+    if st["er_partials"] > 0 and world > 1:
+        # a panel never straddles a column segment, and the units of a segment are a run of the unit list
+        u1 = plan.array("pb_units1").reshape(-1, 4)
+        su = plan.array("pb_seg_unit")
+        assert len(su) == len(segs) and su[0] == 0 and su[-1] == len(u1)
+        for s in range(len(segs) - 1):
+            uu = u1[su[s]:su[s + 1]]
+            assert np.all(uu[:, 0] >= segs[s]) and np.all(uu[:, 0] + uu[:, 1] <= segs[s + 1])
     y_plan, written = O.walk_plan(plan, x_ext.numpy())
     assert written[:L.n_loc].min() == 1 and written.sum() == L.n_loc
     y = L.y_from_plan(y_plan[:L.n_loc])
@@ -93,6 +123,11 @@ def main():
     # rank pays, every partition is given up, phase 1 is empty and pass 2 of the panel residual assigns every row
     cfgp = E.make_config(lds_doubles=256, er_mode=2, er_panel_cols=512, er_block_rows=300)
     bad += check_rank("rmat-rows-panel", g.I[a:b].copy(), g.J[a:b].copy(), g.V[a:b].copy(), base, rank, world, cfgp, symmetric=False)
+    # 2c. the same with the ghost columns in three chunks of unequal share (three exchange steps, four column segments),
+    # and in two chunks through explicit send/recv pairs
+    bad += check_rank("rmat-rows-panel-chunks", g.I[a:b].copy(), g.J[a:b].copy(), g.V[a:b].copy(), base, rank, world, cfgp, symmetric=False,
+                      chunks=3, shares=[0.2, 0.3, 0.5])
+    bad += check_rank("rmat-rows-chunks-p2p", g.I[a:b].copy(), g.J[a:b].copy(), g.V[a:b].copy(), base, rank, world, cfg, symmetric=False, chunks=2)
     # 3. block diagonal: no ghosts at all, the exchange is empty
     cfg = E.make_config(lds_doubles=1024, window_mode=1, partitioner=1)
     g = E.Matrix.generate("banded", 2048, 16, 1024, cfg=cfg)
@@ -113,7 +148,7 @@ def main():
         a, b = int(A.indptr[fcuts[rank]]), int(A.indptr[fcuts[rank + 1]])
         rows = np.repeat(np.arange(nA, dtype=np.int32), np.diff(A.indptr))
         bad += check_rank(f"fuzz-{seed}", rows[a:b].copy(), A.indices[a:b].astype(np.int32), A.data[a:b].copy(), fcuts, rank, world,
-                          E.make_config(**kw), symmetric=False)
+                          E.make_config(**kw), symmetric=False, chunks=1 + seed % 3)
     dist.barrier()
     if rank == 0:
         print("HALO_OK" if bad == 0 else f"HALO_FAIL {bad}", flush=True)

@@ -76,6 +76,34 @@ def test_world_size_mismatch_is_refused(gpu):
     assert p.returncode != 0 and "WORLD_SIZE=2" in p.stderr
 
 
+@pytest.mark.parametrize("world", [2, 3])
+def test_pipelined_step_equals_plain_step(gpu, world):
+    """The chunked, pipelined exchange step (own-column panels while chunk 0 travels, chunk k's panels while chunk k+1
+    travels, one C call per part) against the plain step (every chunk, then one multiply) on the same plan: R-MAT 2^18 in
+    panel form with 3 chunks (all_to_all) and 2 chunks (send/recv pairs), CSR residual, and a FEM matrix with windows --
+    equal to rounding of the atomics' order (bit for bit where the kernels are deterministic), all equal to the oracle."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "pipeline_worker.py")]
+    p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ), cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
+    assert "PIPE_OK" in p.stdout and p.stdout.count("PIPE_CASE") == 4, p.stdout[-2000:]
+
+
+def test_strong_bench_line_carries_the_step_anatomy(gpu):
+    """bench.py --gpus 2 (strong, halo, 3 chunks): the JSON line says how much of the local multiply can run before the
+    first chunk lands, what the host spends per step, and who receives how much from whom per exchange step."""
+    out = _bench(2, ["--chunks", "3", "--chunk-shares", "0.2,0.3,0.5"], workload="rmat-18")
+    assert out["parity"]["rows_over_1e-12"] == 0
+    c = out["config"]
+    assert c["exchange_steps"] == 3 and c["pipelined"] is True and c["exchange_mode"] == "a2a"
+    vol = c["recv_doubles_by_rank_step_peer"]
+    assert len(vol) == 2 and all(len(r) == 3 and all(len(k) == 2 for k in r) for r in vol)
+    assert sum(sum(sum(k) for k in r) for r in vol) == c["exchange_doubles_received_all_gpus"]
+    assert vol[0][0][0] == 0 and vol[1][0][1] == 0          # nobody receives from itself
+    assert 0 < out["phase1_share_of_local_ms"] < 1 and out["host_us_per_step"] > 0
+    assert 0 < out["own_columns_share_of_entries"] < 1
+
+
 @pytest.mark.parametrize("world", [1, 2])
 def test_halo_cg_ranks_on_one_gpu(gpu, world):
     """HaloCG: conjugate gradients over the rank-local plans -- the direction vector travels through the
