@@ -126,7 +126,7 @@ Config resolve_config(const ehyb_config* in)
     c.ell_prune = z.ell_prune == 2 ? 2 : 1;
     c.value_map = z.value_map == 1 ? 1 : 0;
     c.prune_pct = z.prune_pct > 0 ? z.prune_pct : 110;
-    c.er_units1 = z.er_units1 > 0 ? z.er_units1 : 2048;
+    c.er_units1 = z.er_units1 > 0 ? z.er_units1 : 1024;
     c.er_units2 = z.er_units2 > 0 ? z.er_units2 : 2048;
     c.graph_compress = z.graph_compress == 2 ? 2 : 1;
     c.balance = (z.balance == 1 || z.balance == 2) ? z.balance : 0;

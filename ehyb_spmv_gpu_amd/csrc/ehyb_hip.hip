@@ -420,7 +420,7 @@ __device__ __forceinline__ double piece_sums(double prod, unsigned long long hea
 // xcd_map: workgroup b takes unit xcd_item(b): the units of one panel (neighbours in the unit list) then run on ONE XCD at
 // about the same time and stage their panel from its L2 instead of each from the fabric.
 template <int THREADS, bool SUMS_DPP>
-__global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __restrict__ units,
+__global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __restrict__ items, const int4* __restrict__ units,
                                                                 const double* __restrict__ val,
                                                                 const uint16_t* __restrict__ colf,
                                                                 const uint32_t* __restrict__ chunk,
@@ -432,7 +432,16 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
     // 4 no LDS gather, 8 no panel staging
     extern __shared__ __attribute__((aligned(16))) double win[];
     constexpr int WAVES = THREADS / 64;
-    const int4 u = units[xcd_map ? xcd_item(blockIdx.x, gridDim.x) : (int)blockIdx.x];
+    // one workgroup = one ITEM: a run of units of (nearly) equal total cost, cut by the host (er_panel.cpp); every unit is
+    // a stretch of one panel's entries and stages that panel once
+    const int2 it = items[xcd_map ? xcd_item(blockIdx.x, gridDim.x) : (int)blockIdx.x];
+    const int lane = threadIdx.x & 63;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double* scr = win + panel_cols + 64 * wave;  // this wave's 64 piece accumulators, behind the panel (!SUMS_DPP only)
+    if (!SUMS_DPP) scr[lane] = 0.0;
+  for (int un = it.x; un < it.y; ++un) {
+    const int4 u = units[un];
+    if (un != it.x) __syncthreads();  // every wave is done with the previous panel
     // stage the panel: all of a thread's loads in flight before the first store (a 64 KiB panel is 16
     // double2 loads per thread; one load per loop trip would pay the memory latency 16 times)
     if (!(probe & 8)) {
@@ -455,10 +464,6 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
         if ((u.y & 1) && threadIdx.x == 0) win[u.y - 1] = x[u.x + u.y - 1];
     }
     __syncthreads();
-    const int lane = threadIdx.x & 63;
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    double* scr = win + panel_cols + 64 * wave;  // this wave's 64 piece accumulators, behind the panel (!SUMS_DPP only)
-    if (!SUMS_DPP) scr[lane] = 0.0;
     const int c0 = u.z >> 6, c1 = u.w >> 6;  // chunks of 64 entries
     constexpr int K = 8;  // chunks per wave and step: 24 independent vector loads in flight per lane
     // The jump-list range of a chunk is known from the chunk records alone (wave-uniform, scalar loads): they are
@@ -538,6 +543,7 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int4* __re
 #pragma unroll
         for (int j = 0; j < K; ++j) f0[j] = g0[j], fn[j] = gn[j];
     }
+  }
 }
 
 // Pass 2: one workgroup per unit {first partial, end partial, first row, rows}.  The row block's
@@ -705,13 +711,13 @@ static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st, 
     return launch_ell_impl<false>(P, x, y, st, inl, nullptr);
 }
 
-// which: 1 = pass 1 (scale), 2 = pass 2 (reduce), 3 = both; pass 1 over the units [unit_begin, unit_end) (-1: all)
+// which: 1 = pass 1 (scale), 2 = pass 2 (reduce), 3 = both; pass 1 over the items [unit_begin, unit_end) (-1: all)
 static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st, int probe, int which, int unit_begin = 0, int unit_end = -1)
 {
     const HostLayout& H = P->host;
-    const int u_all = (int)(H.pb_units1.size() / 4), u2 = (int)(H.pb_units2.size() / 4);
+    const int u_all = (int)(H.pb_items1.size() / 2), u2 = (int)(H.pb_units2.size() / 4);
     if (unit_end < 0) unit_end = u_all;
-    if (unit_begin < 0 || unit_end > u_all || unit_begin > unit_end) EHYB_FAIL(EHYB_ERR_ARG, "launch_panel: units [%d, %d) of %d", unit_begin, unit_end, u_all);
+    if (unit_begin < 0 || unit_end > u_all || unit_begin > unit_end) EHYB_FAIL(EHYB_ERR_ARG, "launch_panel: items [%d, %d) of %d", unit_begin, unit_end, u_all);
     const int u1 = unit_end - unit_begin;
     if ((which & 1) && u1 > 0) {
         // panels of up to 9,728 columns: two 512-thread workgroups per CU (one stages while the other streams); wider
@@ -720,7 +726,7 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
         const bool dpp = P->cfg.er_sums != 2;
         const int xcd = P->cfg.xcd_map != 2 ? 1 : 0;
 #define PB_SCALE(T, D)                                                                                                          \
-    hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D>), dim3(u1), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T))) * 8, st, (const int4*)P->d_pb_units1 + unit_begin, \
+    hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D>), dim3(u1), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T))) * 8, st, (const int2*)P->d_pb_items1 + unit_begin, (const int4*)P->d_pb_units1, \
                        P->d_pb_val, P->d_pb_colf, P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, probe, xcd)
         if (wide) {
             if (dpp) PB_SCALE(1024, true); else PB_SCALE(1024, false);
@@ -779,7 +785,7 @@ static void free_device(ehyb_plan* P)
                      (void**)&P->d_slab_meta,  (void**)&P->d_items,     (void**)&P->d_segs,       (void**)&P->d_er_seg_ptr,
                      (void**)&P->d_er_seg_row, (void**)&P->d_er_col,    (void**)&P->d_er_val,     (void**)&P->d_er_blocks,
                      (void**)&P->d_slab_lrow,  (void**)&P->d_pb_val,    (void**)&P->d_pb_colf,    (void**)&P->d_pb_chunk,   (void**)&P->d_pb_jump,
-                     (void**)&P->d_pb_units1,  (void**)&P->d_pb_row,    (void**)&P->d_pb_units2,  (void**)&P->d_pb_partial,
+                     (void**)&P->d_pb_units1,  (void**)&P->d_pb_items1,  (void**)&P->d_pb_row,    (void**)&P->d_pb_units2,  (void**)&P->d_pb_partial,
                      (void**)&P->d_ell_src,    (void**)&P->d_ell_src2,  (void**)&P->d_er_src,     (void**)&P->d_pb_src};
     for (void** q : ptrs) {
         if (*q) (void)hipFree(*q);
@@ -948,6 +954,7 @@ int ehyb_plan_upload(ehyb_plan* P)
         UP(d_pb_chunk, pb_chunk)
         UP(d_pb_jump, pb_jump)
         UP(d_pb_units1, pb_units1)
+        UP(d_pb_items1, pb_items1)
         UP(d_pb_row, pb_row)
         UP(d_pb_units2, pb_units2)
         if (hipMalloc((void**)&P->d_pb_partial, (size_t)std::max<int64_t>(H.pb_partials, 1) * 8) != hipSuccess) {
@@ -1038,8 +1045,8 @@ int ehyb_spmv_part(ehyb_plan* P, const double* x, double* y, void* stream, int s
     if (rc != EHYB_OK || H.er_bins[3] == 0) return rc;
     if (!H.er_panel) return (flags & EHYB_PART_LAST) ? launch_er(P, x, y, st) : EHYB_OK;  // CSR residual: one launch, needs all of x
     if (seg_end > seg_begin) {
-        const int ub = H.pb_seg_unit.empty() ? 0 : H.pb_seg_unit[(size_t)seg_begin];
-        const int ue = H.pb_seg_unit.empty() ? -1 : H.pb_seg_unit[(size_t)seg_end];
+        const int ub = H.pb_seg_item.empty() ? 0 : H.pb_seg_item[(size_t)seg_begin];
+        const int ue = H.pb_seg_item.empty() ? -1 : H.pb_seg_item[(size_t)seg_end];
         rc = launch_panel(P, x, y, st, 0, 1, ub, ue);
     }
     if (rc == EHYB_OK && (flags & EHYB_PART_LAST)) rc = launch_panel(P, x, y, st, 0, 2);

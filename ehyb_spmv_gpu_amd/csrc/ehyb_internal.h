@@ -131,7 +131,8 @@ struct HostLayout {
     std::vector<double> pb_val;       // pass-1 order, panels padded to multiples of 64 entries
     std::vector<uint16_t> pb_col;     // column - panel start
     std::vector<uint32_t> pb_dst;     // partial slot; 0xFFFFFFFF = padding
-    std::vector<int32_t> pb_units1;   // {first column, columns, first entry, end entry}
+    std::vector<int32_t> pb_units1;   // {first column, columns, first entry, end entry}: a stretch of one panel's entries
+    std::vector<int32_t> pb_items1;   // {first unit, end unit}: one pass-1 workgroup's work, a run of units of equal total cost
     std::vector<uint16_t> pb_row;     // per partial: row - first row of its block
     std::vector<int32_t> pb_units2;   // {first partial, end partial, first row, rows}; rows < 0: the block ASSIGNS y (-rows rows)
     // Partitions that went to the residual whole (their window did not pay, plan.cpp) have no ELL work at all:
@@ -140,10 +141,10 @@ struct HostLayout {
     bool pb_assign = false;
     std::vector<uint8_t> part_windowless;  // [n_parts] host only
     // Column segments (multi-GPU, ehyb_plan_create_host_segs): [0] = 0 < ... < [n] = n_cols; a panel never straddles a
-    // boundary, and the pass-1 units of segment s are pb_seg_unit[s] .. pb_seg_unit[s+1] -- the multiply can then run
+    // boundary, and the pass-1 items of segment s are pb_seg_item[s] .. pb_seg_item[s+1] -- the multiply can then run
     // segment by segment as the x entries of each arrive (ehyb_spmv_part).  Empty = one segment.
     std::vector<int32_t> col_seg_first;
-    std::vector<int32_t> pb_seg_unit;
+    std::vector<int32_t> pb_seg_item;
     // what pass 1 streams in place of pb_col + pb_dst (derived from them by encode_panel_slots, not stored in plan files)
     std::vector<uint16_t> pb_colf;    // column | head flag (bit 15) | jump flag (bit 14)
     std::vector<uint32_t> pb_chunk;   // per 64-entry chunk: its first jump
@@ -234,6 +235,7 @@ struct ehyb_plan {
     uint32_t* d_pb_chunk = nullptr;
     uint32_t* d_pb_jump = nullptr;
     int32_t* d_pb_units1 = nullptr;
+    int32_t* d_pb_items1 = nullptr;
     uint16_t* d_pb_row = nullptr;
     int32_t* d_pb_units2 = nullptr;
     double* d_pb_partial = nullptr;  // [pb_partials] written by pass 1, read by pass 2: one multiply at a time per plan

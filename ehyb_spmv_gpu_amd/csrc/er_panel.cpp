@@ -272,20 +272,67 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     for (int64_t pos = 0; pos < padded; ++pos)
         if (L->pb_dst[(size_t)pos] != 0xFFFFFFFFu) L->pb_dst[(size_t)pos] = slot_of_piece[L->pb_dst[(size_t)pos]];
 
-    // ---- work units
-    // pass 1: {first column, columns, first entry, end entry} -- chunks of a panel, multiples of 64 entries
-    const int64_t c1 = std::min<int64_t>(std::max<int64_t>((padded / cfg.er_units1 + 63) / 64 * 64, 8192), 1 << 20);
+    // ---- work of pass 1: ITEMS of equal cost, one workgroup each; an item is a run of UNITS {first column, columns,
+    // first entry, end entry} -- a stretch of one panel's entries, multiples of 64 -- and stages a panel once per unit.
+    // (Round 2: one workgroup per unit of padded/2048 entries, handed out by the hardware.  A heavy panel -- the hub
+    // columns of a degree-ordered matrix hold a third of all entries -- was then staged hundreds of times, and a
+    // workgroup lived for four loop trips per wave: R-MAT 2^22 moved 139 MB of staging for 350 MB of entries.)
+    // Cost of a unit = 11 B per entry (value, column word, its share of the chunk records) + 8 B per staged column +
+    // a fixed 16 KiB for the two barriers and the pipeline fill.  Items never straddle a column segment.
+    const int64_t kPerEntry = 11, kPerCol = 8, kFixed = 16384;
     L->pb_units1.clear();
-    L->pb_seg_unit.assign((size_t)n_segs + 1, 0);
+    L->pb_items1.clear();
+    L->pb_seg_item.assign((size_t)n_segs + 1, 0);
     int64_t staged = 0;
-    for (int s = 0; s < n_segs; ++s) {
-        for (int p = seg_panel0[s]; p < seg_panel0[s + 1]; ++p)
-            for (int64_t b = pstart[p]; b < pstart[p + 1]; b += c1) {
-                const int32_t u[4] = {panel_first[p], std::min(W, seg_first[s + 1] - panel_first[p]), (int32_t)b, (int32_t)std::min(b + c1, pstart[p + 1])};
-                L->pb_units1.insert(L->pb_units1.end(), u, u + 4);
-                staged += u[1];
+    {
+        int64_t total_cost = 0;
+        std::vector<int64_t> seg_cost((size_t)n_segs, 0);
+        for (int s = 0; s < n_segs; ++s)
+            for (int p = seg_panel0[s]; p < seg_panel0[s + 1]; ++p)
+                if (pstart[p + 1] > pstart[p]) {
+                    const int64_t c = kPerEntry * (pstart[p + 1] - pstart[p]) + kPerCol * std::min(W, seg_first[s + 1] - panel_first[p]) + kFixed;
+                    seg_cost[(size_t)s] += c;
+                    total_cost += c;
+                }
+        for (int s = 0; s < n_segs; ++s) {
+            if (seg_cost[(size_t)s] == 0) {
+                L->pb_seg_item[(size_t)s + 1] = (int32_t)(L->pb_items1.size() / 2);
+                continue;
             }
-        L->pb_seg_unit[(size_t)s + 1] = (int32_t)(L->pb_units1.size() / 4);
+            // this segment's share of the items; the target leaves room for the extra stagings the cuts add
+            const int64_t want = std::max<int64_t>(1, (int64_t)((double)cfg.er_units1 * (double)seg_cost[(size_t)s] / (double)total_cost + 0.5));
+            const int64_t target = seg_cost[(size_t)s] / want + (kPerCol * W + kFixed) / 2 + 1;
+            int64_t item_cost = 0;
+            int32_t item_first = (int32_t)(L->pb_units1.size() / 4);
+            auto close_item = [&]() {
+                const int32_t end = (int32_t)(L->pb_units1.size() / 4);
+                if (end > item_first) {
+                    L->pb_items1.push_back(item_first);
+                    L->pb_items1.push_back(end);
+                }
+                item_first = end;
+                item_cost = 0;
+            };
+            for (int p = seg_panel0[s]; p < seg_panel0[s + 1]; ++p) {
+                const int32_t cols = std::min(W, seg_first[s + 1] - panel_first[p]);
+                const int64_t stage = kPerCol * cols + kFixed;
+                int64_t pos = pstart[p];
+                while (pos < pstart[p + 1]) {
+                    // not worth staging a panel for less than a quarter of what it costs to stage it
+                    if (item_cost > 0 && target - item_cost < stage + stage / 4) close_item();
+                    const int64_t fit = std::max<int64_t>(64, (target - item_cost - stage) / kPerEntry / 64 * 64);
+                    const int64_t take = std::min(pstart[p + 1] - pos, fit);
+                    const int32_t u[4] = {panel_first[p], cols, (int32_t)pos, (int32_t)(pos + take)};
+                    L->pb_units1.insert(L->pb_units1.end(), u, u + 4);
+                    staged += cols;
+                    item_cost += stage + kPerEntry * take;
+                    pos += take;
+                    if (item_cost >= target) close_item();
+                }
+            }
+            close_item();
+            L->pb_seg_item[(size_t)s + 1] = (int32_t)(L->pb_items1.size() / 2);
+        }
     }
     // pass 2: {first slot, end slot, first row, rows}; blocks without partials are skipped -- unless the block
     // ASSIGNS y (rows stored negative): then it is the only writer of its rows
@@ -311,11 +358,11 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     encode_panel_slots(L);
     // (value, column+flags) + chunk records + jump list instead of a 4-byte slot per entry
     L->pb_bytes = 10 * padded + 4 * (padded / 64 + 1) + 4 * (int64_t)L->pb_jump.size() + 8 * staged + 8 * n_pieces + 10 * n_pieces + (L->pb_assign ? 8 * rows_assigned + 16 * std::max<int64_t>(0, L->stats.rows_er - rows_assigned) : 16 * L->stats.rows_er) +
-                  16 * (int64_t)(L->pb_units1.size() / 4 + L->pb_units2.size() / 4);
+                  16 * (int64_t)(L->pb_units1.size() / 4 + L->pb_units2.size() / 4) + 8 * (int64_t)(L->pb_items1.size() / 2);
     if (cfg.verbose)
         printf("panel residual: %lld entries (%lld with padding) in %d panels of %d columns -> %lld partials, %zu + %zu work units, "
                "row blocks <= %d rows\n",
-               (long long)nnz_er, (long long)padded, n_panels, W, (long long)n_pieces, L->pb_units1.size() / 4, L->pb_units2.size() / 4,
+               (long long)nnz_er, (long long)padded, n_panels, W, (long long)n_pieces, L->pb_items1.size() / 2, L->pb_units2.size() / 4,
                max_rows);
     (void)rows_touched;
     return EHYB_OK;

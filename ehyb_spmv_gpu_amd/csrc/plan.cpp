@@ -212,7 +212,8 @@ int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int
         case EHYB_ARR_PB_SRC: VIEW(H.pb_src);
         case EHYB_ARR_ELL_SRC2: VIEW(H.ell_src2);
         case EHYB_ARR_COL_SEG_FIRST: VIEW(H.col_seg_first);
-        case EHYB_ARR_PB_SEG_UNIT: VIEW(H.pb_seg_unit);
+        case EHYB_ARR_PB_SEG_ITEM: VIEW(H.pb_seg_item);
+        case EHYB_ARR_PB_ITEMS1: VIEW(H.pb_items1);
         case EHYB_ARR_ER_BINS:
             *ptr = (const void*)H.er_bins;
             *count = 8;

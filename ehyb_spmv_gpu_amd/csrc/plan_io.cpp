@@ -62,7 +62,7 @@ bool each_array(HostLayout& H, F&& io)
            io(H.slab_row) && io(H.slab_part) && io(H.ell_val) && io(H.ell_col) && io(H.slab_col_ptr) && io(H.lane_group) &&
            io(H.slab_meta) && io(H.items) && io(H.segs) && io(H.er_seg_ptr) && io(H.er_seg_row) && io(H.er_col) &&
            io(H.er_val) && io(H.er_blocks) && io(H.slab_lrow) && io(H.pb_val) && io(H.pb_col) && io(H.pb_dst) &&
-           io(H.pb_units1) && io(H.pb_row) && io(H.pb_units2) && io(H.col_seg_first) && io(H.pb_seg_unit);
+           io(H.pb_units1) && io(H.pb_row) && io(H.pb_units2) && io(H.col_seg_first) && io(H.pb_seg_item) && io(H.pb_items1);
 }
 
 struct Scalars {
@@ -83,6 +83,12 @@ bool panel_consistent(const HostLayout& H)
     if (H.pb_col.size() != ne || H.pb_dst.size() != ne || ne % 64 != 0 || H.pb_units1.size() % 4 || H.pb_units2.size() % 4) return false;
     if (H.pb_partials < 0 || H.pb_row.size() != (size_t)H.pb_partials) return false;
     if (H.pb_panel_cols < 64 || H.pb_panel_cols > 16384 || H.pb_rows_max < 1 || H.pb_rows_max > 16384) return false;
+    if (H.pb_items1.size() % 2) return false;
+    for (size_t i = 0; i < H.pb_items1.size(); i += 2)  // the items are consecutive runs of the unit list, all of it
+        if (H.pb_items1[i] != (i ? H.pb_items1[i - 1] : 0) || H.pb_items1[i + 1] <= H.pb_items1[i] || (size_t)H.pb_items1[i + 1] > H.pb_units1.size() / 4) return false;
+    if (!H.pb_items1.empty() && (size_t)H.pb_items1.back() != H.pb_units1.size() / 4) return false;
+    if (H.pb_items1.empty() != H.pb_units1.empty()) return false;
+    if (!H.pb_seg_item.empty() && (H.pb_seg_item.size() != H.col_seg_first.size() + (H.col_seg_first.empty() ? 2 : 0) || H.pb_seg_item.front() != 0 || (size_t)H.pb_seg_item.back() != H.pb_items1.size() / 2)) return false;
     for (size_t u = 0; u < H.pb_units1.size(); u += 4) {
         const int32_t* q = &H.pb_units1[u];
         if (q[0] < 0 || q[1] < 1 || q[1] > H.pb_panel_cols || (int64_t)q[0] + q[1] > H.n_cols || q[2] < 0 || q[3] < q[2] || (size_t)q[3] > ne ||

@@ -28,7 +28,7 @@ ARRAYS = {
     "pb_row": (25, np.uint16), "pb_units2": (26, np.int32),
     "pb_colf": (31, np.uint16), "pb_chunk": (32, np.uint32), "pb_jump": (33, np.uint32),
     "ell_src": (27, np.int32), "er_src": (28, np.int32), "pb_src": (29, np.int32), "ell_src2": (30, np.int32),
-    "col_seg_first": (34, np.int32), "pb_seg_unit": (35, np.int32),
+    "col_seg_first": (34, np.int32), "pb_seg_item": (35, np.int32), "pb_items1": (36, np.int32),
 }
 
 

@@ -157,7 +157,7 @@ typedef struct ehyb_config {
        EHYB_MTMETIS_LIB, names a shared object to load the optional mt-metis backend from). */
     int32_t prune_pct;     /* ell_prune: a window is given up when it costs more than this share (per cent) of what
                               the panel form would cost for its entries; 0 = 110                                */
-    int32_t er_units1;     /* panel form: work units pass 1 aims at (0 = 2048)                                 */
+    int32_t er_units1;     /* panel form: work items (workgroups) pass 1 aims at (0 = 1024)                     */
     int32_t er_units2;     /* panel form: row blocks pass 2 aims at (0 = 2048)                                 */
     int32_t graph_compress;/* 0/1 = the k-way partitioner works on the compressed graph where rows come in groups with one
                               column list (the unknowns of a node), 2 = never.  Plain storage (sym_pairs off) ignores it
@@ -348,7 +348,8 @@ enum {
     EHYB_ARR_PB_COL        = 22,/* uint16 same length: column - first column of the panel                  */
     EHYB_ARR_PB_DST        = 23,/* uint32 same length: partial sum the entry belongs to (entries of one row that are
                                    neighbours inside a 64-entry chunk share one); 0xFFFFFFFF = padding     */
-    EHYB_ARR_PB_UNITS1     = 24,/* int32  [4*u1] pass-1 work units {first column, columns, first entry, end entry}  */
+    EHYB_ARR_PB_UNITS1     = 24,/* int32  [4*u1] pass-1 units {first column, columns, first entry, end entry}: a stretch of the
+                                   entries of one panel (multiples of 64), staged once                     */
     EHYB_ARR_PB_ROW        = 25,/* uint16 [er_partials] row of the partial - first row of its row block; partials are
                                    numbered by (row block, panel, row)                                     */
     EHYB_ARR_PB_UNITS2     = 26,/* int32  [4*u2] pass-2 work units {first partial, end partial, first row, rows}    */
@@ -369,7 +370,9 @@ enum {
                                    slot(entry) = PB_JUMP[chunk's first + jumps up to the entry - 1] + pieces before the
                                    entry's; the padding piece of a panel's last chunk yields 0xFFFFFFFF             */
     EHYB_ARR_COL_SEG_FIRST = 34,/* int32  [segments+1] column segments of ehyb_plan_create_host_segs (empty: one segment)  */
-    EHYB_ARR_PB_SEG_UNIT   = 35 /* int32  [segments+1] panel form: first pass-1 unit of every column segment              */
+    EHYB_ARR_PB_SEG_ITEM   = 35,/* int32  [segments+1] panel form: first pass-1 item of every column segment              */
+    EHYB_ARR_PB_ITEMS1     = 36 /* int32  [2*items] {first unit, end unit}: the work of one pass-1 workgroup -- consecutive
+                                   units of (nearly) equal total cost (entries streamed + panels staged)                */
 };
 int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int64_t* count);
 

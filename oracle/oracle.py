@@ -364,6 +364,17 @@ def walk_panel_residual(plan, x, written=None):
         np.add.at(partial, dst[k], val[k] * win[col[k]])
         covered[b:e] += 1
     assert np.all(covered == 1), "every entry belongs to exactly one pass-1 unit"
+    # one pass-1 workgroup = one item = a run of consecutive units; the items tile the unit list; with column segments
+    # (multi-GPU) an item stays inside one segment
+    it1 = plan.array("pb_items1").reshape(-1, 2)
+    assert len(it1) > 0 and it1[0, 0] == 0 and it1[-1, 1] == len(u1) and np.all(it1[1:, 0] == it1[:-1, 1]) and np.all(it1[:, 1] > it1[:, 0])
+    segf, segi = plan.array("col_seg_first"), plan.array("pb_seg_item")
+    if len(segf) >= 2:
+        assert len(segi) == len(segf) and segi[0] == 0 and segi[-1] == len(it1)
+        for s in range(len(segf) - 1):
+            if segi[s + 1] > segi[s]:
+                uu = u1[it1[segi[s], 0]:it1[segi[s + 1] - 1, 1]]
+                assert np.all(uu[:, 0] >= segf[s]) and np.all(uu[:, 0] + uu[:, 1] <= segf[s + 1]), "a pass-1 item straddles a column segment"
     y = np.zeros(n)
     seen = np.zeros(P, dtype=np.int32)
     rows_seen = np.zeros(n, dtype=np.int32)

@@ -66,11 +66,13 @@ def check_rank(tag, I, J, V, cuts, rank, world, cfg, symmetric, chunks=1, shares
     if st["er_partials"] > 0 and world > 1:
         # a panel never straddles a column segment, and the units of a segment are a run of the unit list
         u1 = plan.array("pb_units1").reshape(-1, 4)
-        su = plan.array("pb_seg_unit")
-        assert len(su) == len(segs) and su[0] == 0 and su[-1] == len(u1)
+        it1 = plan.array("pb_items1").reshape(-1, 2)
+        si = plan.array("pb_seg_item")
+        assert len(si) == len(segs) and si[0] == 0 and si[-1] == len(it1)
         for s in range(len(segs) - 1):
-            uu = u1[su[s]:su[s + 1]]
-            assert np.all(uu[:, 0] >= segs[s]) and np.all(uu[:, 0] + uu[:, 1] <= segs[s + 1])
+            if si[s + 1] > si[s]:
+                uu = u1[it1[si[s], 0]:it1[si[s + 1] - 1, 1]]
+                assert np.all(uu[:, 0] >= segs[s]) and np.all(uu[:, 0] + uu[:, 1] <= segs[s + 1])
     y_plan, written = O.walk_plan(plan, x_ext.numpy())
     assert written[:L.n_loc].min() == 1 and written.sum() == L.n_loc
     y = L.y_from_plan(y_plan[:L.n_loc])

@@ -75,7 +75,7 @@ def test_plan_cache_round_trip_with_panel_form(E, O, tmp_path):
     plan.save(path, c.perm, key=7)
     loaded, perm = E.Plan.load(path, key=7, upload=False)
     assert loaded.stats == plan.stats and np.array_equal(perm, c.perm)
-    for name in ("pb_val", "pb_col", "pb_dst", "pb_units1", "pb_row", "pb_units2"):
+    for name in ("pb_val", "pb_col", "pb_dst", "pb_units1", "pb_items1", "pb_row", "pb_units2"):
         assert np.array_equal(loaded.array(name), plan.array(name)), name
     y, _ = O.walk_plan(loaded, c.xp)
     assert c.check(y)[0] == 0

@@ -68,7 +68,7 @@ def main():
                     ms = r["ms_total"] / args.iters
                     out = {"workload": wl, "order": part, "panel_cols": pc, "block_rows": br, "units1_aim": u1, "er_sums": sums, "xcd_map": xcd,
                            "nnz": nnz, "nnz_ell": st["nnz_ell"], "partials": st["er_partials"],
-                           "units1": len(plan.array("pb_units1")) // 4 if first else None, "units2": len(plan.array("pb_units2")) // 4 if first else None,
+                           "items1": len(plan.array("pb_items1")) // 2 if first else None, "units1": len(plan.array("pb_units1")) // 4 if first else None, "units2": len(plan.array("pb_units2")) // 4 if first else None,
                            "us_spmv": round(ms * 1e3, 1), "GFLOPs": round(2.0 * nnz / ms / 1e6, 1), "us_ell": round(r["ms_ell_avg"] * 1e3, 1),
                            "us_er": round(r["ms_er_avg"] * 1e3, 1), "format_MB": round(st["bytes_format"] / 1e6, 1), "alg_MB": round(st["bytes_alg"] / 1e6, 1),
                            "rows_over_tol": bad, "worst": float(f"{worst:.2e}"), "plan_s": round(t_plan, 1), "reorder_s": round(t_re, 1)}

@@ -56,7 +56,7 @@ def main():
             r = plan.bench(xd.ptr, yd.ptr, warmup=5, iters=args.iters)
             bad, worst = O.check_tolerance(E.vector_recover(yd.download(), perm), y_ref, scale)
             out = {"workload": args.workload, "panel_cols": pc, "block_rows": br, "units2_aim": u2, "prune_pct": pct, "nnz_ell": st["nnz_ell"], "nnz_er": st["nnz_er"], "partials": st["er_partials"],
-                   "units1": len(plan.array("pb_units1")) // 4, "units2": len(plan.array("pb_units2")) // 4,
+                   "items1": len(plan.array("pb_items1")) // 2, "units1": len(plan.array("pb_units1")) // 4, "units2": len(plan.array("pb_units2")) // 4,
                    "us_spmv": round(r["ms_total"] / args.iters * 1e3, 1), "us_ell": round(r["ms_ell_avg"] * 1e3, 1), "us_er": round(r["ms_er_avg"] * 1e3, 1),
                    "er_format_MB": round((st["bytes_format"] - st["bytes_format_ell"]) / 1e6, 1), "rows_over_tol": bad, "plan_s": round(t_plan, 1)}
             for probe in [int(v) for v in args.probes.split(",")]:
