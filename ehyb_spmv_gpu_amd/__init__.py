@@ -9,6 +9,7 @@ from .host import (  # noqa: F401
     ARRAYS,
     EHYB_PART_AUTO,
     EHYB_PART_CONTIGUOUS,
+    EHYB_PART_DEGREE,
     EHYB_PART_MTMETIS,
     EHYB_PART_MULTILEVEL,
     EHYB_WINDOW_HALO,

@@ -72,7 +72,8 @@ class Config(C.Structure):
         ("xcd_map", C.c_int32),
         ("graphs", C.c_int32),
         ("er_sums", C.c_int32),
-        ("reserved", C.c_int32 * 30),
+        ("er_panel_threads", C.c_int32),
+        ("reserved", C.c_int32 * 29),
     ]
 
 

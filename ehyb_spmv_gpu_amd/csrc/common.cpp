@@ -126,15 +126,16 @@ Config resolve_config(const ehyb_config* in)
     c.ell_prune = z.ell_prune == 2 ? 2 : 1;
     c.value_map = z.value_map == 1 ? 1 : 0;
     c.prune_pct = z.prune_pct > 0 ? z.prune_pct : 110;
-    c.er_units1 = z.er_units1 > 0 ? z.er_units1 : 1024;
+    c.er_units1 = z.er_units1 > 0 ? z.er_units1 : 2048;
     c.er_units2 = z.er_units2 > 0 ? z.er_units2 : 2048;
-    c.graph_compress = z.graph_compress == 2 ? 2 : 1;
+    c.graph_compress = (z.graph_compress == 1 || z.graph_compress == 2) ? z.graph_compress : 0;
     c.balance = (z.balance == 1 || z.balance == 2) ? z.balance : 0;
     c.req_margin = z.req_margin;
     c.sym_slack_permille = z.sym_slack_permille > 0 ? z.sym_slack_permille : 30;
     c.xcd_map = z.xcd_map == 2 ? 2 : 1;
     c.graphs = z.graphs == 2 ? 2 : 1;
     c.er_sums = z.er_sums == 2 ? 2 : 1;
+    c.er_panel_threads = (z.er_panel_threads == 512 || z.er_panel_threads == 1024) ? z.er_panel_threads : 0;
     // the automatic choice of the direct shape is for callers that left the window sizing alone: a caller
     // that names a window (lds_doubles / part_rows other than the defaults) gets that window
     if (c.direct == 0 && (c.lds_doubles != EHYB_LDS_MAX_DOUBLES || c.part_rows != round_down(EHYB_LDS_MAX_DOUBLES * 11 / 20, kSlabRows) ||
@@ -202,6 +203,7 @@ void ehyb_config_resolve(const ehyb_config* in, ehyb_config* out)
     r.xcd_map = c.xcd_map;
     r.graphs = c.graphs;
     r.er_sums = c.er_sums;
+    r.er_panel_threads = c.er_panel_threads;
     *out = r;
 }
 

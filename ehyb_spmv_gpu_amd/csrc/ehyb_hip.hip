@@ -722,7 +722,7 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
     if ((which & 1) && u1 > 0) {
         // panels of up to 9,728 columns: two 512-thread workgroups per CU (one stages while the other streams); wider
         // panels leave room for one workgroup only, which then gets the CU's 16 waves
-        const bool wide = H.pb_panel_cols > 9728;
+        const bool wide = P->cfg.er_panel_threads ? P->cfg.er_panel_threads == 1024 : H.pb_panel_cols > 9728;
         const bool dpp = P->cfg.er_sums != 2;
         const int xcd = P->cfg.xcd_map != 2 ? 1 : 0;
 #define PB_SCALE(T, D)                                                                                                          \

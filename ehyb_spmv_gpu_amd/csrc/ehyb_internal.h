@@ -53,13 +53,14 @@ struct Config {
     int prune_pct;          // ell_prune threshold in per cent of the panel form's cost (110)
     int er_units1;          // panel form: work units aimed at, pass 1 / pass 2 (2048)
     int er_units2;
-    int graph_compress;     // 1 on, 2 off
+    int graph_compress;     // 0 automatic (on with symmetric pair storage), 1 on, 2 off
     int balance;            // 0 automatic, 1 entries, 2 rows
     int req_margin;         // 0 default, -1 none, > 0 as given
     int sym_slack_permille; // 30
     int xcd_map;            // 1 on, 2 off
     int graphs;             // 1 on, 2 off
     int er_sums;            // 1 DPP scan, 2 LDS words
+    int er_panel_threads;   // 0 automatic, 512, 1024
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -161,7 +162,7 @@ struct HostLayout {
 };
 
 int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* out,
-                 const std::vector<uint8_t>* part_to_er = nullptr);
+                 const std::vector<uint8_t>* part_to_er = nullptr, int local_lo = -1, int local_hi = -1);
 int build_panel_residual(const Config& cfg, HostLayout* L);  // er_panel.cpp; reads the CSR residual of *L
 void encode_panel_slots(HostLayout* L);                      // er_panel.cpp; pb_col + pb_dst -> pb_colf, pb_chunk, pb_jump
 bool sym_storage_suits(const matrixCOO* m);  // spmvGPuEHYB's own choice of the storage (plan.cpp)

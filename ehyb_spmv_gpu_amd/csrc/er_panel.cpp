@@ -30,6 +30,8 @@
 
 #include <omp.h>
 
+#include <parallel/algorithm>
+
 #include <algorithm>
 #include <numeric>
 
@@ -108,26 +110,35 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     const int rows_max = cfg.er_block_rows;
     L->er_panel = false;
     if (nnz_er == 0) return EHYB_OK;
+    double t_lap = wall_seconds();
+    auto lap = [&](const char* what) {
+        const double now = wall_seconds();
+        if (cfg.verbose > 1) printf("  panel form: %-32s %7.1f ms\n", what, (now - t_lap) * 1e3);
+        t_lap = now;
+    };
     if (nnz_er + 64 * ((int64_t)n_cols / W + 2 + (int64_t)L->col_seg_first.size()) >= 0x7FFFFF00ll)
         EHYB_FAIL(EHYB_ERR_ARG, "build_panel_residual: residual of %lld entries too large for 32-bit offsets", (long long)nnz_er);
 
-    // ---- (row, column, value) of every residual entry, from the CSR segments
-    std::vector<int32_t> erow((size_t)nnz_er);
-#pragma omp parallel for schedule(static, 1024)
-    for (int64_t s = 0; s < nseg; ++s) {
-        const int32_t r = L->er_seg_row[s] & 0x7FFFFFFF;
-        for (int64_t k = L->er_seg_ptr[s]; k < L->er_seg_ptr[s + 1]; ++k) erow[(size_t)k] = r;
-    }
     const int32_t* ecol = L->er_col.data();
     const double* evalv = L->er_val.data();
 
     // ---- row blocks: consecutive rows with about `target` entries each, at most rows_max rows
     const int row_begin = L->row_begin, nrows = L->row_end - L->row_begin;
     std::vector<int32_t> cnt_row((size_t)nrows, 0);
-    for (int64_t k = 0; k < nnz_er; ++k) {
-        const int r = erow[(size_t)k] - row_begin;
-        if ((unsigned)r >= (unsigned)nrows) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_panel_residual: residual row outside the plan's rows");
-        ++cnt_row[r];
+    {
+        bool bad_row = false;
+#pragma omp parallel for schedule(static, 4096) reduction(|| : bad_row)
+        for (int64_t s = 0; s < nseg; ++s) {
+            const int r = (L->er_seg_row[s] & 0x7FFFFFFF) - row_begin;
+            if ((unsigned)r >= (unsigned)nrows) {
+                bad_row = true;
+                continue;
+            }
+            const int32_t len = (int32_t)(L->er_seg_ptr[s + 1] - L->er_seg_ptr[s]);
+#pragma omp atomic
+            cnt_row[r] += len;  // (a long row comes in several segments)
+        }
+        if (bad_row) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_panel_residual: residual row outside the plan's rows");
     }
     // (cfg.er_units1 / er_units2 = work units aimed at per pass: tools/panel_sweep.py)
     const int64_t target = std::min<int64_t>(std::max<int64_t>(nnz_er / cfg.er_units2, 4096), 1 << 20);
@@ -158,6 +169,7 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     }
     const int n_rb = (int)rb_first.size() - 1;
 
+    lap("row blocks");
     // ---- panels: W columns each, starting afresh at every column segment (one segment = the whole matrix unless the
     // caller named more: multi-GPU, the x entries of a segment arrive together)
     std::vector<int32_t> seg_first = L->col_seg_first;
@@ -178,34 +190,57 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
         while (c >= seg_first[s + 1]) ++s;  // a handful of segments
         return seg_panel0[s] + (c - seg_first[s]) / W;
     };
-    // ---- pass-1 order: by panel (counting sort), inside a panel by (row, column)
+    // ---- pass-1 order: by panel, inside a panel by (row, column).  No comparison sort of the entries (round 2 sorted
+    // every panel by itself: the hub panel of a degree-ordered R-MAT holds a third of all entries, one thread sorted it
+    // for seconds): the segments are taken in ROW order -- a sort of the segments, not of the entries -- cut into one
+    // run per thread, and every run deals its entries out to the panels, behind what the runs before it put there (a
+    // parallel counting sort by panel that keeps the row order).  A row's entries stay in column order because the
+    // rows are stored that way; a segment that is not is dealt through a sorted index list.
+    std::vector<uint64_t> seg_key((size_t)nseg);
+#pragma omp parallel for schedule(static, 4096)
+    for (int64_t s = 0; s < nseg; ++s) seg_key[(size_t)s] = (uint64_t)(uint32_t)(L->er_seg_row[s] & 0x7FFFFFFF) << 32 | (uint64_t)s;
+    __gnu_parallel::sort(seg_key.begin(), seg_key.end());  // (segments of one row ascend with their position: the row's own order)
+    lap("segments in row order");
+    const int T = std::max(1, omp_get_max_threads());
+    std::vector<int64_t> run_first((size_t)T + 1, nseg);  // first segment (in key order) of every run: about equal entries each
+    {
+        std::vector<int64_t> ent_before((size_t)nseg + 1, 0);
+        for (int64_t i = 0; i < nseg; ++i) {
+            const int64_t s = (int64_t)(seg_key[(size_t)i] & 0xFFFFFFFFull);
+            ent_before[(size_t)i + 1] = ent_before[(size_t)i] + (L->er_seg_ptr[s + 1] - L->er_seg_ptr[s]);
+        }
+        for (int t = 0; t <= T; ++t)
+            run_first[(size_t)t] = std::lower_bound(ent_before.begin(), ent_before.end(), nnz_er * t / T) - ent_before.begin();
+        run_first[0] = 0;
+        run_first[(size_t)T] = nseg;
+    }
     std::vector<int64_t> pcount((size_t)n_panels + 1, 0);
-    std::vector<int32_t> epanel((size_t)nnz_er);
+    std::vector<int64_t> run_cnt((size_t)T * (size_t)n_panels, 0);  // [run][panel]
     bool bad_col = false;
-#pragma omp parallel for schedule(static, 65536) reduction(|| : bad_col)
-    for (int64_t k = 0; k < nnz_er; ++k) {
-        if ((unsigned)ecol[k] >= (unsigned)n_cols) {
-            bad_col = true;
-            epanel[(size_t)k] = 0;
-        } else {
-            epanel[(size_t)k] = panel_of(ecol[k]);
+#pragma omp parallel for schedule(static, 1) reduction(|| : bad_col)
+    for (int t = 0; t < T; ++t) {
+        int64_t* c = &run_cnt[(size_t)t * (size_t)n_panels];
+        for (int64_t i = run_first[(size_t)t]; i < run_first[(size_t)t + 1]; ++i) {
+            const int64_t s = (int64_t)(seg_key[(size_t)i] & 0xFFFFFFFFull);
+            for (int64_t k = L->er_seg_ptr[s]; k < L->er_seg_ptr[s + 1]; ++k) {
+                if ((unsigned)ecol[k] >= (unsigned)n_cols)
+                    bad_col = true;
+                else
+                    ++c[panel_of(ecol[k])];
+            }
         }
     }
     if (bad_col) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_panel_residual: column outside the matrix");
-    for (int64_t k = 0; k < nnz_er; ++k) ++pcount[(size_t)epanel[(size_t)k] + 1];
-    for (int p = 0; p < n_panels; ++p) pcount[p + 1] += pcount[p];
-    std::vector<uint32_t> order((size_t)nnz_er);
-    {
-        std::vector<int64_t> fill(pcount.begin(), pcount.end() - 1);
-        for (int64_t k = 0; k < nnz_er; ++k) order[(size_t)fill[epanel[(size_t)k]]++] = (uint32_t)k;
+    for (int p = 0; p < n_panels; ++p) {
+        int64_t at = pcount[p];
+        for (int t = 0; t < T; ++t) {
+            const int64_t c = run_cnt[(size_t)t * (size_t)n_panels + (size_t)p];
+            run_cnt[(size_t)t * (size_t)n_panels + (size_t)p] = at;  // from here on: where run t puts its next entry of panel p
+            at += c;
+        }
+        pcount[p + 1] = at;
     }
-    std::vector<int32_t>().swap(epanel);
-#pragma omp parallel for schedule(dynamic, 1)
-    for (int p = 0; p < n_panels; ++p)
-        std::sort(order.begin() + pcount[p], order.begin() + pcount[p + 1], [&](uint32_t a, uint32_t b) {
-            return erow[a] != erow[b] ? erow[a] < erow[b] : (ecol[a] != ecol[b] ? ecol[a] < ecol[b] : a < b);
-        });
-
+    lap("entries counted per run and panel");
     // ---- padded positions: every panel starts on a multiple of 64 entries
     std::vector<int64_t> pstart((size_t)n_panels + 1, 0);
     for (int p = 0; p < n_panels; ++p) pstart[p + 1] = pstart[p] + (pcount[p + 1] - pcount[p] + 63) / 64 * 64;
@@ -215,43 +250,82 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     L->pb_dst.assign((size_t)padded, 0xFFFFFFFFu);
     const bool vmap = !L->er_src.empty();
     L->pb_src.assign(vmap ? (size_t)padded : 0, -1);
-
-    // ---- pieces: runs of one row inside a 64-entry chunk of a panel, numbered in pass-1 order
-    // piece_of[pos] (temporarily in pb_dst), and per piece its row
-    std::vector<int32_t> piece_row;
-    std::vector<int64_t> panel_piece0((size_t)n_panels + 1, 0);
-    {
-        // count first (parallel), then fill
-        std::vector<int64_t> pieces_in((size_t)n_panels, 0);
-#pragma omp parallel for schedule(dynamic, 1)
-        for (int p = 0; p < n_panels; ++p) {
-            int64_t c = 0;
-            const int64_t b = pcount[p], e = pcount[p + 1];
-            for (int64_t k = b; k < e; ++k)
-                if (k == b || ((k - b) & 63) == 0 || erow[order[(size_t)k]] != erow[order[(size_t)k - 1]]) ++c;
-            pieces_in[p] = c;
-        }
-        for (int p = 0; p < n_panels; ++p) panel_piece0[p + 1] = panel_piece0[p] + pieces_in[p];
-        const int64_t n_pieces = panel_piece0[n_panels];
-        if (n_pieces >= 0x7FFFFF00ll) EHYB_FAIL(EHYB_ERR_ARG, "build_panel_residual: too many partial sums");
-        piece_row.resize((size_t)n_pieces);
-#pragma omp parallel for schedule(dynamic, 1)
-        for (int p = 0; p < n_panels; ++p) {
-            int64_t piece = panel_piece0[p] - 1;
-            const int64_t b = pcount[p], e = pcount[p + 1];
-            for (int64_t k = b; k < e; ++k) {
-                const uint32_t src = order[(size_t)k];
-                if (k == b || ((k - b) & 63) == 0 || erow[src] != erow[order[(size_t)k - 1]]) piece_row[(size_t)++piece] = erow[src];
-                const int64_t pos = pstart[p] + (k - b);
-                L->pb_val[(size_t)pos] = evalv[src];
-                if (vmap) L->pb_src[(size_t)pos] = L->er_src[src];
-                L->pb_col[(size_t)pos] = (uint16_t)(ecol[src] - panel_first[p]);
-                L->pb_dst[(size_t)pos] = (uint32_t)piece;
+    std::vector<int32_t> prow((size_t)padded, -1);  // row of every stored entry, pass-1 order (scratch)
+    lap("stream arrays allocated");  // (first touch of fresh pages: most of the time on a freshly started VM)
+    // every run deals its entries out: value, local column, row (and the slot-map entry) straight to their final places
+    // -- the reads are sequential, the writes go to one open stream per panel
+#pragma omp parallel for schedule(static, 1)
+    for (int t = 0; t < T; ++t) {
+        int64_t* at = &run_cnt[(size_t)t * (size_t)n_panels];
+        for (int p = 0; p < n_panels; ++p) at[p] += pstart[p] - pcount[p];  // unpadded -> padded position
+        std::vector<uint32_t> idx;
+        for (int64_t i = run_first[(size_t)t]; i < run_first[(size_t)t + 1]; ++i) {
+            const int64_t sg = (int64_t)(seg_key[(size_t)i] & 0xFFFFFFFFull);
+            const int32_t r = L->er_seg_row[sg] & 0x7FFFFFFF;
+            const int64_t b = L->er_seg_ptr[sg], e = L->er_seg_ptr[sg + 1];
+            bool ascending = true;
+            for (int64_t k = b + 1; k < e && ascending; ++k) ascending = ecol[k - 1] <= ecol[k];
+            auto deal = [&](int64_t k) {
+                const int p = panel_of(ecol[k]);
+                const int64_t pos = at[p]++;
+                L->pb_val[(size_t)pos] = evalv[k];
+                L->pb_col[(size_t)pos] = (uint16_t)(ecol[k] - panel_first[p]);
+                prow[(size_t)pos] = r;
+                if (vmap) L->pb_src[(size_t)pos] = L->er_src[(size_t)k];
+            };
+            if (ascending) {
+                for (int64_t k = b; k < e; ++k) deal(k);
+            } else {
+                idx.resize((size_t)(e - b));
+                std::iota(idx.begin(), idx.end(), (uint32_t)b);
+                std::sort(idx.begin(), idx.end(), [&](uint32_t x, uint32_t y) { return ecol[x] != ecol[y] ? ecol[x] < ecol[y] : x < y; });
+                for (uint32_t k : idx) deal((int64_t)k);
             }
         }
     }
+    std::vector<uint64_t>().swap(seg_key);
+
+    lap("entries dealt to the panels");
+    // ---- pieces: runs of one row inside a 64-entry chunk of a panel, numbered in pass-1 order
+    // piece_of[pos] (temporarily in pb_dst), and per piece its row
+    std::vector<int32_t> piece_row;
+    {
+        // tasks: stretches of one panel's entries, whole 64-entry chunks each (a chunk starts a piece whatever the rows
+        // do), so the hub panel of a degree-ordered matrix is shared out like the rest; count first, then fill
+        struct Task {
+            int64_t b, e;  // padded positions of stored entries
+        };
+        std::vector<Task> tasks;
+        for (int p = 0; p < n_panels; ++p) {
+            const int64_t end = pstart[p] + (pcount[p + 1] - pcount[p]);
+            for (int64_t b = pstart[p]; b < end; b += 1 << 16) tasks.push_back({b, std::min<int64_t>(b + (1 << 16), end)});
+        }
+        const int64_t nt = (int64_t)tasks.size();
+        std::vector<int64_t> piece0((size_t)nt + 1, 0);
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int64_t t = 0; t < nt; ++t) {
+            int64_t c = 0;
+            for (int64_t k = tasks[(size_t)t].b; k < tasks[(size_t)t].e; ++k)
+                if ((k & 63) == 0 || prow[(size_t)k] != prow[(size_t)k - 1]) ++c;
+            piece0[(size_t)t + 1] = c;
+        }
+        for (int64_t t = 0; t < nt; ++t) piece0[(size_t)t + 1] += piece0[(size_t)t];
+        const int64_t n_pieces = piece0[(size_t)nt];
+        if (n_pieces >= 0x7FFFFF00ll) EHYB_FAIL(EHYB_ERR_ARG, "build_panel_residual: too many partial sums");
+        piece_row.resize((size_t)n_pieces);
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int64_t t = 0; t < nt; ++t) {
+            int64_t piece = piece0[(size_t)t] - 1;
+            for (int64_t k = tasks[(size_t)t].b; k < tasks[(size_t)t].e; ++k) {
+                if ((k & 63) == 0 || prow[(size_t)k] != prow[(size_t)k - 1]) piece_row[(size_t)++piece] = prow[(size_t)k];
+                L->pb_dst[(size_t)k] = (uint32_t)piece;
+            }
+        }
+    }
+    std::vector<int32_t>().swap(prow);
     const int64_t n_pieces = (int64_t)piece_row.size();
 
+    lap("pieces and values");
     // ---- slots: pieces in (row block, panel, pass-1 order) = stable counting sort by row block
     std::vector<int64_t> rb_count((size_t)n_rb + 1, 0);
     for (int64_t j = 0; j < n_pieces; ++j) ++rb_count[(size_t)rb_of_row[piece_row[(size_t)j] - row_begin] + 1];
@@ -272,6 +346,7 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     for (int64_t pos = 0; pos < padded; ++pos)
         if (L->pb_dst[(size_t)pos] != 0xFFFFFFFFu) L->pb_dst[(size_t)pos] = slot_of_piece[L->pb_dst[(size_t)pos]];
 
+    lap("slots");
     // ---- work of pass 1: ITEMS of equal cost, one workgroup each; an item is a run of UNITS {first column, columns,
     // first entry, end entry} -- a stretch of one panel's entries, multiples of 64 -- and stages a panel once per unit.
     // (Round 2: one workgroup per unit of padded/2048 entries, handed out by the hardware.  A heavy panel -- the hub
@@ -349,6 +424,7 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
         rows_touched += rows;
         rows_assigned += assign ? rows : 0;
     }
+    lap("work items");
     L->pb_panel_cols = W;
     L->pb_rows_max = max_rows;
     L->pb_partials = n_pieces;
@@ -359,6 +435,7 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
     // (value, column+flags) + chunk records + jump list instead of a 4-byte slot per entry
     L->pb_bytes = 10 * padded + 4 * (padded / 64 + 1) + 4 * (int64_t)L->pb_jump.size() + 8 * staged + 8 * n_pieces + 10 * n_pieces + (L->pb_assign ? 8 * rows_assigned + 16 * std::max<int64_t>(0, L->stats.rows_er - rows_assigned) : 16 * L->stats.rows_er) +
                   16 * (int64_t)(L->pb_units1.size() / 4 + L->pb_units2.size() / 4) + 8 * (int64_t)(L->pb_items1.size() / 2);
+    lap("compressed slots");
     if (cfg.verbose)
         printf("panel residual: %lld entries (%lld with padding) in %d panels of %d columns -> %lld partials, %zu + %zu work units, "
                "row blocks <= %d rows\n",

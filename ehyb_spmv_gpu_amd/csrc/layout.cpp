@@ -157,8 +157,11 @@ void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64
 // part_to_er (may be null): partitions (by their index in the layout's own partition list) whose rows go
 // to the residual whole -- no window, no halo, zero-width slabs (plan.cpp decides, see ell_pays()).
 int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* L,
-                 const std::vector<uint8_t>* part_to_er)
+                 const std::vector<uint8_t>* part_to_er, int local_lo, int local_hi)
 {
+    // multi-GPU (cfg.n_top > 1): the columns a window may hold are the rank's own, [local_lo, local_hi) -- the plan's
+    // rows unless the caller lays out a SAMPLE of a rank's partitions (plan.cpp) and names the rank's range
+    if (local_lo < 0) local_lo = row_begin, local_hi = row_end;
     if (!m || !L) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: null argument");
     const int n = m->dimension;
     if (n <= 0 || !m->rowIdx || (m->totalNum > 0 && (!m->J || !m->V)))
@@ -301,7 +304,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             if (whole_to_er) {
                 wlen = 0;  // nothing of this partition is multiplied from a window: nothing is staged
             } else if (!halo_mode) {
-                wlen = std::min(lds - (s & 1), std::min(n, cfg.n_top > 1 ? row_end : n) - s);
+                wlen = std::min(lds - (s & 1), std::min(n, cfg.n_top > 1 ? local_hi : n) - s);
             } else {
                 wlen = own;
                 // the LDS image starts at the even row below s; with symmetric pairs it is followed
@@ -316,7 +319,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                             continue;
                         }
                         if (j >= s && j < e) continue;
-                        if (cfg.n_top > 1 && (j < row_begin || j >= row_end)) continue;  // remote column
+                        if (cfg.n_top > 1 && (j < local_lo || j >= local_hi)) continue;  // remote column
                         cand.push_back(j);
                     }
                 if (hcap > 0 && !cand.empty()) {

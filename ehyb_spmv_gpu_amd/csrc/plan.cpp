@@ -49,6 +49,67 @@ int windows_that_do_not_pay(const HostLayout& H, int pct, std::vector<uint8_t>* 
     return count;
 }
 
+// Will every window of this matrix be given up anyway?  The two-build route above costs a power-law matrix its whole
+// layout twice (R-MAT 2^24: 7.6 s of 13.7 s).  Decided from a SAMPLE instead: 24 partitions, evenly spread, the first
+// one among them (the hubs of a degree-ordered matrix), are laid out on their own -- a partition's window is a function of
+// its rows alone -- and judged by the same rule; if the windows that pay would hold less than 20 % of the entries (the
+// all-or-nothing line of the full rule is 25 %), the one and only build starts with every partition in the residual.
+// Only tried where the entries show no locality (more than one distinct 128-byte line of x per two consecutive
+// entries, as the residual's own test in layout.cpp): a mesh never comes here.  A wrong guess costs speed, never
+// correctness: any assignment of partitions to the residual multiplies right.
+static bool windows_will_not_pay(const matrixCOO* m, int row_begin, int row_end, const Config& cfg)
+{
+    const int* rp = m->rowIdx;
+    const int64_t k0 = rp[row_begin], k1 = rp[row_end], nnz = k1 - k0;
+    if (nnz < (1 << 21) || cfg.sym_pairs == 1 || cfg.er_mode == 1 || cfg.ell_prune == 2 || cfg.window_mode != EHYB_WINDOW_HALO) return false;
+    if (!m->partBoundary || m->nParts < 8) return false;
+    // locality of the entries as stored
+    {
+        const int64_t win = 1024, nwin = 64;
+        int64_t lines = 0;
+        std::vector<int32_t> tmp((size_t)win);
+        for (int64_t w = 0; w < nwin; ++w) {
+            const int64_t at = k0 + (nnz - win) * w / (nwin - 1);
+            for (int64_t k = 0; k < win; ++k) tmp[(size_t)k] = m->J[at + k] >> 4;
+            std::sort(tmp.begin(), tmp.end());
+            lines += std::unique(tmp.begin(), tmp.end()) - tmp.begin();
+        }
+        if (lines * 2 <= nwin * win) return false;
+    }
+    std::vector<int> parts;  // partitions inside the plan's rows
+    for (int p = 0; p < m->nParts; ++p)
+        if (m->partBoundary[p] >= row_begin && m->partBoundary[p + 1] <= row_end && m->partBoundary[p + 1] > m->partBoundary[p]) parts.push_back(p);
+    if (parts.size() < 8) return false;
+    // the first partition (the hubs of a degree-ordered matrix: it can hold a tenth of all entries) and 23 more, evenly spread
+    std::vector<int> pick;
+    for (int i = 0; i < 24; ++i) pick.push_back(parts[(parts.size() - 1) * (size_t)i / 23]);
+    pick.erase(std::unique(pick.begin(), pick.end()), pick.end());
+    Config quiet = cfg;
+    quiet.verbose = 0;
+    quiet.er_mode = 1;     // no panel form for the samples
+    quiet.value_map = 0;
+    quiet.direct = 2;
+    int64_t seen = 0, kept_first = 0, kept_rest = 0;
+    for (int p : pick) {
+        HostLayout S;
+        if (build_layout(m, m->partBoundary[p], m->partBoundary[p + 1], quiet, &S, nullptr, row_begin, row_end) != EHYB_OK) {
+            clear_error();
+            return false;
+        }
+        std::vector<uint8_t> to_er;
+        int64_t moved = 0;
+        windows_that_do_not_pay(S, cfg.prune_pct, &to_er, &moved);
+        seen += S.stats.nnz;
+        (p == pick[0] ? kept_first : kept_rest) += S.stats.nnz_ell - moved;
+    }
+    // the first partition counts for itself, the others for their share of the rest
+    const double kept_est = (double)kept_first + (double)kept_rest * (double)(parts.size() - 1) / (double)std::max<size_t>(1, pick.size() - 1);
+    if (cfg.verbose)
+        printf("window sample: %zu partitions laid out (%lld entries): about %.1f %% of the %lld entries would sit in windows that pay\n", pick.size(),
+               (long long)seen, 100.0 * kept_est / (double)nnz, (long long)nnz);
+    return kept_est < 0.20 * (double)nnz;  // the full rule gives every window up below 25 %
+}
+
 bool sym_storage_suits(const matrixCOO* m)
 {
     const int n = m->dimension;
@@ -114,10 +175,27 @@ int ehyb_plan_create_host_segs(const matrixCOO* m, int row_begin, int row_end, c
     if (n_col_segs > 0) P->host.col_seg_first.assign(col_seg_first, col_seg_first + n_col_segs + 1);
     int rc;
     try {
-        rc = build_layout(m, row_begin, row_end, P->cfg, &P->host);
+        bool decided = false;
+        if (windows_will_not_pay(m, row_begin, row_end, P->cfg)) {
+            // straight to the layout the two-build route would end with: every partition in the (panel-form) residual
+            std::vector<uint8_t> all(m->nParts > 0 ? (size_t)m->nParts + 64 : 64, 1);
+            HostLayout direct_to;
+            direct_to.col_seg_first = P->host.col_seg_first;
+            // (the layout's own partition list may be longer than the caller's -- partitions cut down to the window --
+            // so the flags cover any index: every partition goes)
+            all.assign((size_t)(row_end - row_begin) / kSlabRows + (size_t)m->nParts + 64, 1);
+            const int rc0 = build_layout(m, row_begin, row_end, P->cfg, &direct_to, &all);
+            if (rc0 == EHYB_OK && direct_to.er_panel) {
+                P->host = std::move(direct_to);
+                decided = true;
+            } else {
+                clear_error();
+            }
+        }
+        rc = decided ? EHYB_OK : build_layout(m, row_begin, row_end, P->cfg, &P->host);
         // Where the residual runs in panel form (a large residual without locality: R-MAT), a partition
         // whose window does not pay is better off in the residual whole: built a second time with those.
-        if (rc == EHYB_OK && P->host.er_panel && !P->host.sym && P->cfg.er_mode != 1 && P->cfg.ell_prune != 2) {
+        if (!decided && rc == EHYB_OK && P->host.er_panel && !P->host.sym && P->cfg.er_mode != 1 && P->cfg.ell_prune != 2) {
             std::vector<uint8_t> to_er;
             int64_t moved = 0;
             if (windows_that_do_not_pay(P->host, P->cfg.prune_pct, &to_er, &moved) > 0) {

@@ -328,7 +328,10 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
             std::vector<int> twin_group;  // compressed graph used: the group (node) of every row
             bool weighted = false, by_degree = false;
             // the multilevel scheme on the compressed graph where the rows come in groups with one column list
-            const bool compress = c.graph_compress != 2 && symmetric_pattern != 0 && (c.partitioner == EHYB_PART_AUTO || c.partitioner == EHYB_PART_MULTILEVEL) && n >= 4096;
+            // Automatic = with symmetric pair storage only: the partitions of the compressed graph cost the bench matrix with
+            // EVERY entry stored 4 % (same-box A/B at equal format bytes, round 2: 1098-1101 against 1123-1166 GFLOP/s;
+            // bench.py's plain_storage arm fell from 1094 to 1049) while symmetric pairs gain from them (fewer halo columns).
+            const bool compress = (c.graph_compress == 1 || (c.graph_compress == 0 && c.sym_pairs == 1)) && symmetric_pattern != 0 && (c.partitioner == EHYB_PART_AUTO || c.partitioner == EHYB_PART_MULTILEVEL) && n >= 4096;
             if (c.sym_pairs == 1 && n >= 4 * nparts) {
                 rowlen.resize(n);
                 double sum = 0, sq = 0;

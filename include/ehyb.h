@@ -157,11 +157,11 @@ typedef struct ehyb_config {
        EHYB_MTMETIS_LIB, names a shared object to load the optional mt-metis backend from). */
     int32_t prune_pct;     /* ell_prune: a window is given up when it costs more than this share (per cent) of what
                               the panel form would cost for its entries; 0 = 110                                */
-    int32_t er_units1;     /* panel form: work items (workgroups) pass 1 aims at (0 = 1024)                     */
+    int32_t er_units1;     /* panel form: work items (workgroups) pass 1 aims at (0 = 2048)                     */
     int32_t er_units2;     /* panel form: row blocks pass 2 aims at (0 = 2048)                                 */
-    int32_t graph_compress;/* 0/1 = the k-way partitioner works on the compressed graph where rows come in groups with one
-                              column list (the unknowns of a node), 2 = never.  Plain storage (sym_pairs off) ignores it
-                              by default: see reorder.cpp                                                        */
+    int32_t graph_compress;/* the k-way partitioner works on the compressed graph where rows come in groups with one column
+                              list (the unknowns of a node): 0 = with symmetric pair storage only (plain storage runs 4 %
+                              slower on such partitions, reorder.cpp), 1 = always, 2 = never                      */
     int32_t balance;       /* symmetric pair storage, what the partitions are balanced on: 0 = rows unless the row lengths
                               vary by more than 30 % (sigma/mean), 1 = entries, 2 = rows                         */
     int32_t req_margin;    /* entry-balanced partitions of a graded mesh: partitions asked for = nParts - margin; 0 =
@@ -175,7 +175,8 @@ typedef struct ehyb_config {
                               from hipGraphs, 2 = plain launches (A/B, debugging)                                */
     int32_t er_sums;       /* panel form, pass 1: how the products of one row inside a 64-entry chunk are added up: 0/1 =
                               segmented DPP scan in registers, 2 = ds_add_f64 into per-wave LDS words (round 2's way) */
-    int32_t reserved[30];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
+    int32_t er_panel_threads; /* panel form, pass 1: workgroup size, 512 or 1024 (0 = automatic)                 */
+    int32_t reserved[29];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);

@@ -23,6 +23,14 @@ def test_pmc_traffic_is_keyed_by_workload_storage_and_kernel(tmp_path, monkeypat
     assert B.pmc_traffic("small", True, "ehyb_ell_kernel") is None                   # other workload
     assert B.pmc_traffic("rmat-22", False, "ehyb_er_kernel") is None                 # other kernel
     assert B.pmc_traffic("rmat-22", False, "ehyb_pb_scale_kernel+ehyb_pb_reduce_kernel") == 814.7e6
+    # with a plan's statistics: only an entry taken on exactly that layout is quoted
+    st = {"nnz": 77728167, "size_block_ell": 47600000, "nnz_er": 4711, "er_partials": 0, "n_items": 256, "bytes_format": 440000000, "sym_pairs": 1}
+    assert B.pmc_traffic("audikw_1-like", True, "ehyb_ell_kernel", st) is None       # entry without a fingerprint: stale by definition
+    table["entries"]["audikw_1-like|sym|ehyb_ell_kernel"]["layout"] = B.layout_fingerprint(st)
+    f.write_text(json.dumps(table))
+    assert B.pmc_traffic("audikw_1-like", True, "ehyb_ell_kernel", st) == 454.8e6
+    assert B.pmc_traffic("audikw_1-like", True, "ehyb_ell_kernel", dict(st, n_items=254)) is None      # other partitions / work items
+    assert B.pmc_traffic("audikw_1-like", True, "ehyb_ell_kernel", dict(st, bytes_format=441000000)) is None
     monkeypatch.setattr(B, "PMC_FILE", str(tmp_path / "missing.json"))
     assert B.pmc_traffic("audikw_1-like", True, "ehyb_ell_kernel") is None
 
@@ -43,7 +51,7 @@ def test_workload_table(E):
     assert B.symmetric_storage_pays(*B.WORKLOADS["audikw_1-like"][:2])
     assert not B.symmetric_storage_pays(*B.WORKLOADS["bcsstk17-like"][:2])            # below EHYB_SYM_MIN_ROWS
     assert not B.symmetric_storage_pays(*B.WORKLOADS["rmat-24"][:2])
-    assert B.partitioner_for(E, "rmat") == E.EHYB_PART_CONTIGUOUS and B.partitioner_for(E, "fem3d") == E.EHYB_PART_AUTO
+    assert B.partitioner_for(E, "rmat") == E.EHYB_PART_DEGREE and B.partitioner_for(E, "fem3d") == E.EHYB_PART_AUTO
     assert B.SYM_MIN_ROWS == 45056
     # the generators behind the two audikw_1 stand-ins hit audikw_1's size (943,695 rows, 77,651,847 entries)
     for wl in ("audikw_1-like", "audikw_1-graded"):

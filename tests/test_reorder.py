@@ -172,7 +172,7 @@ def test_unknowns_of_a_node_stay_together(E):
     """The k-way partition runs on the compressed graph where rows share their column lists (reorder.cpp,
     partition_compressed): the three unknowns of a finite-element node -- rows with one column list -- are one
     vertex there, so no partition separates them; sizes stay under the cap; deterministic."""
-    cfg = E.make_config(lds_doubles=4096, partitioner=E.EHYB_PART_MULTILEVEL)
+    cfg = E.make_config(lds_doubles=4096, partitioner=E.EHYB_PART_MULTILEVEL, graph_compress=1)  # (automatic: with symmetric pairs only)
     m = E.Matrix.generate("fem3d", 30000, 3, 22, 22, 13500, 1, 1, cfg=cfg)
     rp, J = m.row_idx.astype(np.int64).copy(), m.J.copy()
     n = m.n

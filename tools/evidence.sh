@@ -22,7 +22,7 @@ print("sym" if d["config"]["sym_pairs"] else "plain")
 PY
 )
 PLAIN=(); [ "$STORAGE" = plain ] && PLAIN=(--plain)
-rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_fetch -- python3 tools/pmc_run.py --workload "$WL" "${PLAIN[@]}" > $O/${TAG}_pmc_fetch.log 2>&1
+rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_fetch -- python3 tools/pmc_run.py --workload "$WL" "${PLAIN[@]}" --layout-out $O/${TAG}_layout.json > $O/${TAG}_pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_pmc_write -- python3 tools/pmc_run.py --workload "$WL" "${PLAIN[@]}" > $O/${TAG}_pmc_write.log 2>&1
-python tools/pmc_parse.py $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_traffic.json --workload "$WL" --storage "$STORAGE" --round "$TAG" --table $O/pmc_traffic.json > /dev/null
+python tools/pmc_parse.py $O/${TAG}_pmc_fetch $O/${TAG}_pmc_write $O/${TAG}_pmc_traffic.json --workload "$WL" --storage "$STORAGE" --round "$TAG" --table $O/pmc_traffic.json --layout $O/${TAG}_layout.json > /dev/null
 grep -n "hbm_bytes_per_launch\|factor" $O/${TAG}_pmc_traffic.json | head

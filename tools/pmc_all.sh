@@ -18,9 +18,9 @@ gen, gargs, _ = B.WORKLOADS[sys.argv[1]]
 print("sym" if B.symmetric_storage_pays(gen, gargs) else "plain")
 PY
 )
-  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_${W}_pmc_fetch -- python3 tools/pmc_run.py --workload "$W" --iters 5 > $O/${TAG}_${W}_pmc_fetch.log 2>&1
+  rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/${TAG}_${W}_pmc_fetch -- python3 tools/pmc_run.py --workload "$W" --iters 5 --layout-out $O/${TAG}_${W}_layout.json > $O/${TAG}_${W}_pmc_fetch.log 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/${TAG}_${W}_pmc_write -- python3 tools/pmc_run.py --workload "$W" --iters 5 > $O/${TAG}_${W}_pmc_write.log 2>&1
-  python tools/pmc_parse.py $O/${TAG}_${W}_pmc_fetch $O/${TAG}_${W}_pmc_write $O/${TAG}_${W}_pmc_traffic.json --workload "$W" --storage "$STORAGE" --round "$TAG" --table $O/pmc_traffic.json > /dev/null
+  python tools/pmc_parse.py $O/${TAG}_${W}_pmc_fetch $O/${TAG}_${W}_pmc_write $O/${TAG}_${W}_pmc_traffic.json --workload "$W" --storage "$STORAGE" --round "$TAG" --table $O/pmc_traffic.json --layout $O/${TAG}_${W}_layout.json > /dev/null
   rm -rf $O/${TAG}_${W}_pmc_fetch $O/${TAG}_${W}_pmc_write
   echo "$W $STORAGE done"
 done

@@ -4,7 +4,10 @@ and, with --table, merge it into profiles/pmc_traffic.json -- the table bench.py
 `roofline.traffic` from, keyed by workload | storage | kernel so that a measurement is only ever
 quoted for the case it was taken on.
 
-usage: python tools/pmc_parse.py <fetch_dir> <write_dir> <out.json> [--workload W --storage sym|plain --round rNN_x --table profiles/pmc_traffic.json]
+usage: python tools/pmc_parse.py <fetch_dir> <write_dir> <out.json> [--workload W --storage sym|plain --round rNN_x --table profiles/pmc_traffic.json
+                                  --layout layout.json]
+  --layout: the fingerprint tools/pmc_run.py --layout-out wrote (stored values, residual size and form, work items, format
+  bytes of the plan the counters were taken on); bench.py quotes an entry only for a plan with the same fingerprint.
 
 Units and corrections as MI355X_MICROARCH.md (HBM / rocprofv3) prescribes: the counters are in
 KiB; on gfx950 FETCH_SIZE reports exactly half of a wide coalesced streaming read, so it is
@@ -60,6 +63,13 @@ def main():
         if "ehyb_er_kernel" in name and k["hbm_bytes_per_launch"]:
             res["ehyb_er_kernel_hbm_bytes_per_launch"] = k["hbm_bytes_per_launch"]
     res["workload"], res["storage"] = opts.get("--workload"), opts.get("--storage")
+    layout = None
+    if "--layout" in opts:
+        try:
+            layout = json.load(open(opts["--layout"]))
+        except (OSError, ValueError):
+            layout = None
+    res["layout"] = layout
     json.dump(res, open(out_path, "w"), indent=1)
     if "--table" in opts and res["workload"] and res["storage"]:
         try:
@@ -81,7 +91,7 @@ def main():
                 tab["entries"][f"{res['workload']}|{res['storage']}|{base}"] = {
                     "hbm_bytes_per_launch": k["hbm_bytes_per_launch"], "fetch_bytes_corrected": k["fetch_bytes_corrected"],
                     "write_bytes": k["WRITE_SIZE_bytes"], "fetch_factor": factor, "instantiation": name,
-                    "launches": k["launches"], "evidence": opts.get("--round")}
+                    "launches": k["launches"], "evidence": opts.get("--round"), "layout": layout}
         json.dump(tab, open(opts["--table"], "w"), indent=1, sort_keys=True)
     print(json.dumps(res, indent=1))
 

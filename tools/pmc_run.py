@@ -19,6 +19,7 @@ def main():
     ap.add_argument("--workload", default="audikw_1-like")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--plain", action="store_true", help="every entry stored even for a symmetric workload")
+    ap.add_argument("--layout-out", default="", help="write the plan's layout fingerprint (bench.layout_fingerprint) here: pmc_parse.py stores it with the entry")
     args = ap.parse_args()
     import bench as B
     import ehyb_spmv_gpu_amd as E
@@ -40,6 +41,10 @@ def main():
         plan.spmv(dx.ptr, dy.ptr)
     lib.ehyb_dev_sync()
     st = plan.stats
+    if args.layout_out:
+        import json
+
+        json.dump(B.layout_fingerprint(st), open(args.layout_out, "w"))
     print("PMC_RUN", args.workload, "sym" if st["sym_pairs"] else "plain", {k: st[k] for k in ("nnz", "nnz_ell", "nnz_er", "size_block_ell", "bytes_format", "bytes_alg", "n_items", "window_loads")})
 
 
