@@ -53,6 +53,9 @@ WORKLOADS = {
     "audikw_1-graded": ("fem3d_graded", (943695, 3, 68, 68, 100000, 705000, 1, 1),
                         "harder stand-in for audikw_1: same size (943,695 rows, 77.65 M entries) on a GRADED mesh -- rows of 15 to 303 entries "
                         "(mean 82.3, sigma 41; audikw_1: 21 to 345, mean 82.3), scrambled labels"),
+    "audikw_1-mesh": ("mesh3d", (943695, 3, 24, 1500, 1),
+                      "unstructured stand-in for audikw_1: 314,565 random points (denser towards one corner), 24 nearest neighbours each, "
+                      "made symmetric, 3 unknowns per node -- 943,695 rows, ~78 M entries, rows of 75 to ~150 entries, no lattice anywhere"),
     "banded-4M": ("banded", (1 << 22, 32, 1024), "config 3: block-circulant band, 4,194,304 rows x 32 entries, zero residual"),
     "rmat-24": ("rmat", (24, 1 << 27, 1), "config 5: R-MAT 2^24 rows, 2^27 edge samples"),
     "kkt3d-200": ("kkt3d", (200,), "config 4 stand-in: KKT-like saddle point system on a 200^3 grid"),
@@ -67,7 +70,7 @@ WORKLOADS = {
 # drop-in caller hands to matrixReorder / spmvGPuEHYB
 REFERENCE_SIZING = {"audikw_1-like": (164, 6144, 0)}
 
-SYMMETRIC_GENERATORS = ("fem3d", "fem3d_graded", "kkt3d", "stencil2d")  # A == A^T by construction (include/ehyb.h)
+SYMMETRIC_GENERATORS = ("fem3d", "fem3d_graded", "kkt3d", "stencil2d", "mesh3d")  # A == A^T by construction (include/ehyb.h)
 SYM_MIN_ROWS = 45056  # EHYB_SYM_MIN_ROWS (include/ehyb.h): below it the direct shape with every entry stored is faster
 PMC_FILE = os.path.join(ROOT, "profiles", "pmc_traffic.json")
 
@@ -175,7 +178,7 @@ def all_ranks_agree_or_exit(bad, worst, torch, dist, world, dev, what):
     return bad, worst
 
 
-def partitioner_for(E, gen):
+def partitioner_for(E, gen):  # ("file": a real matrix -- EHYB_PART_AUTO finds out by itself)
     """R-MAT has no locality for a graph partitioner to find (2^24 rows: 124 M of 133 M edges cut after
     110 s of multilevel k-way); EHYB_PART_AUTO notices that itself after one coarsening attempt and falls back to
     blocks of the degree order -- naming that order up front saves even the attempt.  (Round 2 cut contiguous blocks
@@ -455,6 +458,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--mtx", default="", help="N=1: the headline on a Matrix Market file (e.g. ./read/audikw_1.mtx, as the reference's -m) instead of "
+                                              "a synthetic workload; symmetric files of >= 45056 rows get symmetric pair storage (--sym-pairs auto)")
     ap.add_argument("--workload", default=None, choices=sorted(WORKLOADS),
                     help="default: audikw_1-like at N = 1 (BASELINE config 2) and for --scaling weak, rmat-24 (config 5) for N > 1")
     ap.add_argument("--lds-doubles", type=int, default=0)
@@ -543,6 +548,22 @@ def main():
     # Symmetric pair storage for matrices that are symmetric (the reference reads such files with
     # matrixRead_sym, solver_test.c:127-265, and knows it too): an in-partition pair is stored once.
     sym = args.sym_pairs == "on" or (args.sym_pairs == "auto" and symmetric_storage_pays(gen, gargs))
+    file_matrix = None
+    if args.mtx:
+        if world > 1:
+            raise SystemExit("bench.py: --mtx is an N = 1 option")
+        # a real file (the reference's `-m name` = ./read/name.mtx): read once to learn its size and symmetry -- the
+        # storage, and with it the partition sizing, follow from the banner as in solver_test (solver_test.c:348-354)
+        t0 = time.time()
+        probe = E.Matrix.read_mtx(args.mtx)
+        sym = args.sym_pairs == "on" or (args.sym_pairs == "auto" and probe.symmetric and probe.n >= SYM_MIN_ROWS)
+        file_matrix = (probe.symmetric, probe.n, probe.nnz)
+        probe.free()
+        gen, gargs = "file", (args.mtx,)
+        args.workload = os.path.splitext(os.path.basename(args.mtx))[0]
+        desc = f"{args.mtx} ({'symmetric' if file_matrix[0] else 'general'} Matrix Market file, {file_matrix[1]} rows, {file_matrix[2]} entries expanded)"
+        args.no_plain_arm = args.no_dropin_arm = True   # those arms rebuild the matrix from its generator
+        print(f"[bench] {desc}: read in {time.time() - t0:.1f}s", file=sys.stderr, flush=True)
 
     if world > 1:
         if sym:
@@ -564,9 +585,9 @@ def main():
         kw["sym_pairs"] = 1
     cfg = E.make_config(partitioner=partitioner_for(E, gen), verbose=1 if args.verbose else 0, value_map=0 if args.no_refill_arm else 1, **kw)
     t0 = time.time()
-    m = E.Matrix.generate(gen, *gargs, cfg=cfg)
+    m = E.Matrix.read_mtx(args.mtx, cfg) if args.mtx else E.Matrix.generate(gen, *gargs, cfg=cfg)
     n, nnz = m.n, m.nnz
-    log(f"[bench] generated {args.workload}: n={n} nnz={nnz} in {time.time() - t0:.1f}s")
+    log(f"[bench] {'read' if args.mtx else 'generated'} {args.workload}: n={n} nnz={nnz} in {time.time() - t0:.1f}s")
 
     # ---- CPU baseline on the un-permuted matrix: the oracle, timed; its y is also the parity checker
     cpu_baseline = None
@@ -743,7 +764,7 @@ def main():
         "metric": "fp64 SpMV GFLOP/s (2*nnz/t_iter), EHYB on MI355X",
         "value": round(2.0 * nnz * args.steps / elapsed / 1e9, 2), "unit": "GFLOP/s", "n_gpus": 1, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 5), "higher_is_better": True,
-        "scaling": "none", "vs_baseline": None, "dtype": "f64", "data": "synthetic: " + desc,
+        "scaling": "none", "vs_baseline": None, "dtype": "f64", "data": ("file: " if args.mtx else "synthetic: ") + desc,
         "config": {"workload": args.workload, "rows": n, "nnz": nnz, "parts": st["n_parts"],
                    "lds_doubles": int(cfg.lds_doubles), "part_rows": int(cfg.part_rows), "threads": int(cfg.threads),
                    "window_mode": "halo" if cfg.window_mode != 1 else "reference",

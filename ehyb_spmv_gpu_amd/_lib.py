@@ -170,6 +170,7 @@ SIGNATURES = {
     "ehyb_gen_rmat_block": (C.c_int, [C.c_int, C.c_int64, C.c_uint64, C.c_int, C.c_int, _ip, _cfgp, _mp]),
     "ehyb_gen_stencil2d": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _cfgp, _mp]),
     "ehyb_gen_kkt3d": (C.c_int, [C.c_int, _cfgp, _mp]),
+    "ehyb_gen_mesh3d": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _cfgp, _mp]),
 }
 
 # C++-linkage names of include/reordering.h, as the reference's driver links them (reordering.h:6-10;

@@ -120,13 +120,16 @@ Config resolve_config(const ehyb_config* in)
     c.hub_rule = z.hub_rule == 2 ? 2 : 1;
     c.part_boundary_cap = z.part_boundary_cap > 0 ? z.part_boundary_cap : 0;
     c.er_mode = (z.er_mode == 1 || z.er_mode == 2) ? z.er_mode : 0;
-    c.er_panel_cols = z.er_panel_cols > 0 ? std::min(16384, std::max(256, round_down(z.er_panel_cols, 64))) : 8192;
+    // default 16,384 columns = 128 KiB of x per panel, one 1024-thread workgroup per CU: with the degree order and the
+    // equal-cost items of round 3 the wider panel wins at every size measured (R-MAT 2^24: 544 us against 567-660 us for
+    // 8,192 columns, 2^22: 149 against 147 us; fewer partial sums: 46.1 M against 55.2 M).  Round 2's default was 8,192.
+    c.er_panel_cols = z.er_panel_cols > 0 ? std::min(16384, std::max(256, round_down(z.er_panel_cols, 64))) : 16384;
     c.er_block_rows = z.er_block_rows > 0 ? std::min(16384, std::max(64, z.er_block_rows)) : 2048;  // measured best on R-MAT 2^22 (1024-4096 level, 8192 25 % slower)
     c.direct = (z.direct == 1 || z.direct == 2) ? z.direct : 0;
     c.ell_prune = z.ell_prune == 2 ? 2 : 1;
     c.value_map = z.value_map == 1 ? 1 : 0;
     c.prune_pct = z.prune_pct > 0 ? z.prune_pct : 110;
-    c.er_units1 = z.er_units1 > 0 ? z.er_units1 : 2048;
+    c.er_units1 = z.er_units1 > 0 ? z.er_units1 : 0;  // 0: from the residual's size (er_panel.cpp)
     c.er_units2 = z.er_units2 > 0 ? z.er_units2 : 2048;
     c.graph_compress = (z.graph_compress == 1 || z.graph_compress == 2) ? z.graph_compress : 0;
     c.balance = (z.balance == 1 || z.balance == 2) ? z.balance : 0;

@@ -375,7 +375,11 @@ int build_panel_residual(const Config& cfg, HostLayout* L)
                 continue;
             }
             // this segment's share of the items; the target leaves room for the extra stagings the cuts add
-            const int64_t want = std::max<int64_t>(1, (int64_t)((double)cfg.er_units1 * (double)seg_cost[(size_t)s] / (double)total_cost + 0.5));
+            // items aimed at (cfg.er_units1 = 0): one per 48 k entries, between 512 (two rounds of one workgroup per CU) and
+            // 4096 -- R-MAT 2^22 (33 M entries): 1024 items 149 us, 2048 items 166 us (each item stages its 128 KiB panel
+            // again); 2^24 (133 M entries): 2048 items 544 us, 4096 items 563 us, 1024 items 663 us
+            const int64_t aim = cfg.er_units1 > 0 ? cfg.er_units1 : std::min<int64_t>(4096, std::max<int64_t>(512, nnz_er / 49152));
+            const int64_t want = std::max<int64_t>(1, (int64_t)((double)aim * (double)seg_cost[(size_t)s] / (double)total_cost + 0.5));
             const int64_t target = seg_cost[(size_t)s] / want + (kPerCol * W + kFixed) / 2 + 1;
             int64_t item_cost = 0;
             int32_t item_first = (int32_t)(L->pb_units1.size() / 4);

@@ -693,6 +693,140 @@ int ehyb_gen_stencil2d(int nx, int ny, int points, int extra, uint64_t seed, con
     return EHYB_OK;
 }
 
+// Unstructured-mesh stand-in (nothing here is a lattice): `nodes` random points in the unit cube, denser towards one
+// corner (coordinates u^grade), every node coupled to its `knn` nearest neighbours -- found through a cell grid --, the
+// coupling made symmetric (node degrees knn .. ~2 knn), `dof` unknowns per node with dense dof x dof blocks and
+// symmetric hashed values.  Labels are the points' random order: no locality in the numbering, row lengths vary.
+int ehyb_gen_mesh3d(int n, int dof, int knn, int grade_permille, uint64_t seed, const ehyb_config* cfg, matrixCOO* out)
+{
+    clear_error();
+    OmpScope omp_scope(cfg);
+    if (!out || n <= 0 || dof < 1 || dof > 8 || knn < 1 || knn > 64 || grade_permille < 0)
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_mesh3d: bad arguments");
+    const int nodes = (n + dof - 1) / dof;
+    const double grade = grade_permille > 0 ? grade_permille / 1000.0 : 1.0;
+    std::vector<float> px(nodes), py(nodes), pz(nodes);
+    {
+        uint64_t s = seed * 0x9E3779B97F4A7C15ull + 12345;
+        for (int i = 0; i < nodes; ++i) {
+            const double u = (double)(splitmix64(s) >> 11) / 9007199254740992.0, v = (double)(splitmix64(s) >> 11) / 9007199254740992.0,
+                         w = (double)(splitmix64(s) >> 11) / 9007199254740992.0;
+            px[i] = (float)std::pow(u, grade);
+            py[i] = (float)std::pow(v, grade);
+            pz[i] = (float)w;
+        }
+    }
+    // cell grid with about 4 points per cell on average
+    const int g = std::max(1, (int)std::cbrt(nodes / 4.0));
+    auto cell_of = [&](int i) {
+        const int cx = std::min(g - 1, (int)(px[i] * g)), cy = std::min(g - 1, (int)(py[i] * g)), cz = std::min(g - 1, (int)(pz[i] * g));
+        return (cz * g + cy) * g + cx;
+    };
+    std::vector<int> cell_ptr((size_t)g * g * g + 1, 0), cell_nodes(nodes);
+    for (int i = 0; i < nodes; ++i) ++cell_ptr[(size_t)cell_of(i) + 1];
+    for (size_t c = 0; c < (size_t)g * g * g; ++c) cell_ptr[c + 1] += cell_ptr[c];
+    {
+        std::vector<int> fill(cell_ptr.begin(), cell_ptr.end() - 1);
+        for (int i = 0; i < nodes; ++i) cell_nodes[fill[cell_of(i)]++] = i;
+    }
+    // knn nearest of every node: rings of cells until the knn-th best distance is inside the ring searched
+    std::vector<int> nbr((size_t)nodes * knn, -1);
+#pragma omp parallel
+    {
+        std::vector<std::pair<float, int>> cand;
+#pragma omp for schedule(dynamic, 256)
+        for (int i = 0; i < nodes; ++i) {
+            const int cx = std::min(g - 1, (int)(px[i] * g)), cy = std::min(g - 1, (int)(py[i] * g)), cz = std::min(g - 1, (int)(pz[i] * g));
+            cand.clear();
+            for (int ring = 0; ring <= g; ++ring) {
+                for (int z = cz - ring; z <= cz + ring; ++z)
+                    for (int y = cy - ring; y <= cy + ring; ++y)
+                        for (int x = cx - ring; x <= cx + ring; ++x) {
+                            if (std::max(std::abs(z - cz), std::max(std::abs(y - cy), std::abs(x - cx))) != ring) continue;  // this ring's shell only
+                            if (x < 0 || y < 0 || z < 0 || x >= g || y >= g || z >= g) continue;
+                            const int c = (z * g + y) * g + x;
+                            for (int q = cell_ptr[c]; q < cell_ptr[c + 1]; ++q) {
+                                const int j = cell_nodes[q];
+                                if (j == i) continue;
+                                const float dx = px[j] - px[i], dy = py[j] - py[i], dz = pz[j] - pz[i];
+                                cand.push_back({dx * dx + dy * dy + dz * dz, j});
+                            }
+                        }
+                if ((int)cand.size() >= knn) {
+                    std::nth_element(cand.begin(), cand.begin() + (knn - 1), cand.end());
+                    const float reach = (float)ring / g;  // everything nearer than this has been seen
+                    if (cand[knn - 1].first <= reach * reach || ring == g) break;
+                }
+            }
+            const int k = std::min(knn, (int)cand.size());
+            std::partial_sort(cand.begin(), cand.begin() + k, cand.end());
+            for (int q = 0; q < k; ++q) nbr[(size_t)i * knn + q] = cand[q].second;
+        }
+    }
+    // symmetric node adjacency, self included
+    std::vector<int> deg(nodes, 1);
+    for (int i = 0; i < nodes; ++i)
+        for (int q = 0; q < knn; ++q) {
+            const int j = nbr[(size_t)i * knn + q];
+            if (j >= 0) ++deg[i], ++deg[j];
+        }
+    std::vector<int64_t> aptr((size_t)nodes + 1, 0);
+    for (int i = 0; i < nodes; ++i) aptr[i + 1] = aptr[i] + deg[i];
+    std::vector<int> adj((size_t)aptr[nodes]);
+    {
+        std::vector<int64_t> fill(aptr.begin(), aptr.end() - 1);
+        for (int i = 0; i < nodes; ++i) {
+            adj[fill[i]++] = i;
+            for (int q = 0; q < knn; ++q) {
+                const int j = nbr[(size_t)i * knn + q];
+                if (j >= 0) adj[fill[i]++] = j, adj[fill[j]++] = i;
+            }
+        }
+    }
+    std::vector<int> cnt(nodes, 0);
+#pragma omp parallel for schedule(static, 1024)
+    for (int i = 0; i < nodes; ++i) {
+        std::sort(adj.begin() + aptr[i], adj.begin() + aptr[i + 1]);
+        cnt[i] = (int)(std::unique(adj.begin() + aptr[i], adj.begin() + aptr[i + 1]) - (adj.begin() + aptr[i]));
+    }
+    // rows: unknown d of node a = row a*dof + d (rows beyond n dropped, columns beyond n too)
+    int64_t nnz = 0;
+    std::vector<int> rowlen(n, 0);
+    for (int a = 0; a < nodes; ++a)
+        for (int d = 0; d < dof && a * dof + d < n; ++d) {
+            int len = 0;
+            for (int q = 0; q < cnt[a]; ++q) {
+                const int b = adj[aptr[a] + q];
+                len += std::min(dof, n - b * dof) > 0 ? std::min(dof, n - b * dof) : 0;
+            }
+            rowlen[a * dof + d] = len;
+            nnz += len;
+        }
+    int rc = alloc_matrix(n, nnz, out);
+    if (rc != EHYB_OK) return rc;
+    for (int i = 0; i < n; ++i) out->numInRow[i] = rowlen[i];
+    rc = finish_matrix(out, cfg);
+    if (rc != EHYB_OK) return rc;
+#pragma omp parallel for schedule(static, 256)
+    for (int a = 0; a < nodes; ++a)
+        for (int d = 0; d < dof && a * dof + d < n; ++d) {
+            const int i = a * dof + d;
+            int64_t at = out->rowIdx[i];
+            for (int q = 0; q < cnt[a]; ++q) {
+                const int b = adj[aptr[a] + q];
+                for (int e = 0; e < dof && b * dof + e < n; ++e) {
+                    const int j = b * dof + e;
+                    out->I[at] = i;
+                    out->J[at] = j;
+                    out->V[at] = hash_value_mixed((uint64_t)std::min(i, j), (uint64_t)std::max(i, j), seed);
+                    if (i == j) out->diag[i] = out->V[at];
+                    ++at;
+                }
+            }
+        }
+    return EHYB_OK;
+}
+
 // KKT-like saddle point system [H A^T; A 0] on an nx^3 grid: H = 7-point stencil, A couples a
 // constraint to the 19 primal unknowns within one face/edge step; the zero block keeps an
 // explicit zero diagonal, as nlpkkt200 stores it.

@@ -609,7 +609,8 @@ int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vw
                     int max_part_w, const Config& cfg, int* part, int64_t* edgecut, bool* by_degree)
 {
     if (by_degree) *by_degree = false;
-    if (n < 0 || nparts < 1 || !xadj || (!adjncy && xadj[n] > 0) || !part)
+    // (EHYB_PART_DEGREE reads the degrees only: adjncy may be null there, and the edge cut is then not computed)
+    if (n < 0 || nparts < 1 || !xadj || (!adjncy && xadj[n] > 0 && cfg.partitioner != EHYB_PART_DEGREE) || !part)
         EHYB_FAIL(EHYB_ERR_ARG, "partition_graph: bad arguments (n=%d, nparts=%d)", n, nparts);
     if (edgecut) *edgecut = 0;
     if (n == 0) return EHYB_OK;
@@ -653,7 +654,7 @@ int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vw
             if (last > cap) {  // rounding down to the cap left too much for the last block: spread evenly
                 for (int v = 0; v < n; ++v) part[at(v)] = (int)((int64_t)v * nparts / n);
             }
-            if (edgecut) *edgecut = edge_cut(fine, part);
+            if (edgecut) *edgecut = adjncy ? edge_cut(fine, part) : -1;
             return EHYB_OK;
         }
         int64_t acc = 0;
@@ -671,7 +672,7 @@ int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vw
             acc += w;
             in_p += w;
         }
-        if (edgecut) *edgecut = edge_cut(fine, part);
+        if (edgecut) *edgecut = adjncy ? edge_cut(fine, part) : -1;
         return EHYB_OK;
     };
     if (cfg.partitioner == EHYB_PART_CONTIGUOUS) return contiguous();

@@ -252,7 +252,29 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
         std::vector<int64_t> xadj;
         std::vector<int> adj;
         const double ta = wall_seconds();
-        build_adjacency(m, symmetric_pattern != 0, &xadj, &adj);
+        // EHYB_PART_DEGREE needs the DEGREES only (entries in the row + entries in the column, the diagonal left out):
+        // no adjacency lists -- on R-MAT 2^24 building them was a third of the whole reorder
+        const bool degrees_only = c.partitioner == EHYB_PART_DEGREE && c.n_top <= 1;
+        if (degrees_only) {
+            xadj.assign((size_t)n + 1, 0);
+            std::vector<int> colcnt(n, 0);
+            if (!symmetric_pattern) {
+#pragma omp parallel for schedule(static, 65536)
+                for (int64_t k = 0; k < nnz; ++k)
+                    if (m->J[k] != m->I[k]) {
+#pragma omp atomic
+                        ++colcnt[m->J[k]];
+                    }
+            }
+#pragma omp parallel for schedule(static, 4096)
+            for (int i = 0; i < n; ++i) {
+                int d = 0;
+                for (int k = m->rowIdx[i]; k < m->rowIdx[i + 1]; ++k) d += m->J[k] != i;
+                xadj[(size_t)i + 1] = d + colcnt[i];
+            }
+            for (int i = 0; i < n; ++i) xadj[(size_t)i + 1] += xadj[(size_t)i];
+        } else
+            build_adjacency(m, symmetric_pattern != 0, &xadj, &adj);
         const double t0 = wall_seconds();
         if (c.verbose) printf("adjacency time is %ld us\n", (long)((t0 - ta) * 1e6));
         int64_t cut = 0;
@@ -270,7 +292,7 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
             for (int i = 0; i < n; ++i) total += vw[i], maxw = std::max(maxw, vw[i]);
             std::vector<int> top(n, 0);
             int64_t tcap = (int64_t)((double)total / c.n_top * 1.03) + maxw;
-            rc = partition_graph(n, xadj.data(), adj.data(), vw.data(), c.n_top, (int)std::min<int64_t>(tcap, 0x7FFFFFFF), c,
+            rc = partition_graph(n, xadj.data(), adj.empty() ? nullptr : adj.data(), vw.data(), c.n_top, (int)std::min<int64_t>(tcap, 0x7FFFFFFF), c,
                                  top.data(), &cut);
             if (rc != EHYB_OK) return rc;
             const int usable = std::max(kSlabRows, (int)(cache * 0.97));
@@ -375,14 +397,14 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                     rc = EHYB_OK;
                     if (compress) rc = partition_compressed(m, xadj, adj, rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut, &done, &twin_group);
                     if (rc == EHYB_OK && !done)
-                        rc = partition_graph(n, xadj.data(), adj.data(), rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut, &by_degree);
+                        rc = partition_graph(n, xadj.data(), adj.empty() ? nullptr : adj.data(), rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut, &by_degree);
                 }
             }
             if (!weighted) {
                 bool done = false;
                 rc = EHYB_OK;
                 if (compress) rc = partition_compressed(m, xadj, adj, nullptr, nparts, cap, c, part.data(), &cut, &done, &twin_group);
-                if (rc == EHYB_OK && !done) rc = partition_graph(n, xadj.data(), adj.data(), nullptr, nparts, cap, c, part.data(), &cut, &by_degree);
+                if (rc == EHYB_OK && !done) rc = partition_graph(n, xadj.data(), adj.empty() ? nullptr : adj.data(), nullptr, nparts, cap, c, part.data(), &cut, &by_degree);
             }
             if (rc == EHYB_OK && by_degree) degree_order(n, xadj.data(), &row_order);
             if (c.verbose) printf("k-way partition time is %ld us\n", (long)((wall_seconds() - t0) * 1e6));
@@ -392,7 +414,8 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
             // shrinks both their row count and their halo; on mesh-like matrices the residual
             // (and its kernel launch) disappears.  Partitions that overflow by more than 1.5x
             // (power-law graphs) are left alone: splitting cannot make them fit.
-            if (rc == EHYB_OK && c.window_mode == EHYB_WINDOW_HALO && c.cap_split != 2) {
+            // (blocks of the degree order: a power-law graph -- bisecting a partition with a graph partitioner finds nothing)
+            if (rc == EHYB_OK && c.window_mode == EHYB_WINDOW_HALO && c.cap_split != 2 && !by_degree) {
                 const int* rp0 = m->rowIdx;  // the input is row-grouped: row i = entries [rp0[i], rp0[i+1])
                 for (int round = 0; round < (weighted ? 8 : 3); ++round) {
                     std::vector<int> demand(nparts, 0), local(n, -1);
@@ -521,7 +544,8 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
         {
             std::vector<int> cand;
             std::vector<std::pair<int, int>> uniq;
-#pragma omp for schedule(dynamic, 4)
+            std::vector<int> dense;  // reference counts by column, for partitions with millions of candidates (made on first use)
+#pragma omp for schedule(dynamic, 1)
             for (int p = 0; p < nparts; ++p) {
                 const int own = pb[p + 1] - pb[p];
                 // 2 doubles hold the kernel's slab counter; symmetric pair storage keeps y accumulators too
@@ -534,13 +558,26 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                         if (m->I[k] == i && part[m->J[k]] != p) cand.push_back(m->J[k]);
                 }
                 if (cand.empty()) continue;
-                std::sort(cand.begin(), cand.end());
                 uniq.clear();
-                for (size_t a = 0; a < cand.size();) {
-                    size_t b = a;
-                    while (b < cand.size() && cand[b] == cand[a]) ++b;
-                    uniq.push_back({(int)(b - a), cand[a]});
-                    a = b;
+                if (cand.size() > ((size_t)1 << 20)) {
+                    // the hub partition of a degree-ordered power-law matrix references a third of all entries: counted, not
+                    // sorted (one thread sorted 10 M candidates for a second while the others waited)
+                    if (dense.empty()) dense.assign((size_t)n, 0);
+                    size_t distinct = 0;
+                    for (int cc : cand)
+                        if (dense[(size_t)cc]++ == 0) cand[distinct++] = cc;  // the distinct columns, compacted in front
+                    for (size_t a = 0; a < distinct; ++a) {
+                        uniq.push_back({dense[(size_t)cand[a]], cand[a]});
+                        dense[(size_t)cand[a]] = 0;
+                    }
+                } else {
+                    std::sort(cand.begin(), cand.end());
+                    for (size_t a = 0; a < cand.size();) {
+                        size_t b = a;
+                        while (b < cand.size() && cand[b] == cand[a]) ++b;
+                        uniq.push_back({(int)(b - a), cand[a]});
+                        a = b;
+                    }
                 }
                 if ((int)uniq.size() > hcap) {
                     std::nth_element(uniq.begin(), uniq.begin() + hcap, uniq.end(),

@@ -68,7 +68,7 @@ static void usage()
            "            or write it (the reference repeats mt-metis + COO2EHYB on every run)\n"
            "  -m name   ./read/name.mtx (Matrix Market, general or symmetric)\n"
            "  -g spec   banded:n:band:block | fem3d:n:dof:nx:ny:ppm:scramble | rmat:scale:edges |\n"
-           "            stencil2d:nx:ny:points:extra | kkt3d:nx\n"
+           "            stencil2d:nx:ny:points:extra | kkt3d:nx | mesh3d:n:dof:knn:grade_permille\n"
            "  -w mode   1 = reference window (contiguous), 2 = halo window (default)\n");
 }
 
@@ -141,6 +141,9 @@ int main(int argc, char* argv[])
             rc = ehyb_gen_rmat((int)arg(0, 14), arg(1, 1 << 17), 1, &cfg, &A);
         } else if (kind == "stencil2d") {
             rc = ehyb_gen_stencil2d((int)arg(0, 150), (int)arg(1, 150), (int)arg(2, 5), (int)arg(3, 3000), 1, &cfg, &A);
+            symmetric = 1;
+        } else if (kind == "mesh3d") {
+            rc = ehyb_gen_mesh3d((int)arg(0, 30000), (int)arg(1, 3), (int)arg(2, 14), (int)arg(3, 1500), 1, &cfg, &A);
             symmetric = 1;
         } else if (kind == "kkt3d") {
             rc = ehyb_gen_kkt3d((int)arg(0, 20), &cfg, &A);

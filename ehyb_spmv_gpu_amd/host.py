@@ -151,6 +151,10 @@ class Matrix:
             (nx,) = args
             rc = m.lib.ehyb_gen_kkt3d(nx, cp, C.byref(m.c))
             m.symmetric = True
+        elif kind == "mesh3d":
+            n, dof, knn, grade, seed = args
+            rc = m.lib.ehyb_gen_mesh3d(n, dof, knn, grade, seed, cp, C.byref(m.c))
+            m.symmetric = True
         else:
             raise ValueError(f"unknown generator {kind!r}")
         _check(rc, f"ehyb_gen_{kind}")

@@ -136,7 +136,7 @@ typedef struct ehyb_config {
                               x panels and y blocks in LDS: er_panel.cpp), 0 = automatic: the panel form from 2^21
                               residual entries up when the residual shows no locality (more than one distinct
                               128-byte line of x per two consecutive entries), else CSR segments            */
-    int32_t er_panel_cols; /* panel form: columns per x panel staged in LDS (<= 16384, default 8192 = 64 KiB)          */
+    int32_t er_panel_cols; /* panel form: columns per x panel staged in LDS (<= 16384 = 128 KiB, the default)          */
     int32_t er_block_rows; /* panel form: most rows of a y block accumulated in LDS (<= 16384, default 2048)          */
     int32_t direct;        /* small matrices: 0 = automatic (plans of at most EHYB_DIRECT_MAX_ROWS rows, single GPU,
                               plain storage, window sizing left at its defaults), 1 = on, 2 = off.  On: no LDS window at all -- every row is multiplied by
@@ -157,7 +157,8 @@ typedef struct ehyb_config {
        EHYB_MTMETIS_LIB, names a shared object to load the optional mt-metis backend from). */
     int32_t prune_pct;     /* ell_prune: a window is given up when it costs more than this share (per cent) of what
                               the panel form would cost for its entries; 0 = 110                                */
-    int32_t er_units1;     /* panel form: work items (workgroups) pass 1 aims at (0 = 2048)                     */
+    int32_t er_units1;     /* panel form: work items (workgroups) pass 1 aims at (0 = one per 49,152
+                              residual entries, between 512 and 4096)                                           */
     int32_t er_units2;     /* panel form: row blocks pass 2 aims at (0 = 2048)                                 */
     int32_t graph_compress;/* the k-way partitioner works on the compressed graph where rows come in groups with one column
                               list (the unknowns of a node): 0 = with symmetric pair storage only (plain storage runs 4 %
@@ -600,6 +601,10 @@ int ehyb_gen_rmat_block(int scale, int64_t edges, uint64_t seed, int block, int 
 /* 2-D 5/9-point stencil plus `extra` random symmetric couplings (small test inputs) */
 int ehyb_gen_stencil2d(int nx, int ny, int points, int extra, uint64_t seed,
                        const ehyb_config* cfg, matrixCOO* out);
+/* unstructured-mesh stand-in: ceil(n/dof) random points in the unit cube (x, y = u^(grade_permille/1000): denser towards
+ * one corner; 0 = uniform), every node coupled to its knn nearest neighbours, made symmetric, dof unknowns per node;
+ * random labels, row lengths between (knn+1)*dof and ~2*knn*dof -- a check that thresholds fitted on lattices hold */
+int ehyb_gen_mesh3d(int n, int dof, int knn, int grade_permille, uint64_t seed, const ehyb_config* cfg, matrixCOO* out);
 /* nlpkkt-like 3-D KKT system: [H A^T; A 0] on an nx^3 grid */
 int ehyb_gen_kkt3d(int nx, const ehyb_config* cfg, matrixCOO* out);
 

@@ -47,14 +47,14 @@ def test_committed_pmc_table_matches_the_workload_table():
 
 def test_workload_table(E):
     for name, (gen, gargs, desc) in B.WORKLOADS.items():
-        assert isinstance(desc, str) and gen in ("fem3d", "fem3d_graded", "banded", "rmat", "kkt3d")
+        assert isinstance(desc, str) and gen in ("fem3d", "fem3d_graded", "banded", "rmat", "kkt3d", "mesh3d")
     assert B.symmetric_storage_pays(*B.WORKLOADS["audikw_1-like"][:2])
     assert not B.symmetric_storage_pays(*B.WORKLOADS["bcsstk17-like"][:2])            # below EHYB_SYM_MIN_ROWS
     assert not B.symmetric_storage_pays(*B.WORKLOADS["rmat-24"][:2])
     assert B.partitioner_for(E, "rmat") == E.EHYB_PART_DEGREE and B.partitioner_for(E, "fem3d") == E.EHYB_PART_AUTO
     assert B.SYM_MIN_ROWS == 45056
     # the generators behind the two audikw_1 stand-ins hit audikw_1's size (943,695 rows, 77,651,847 entries)
-    for wl in ("audikw_1-like", "audikw_1-graded"):
+    for wl in ("audikw_1-like", "audikw_1-graded", "audikw_1-mesh"):
         assert B.WORKLOADS[wl][1][0] == 943695
 
 

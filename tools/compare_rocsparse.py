@@ -29,7 +29,7 @@ def rocsparse_arm(E, O, np, gen, gargs, x, y_ref, scale, iters=100, algs=(("defa
     result checked against the CPU oracle.  -> {"best": {...}, name: {...}} (bench.py --vendor-baseline)."""
     build()
     lib = C.CDLL(LIB)
-    m = E.Matrix.generate(gen, *gargs)
+    m = E.Matrix.read_mtx(gargs[0]) if gen == "file" else E.Matrix.generate(gen, *gargs)
     n, nnz = m.n, m.nnz
     rp, J, V = m.row_idx.copy(), m.J.copy(), m.V.copy()
     m.free()
