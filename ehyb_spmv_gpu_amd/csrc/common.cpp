@@ -248,6 +248,14 @@ int ehyb_sizing(int dimension, const ehyb_config* cfg, int* nParts, int* vectorC
         c.part_rows == round_down(EHYB_LDS_MAX_DOUBLES * 11 / 20, kSlabRows)) {
         const int64_t want = ((int64_t)dimension / 160 + kSlabRows - 1) / kSlabRows * kSlabRows;
         cache = (int)std::min<int64_t>(cache, std::max<int64_t>(2048, want));
+        // Below ~160 k rows 2048-row partitions are fewer than 80 and every one is cut into three to five work items
+        // that stage the same window: about 160 partitions of >= 768 rows there (round 3, tools/midsize_sweep.py, two
+        // generators: KKT 128 k rows 9.0 -> 6.6 us, FEM 120 k rows 22.0 -> 21.2 us; at 195 k rows both are as good or
+        // better on the 2048-row partitions -- FEM 30.2 against 34.3 us, KKT 13.8 against 13.4 us -- which stay).
+        if ((int64_t)dimension < 80 * (int64_t)cache) {
+            const int64_t small = ((int64_t)dimension / 160 + kSlabRows - 1) / kSlabRows * kSlabRows;
+            cache = (int)std::min<int64_t>(cache, std::max<int64_t>(768, small));
+        }
     }
     // the graph partitioner needs slack to balance; contiguous blocks are cut exactly
     int64_t usable = c.partitioner == EHYB_PART_CONTIGUOUS ? cache : std::max<int64_t>(kSlabRows, (int64_t)(cache * 0.97));

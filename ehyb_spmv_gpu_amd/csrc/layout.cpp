@@ -23,6 +23,8 @@
 
 #include <omp.h>
 
+#include <parallel/algorithm>
+
 #include <algorithm>
 #include <numeric>
 
@@ -816,24 +818,37 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     };
     std::vector<Seg> segs;
     int64_t rows_er = 0;
-    for (int p = 0; p < np; ++p)
-        for (int r = pb[p]; r < pb[p + 1]; ++r) {
-            const int rr = r - row_begin;
-            int64_t len = er_rp[rr + 1] - er_rp[rr];
+    {
+        // segments per row first (the partitions tile the rows in order), then every row fills its own: parallel
+        auto pieces_of = [&](int64_t len) { return (len == 0 && !direct) ? 0 : (direct ? 1 : (int)((len + cfg.er_seg_len - 1) / cfg.er_seg_len)); };
+        std::vector<int64_t> seg_first((size_t)nrows + 1, 0);
+#pragma omp parallel for schedule(static, 8192) reduction(+ : rows_er)
+        for (int rr = 0; rr < nrows; ++rr) {
+            const int64_t len = er_rp[rr + 1] - er_rp[rr];
             // direct shape: the kernel assigns y, so every row has exactly one segment -- an empty one
             // for an empty row (y = 0), an unsplit one for a long row (no atomics on an unzeroed y)
-            if (len == 0 && !direct) continue;
+            seg_first[(size_t)rr + 1] = pieces_of(len);
             rows_er += len > 0;
-            const int32_t item = item_of_slab[slab_base[p] + slot_of[r - row_begin] / kSlabRows];
-            int pieces = direct ? 1 : (int)((len + cfg.er_seg_len - 1) / cfg.er_seg_len);
-            for (int q = 0; q < pieces; ++q) {
-                int64_t b = er_rp[rr] + len * q / pieces, e2 = er_rp[rr] + len * (q + 1) / pieces;
-                int32_t row = r | (pieces > 1 ? (int32_t)0x80000000 : 0);
-                segs.push_back({row, item, b, (int32_t)(e2 - b)});
-            }
         }
-    std::stable_sort(segs.begin(), segs.end(),
-                     [](const Seg& a, const Seg& b) { return a.item != b.item ? a.item < b.item : a.len > b.len; });
+        for (int rr = 0; rr < nrows; ++rr) seg_first[(size_t)rr + 1] += seg_first[(size_t)rr];
+        segs.resize((size_t)seg_first[(size_t)nrows]);
+#pragma omp parallel for schedule(dynamic, 4)
+        for (int p = 0; p < np; ++p)
+            for (int r = pb[p]; r < pb[p + 1]; ++r) {
+                const int rr = r - row_begin;
+                const int64_t len = er_rp[rr + 1] - er_rp[rr];
+                const int pieces = pieces_of(len);
+                if (pieces == 0) continue;
+                const int32_t item = item_of_slab[slab_base[p] + slot_of[rr] / kSlabRows];
+                for (int q = 0; q < pieces; ++q) {
+                    const int64_t b = er_rp[rr] + len * q / pieces, e2 = er_rp[rr] + len * (q + 1) / pieces;
+                    const int32_t row = r | (pieces > 1 ? (int32_t)0x80000000 : 0);
+                    segs[(size_t)seg_first[(size_t)rr] + (size_t)q] = {row, item, b, (int32_t)(e2 - b)};
+                }
+            }
+    }
+    __gnu_parallel::stable_sort(segs.begin(), segs.end(),
+                                [](const Seg& a, const Seg& b) { return a.item != b.item ? a.item < b.item : a.len > b.len; });
     const int64_t nseg = (int64_t)segs.size();
     if (nseg > 0x7FFFFFFFll) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: too many residual segments");
     L->er_seg_ptr.assign(nseg + 1, 0);
@@ -885,6 +900,12 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             }
         }
     }
+    // the row-order copies are done with: their pages go back before the panel form asks for as many again (on a freshly
+    // started VM the first touch of a page costs more than everything the builder does with it afterwards)
+    std::vector<int32_t>().swap(tcol);
+    std::vector<double>().swap(tval);
+    std::vector<int32_t>().swap(tsrc);
+    std::vector<Seg>().swap(segs);
     lap("pass 4 (residual segments)");
     // ---- a large residual also gets its panel form (er_panel.cpp): what the residual launch then runs
     ehyb_stats& st = L->stats;

@@ -5,7 +5,7 @@ cd "${GRAFT_REPO_ROOT:?}"
 TAG=${1:?tag}
 OUT=gpurun_out/${TAG}_all_workloads.jsonl
 : > $OUT
-for W in audikw_1-like audikw_1-graded banded-4M kkt3d-110 kkt3d-200 rmat-22 rmat-24 small bcsstk17-like; do
+for W in audikw_1-like audikw_1-graded audikw_1-mesh banded-4M kkt3d-110 kkt3d-200 rmat-22 rmat-24 small bcsstk17-like; do
   timeout 900 python bench.py --workload $W --steps 100 --warmup 10 --no-cpu-baseline --no-dropin-arm --no-scaling-anchor 2> gpurun_out/${TAG}_$W.err | grep '^{' >> $OUT || echo "{\"workload\": \"$W\", \"error\": true}" >> $OUT
 done
 python - $OUT <<'PY'
