@@ -297,7 +297,9 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     y_cpu = O.spmv_coo(n, I, J, V, x)[r0:r1]      # checker (not timed): the oracle on this rank's rows
     scale = O.abs_rowsum(n, I, J, V, x)[r0:r1]
     t0 = time.time()
-    shares = [float(v) for v in args.chunk_shares.split(",")] if args.chunk_shares else None
+    # default: the hot quarter of every owner's ghost columns first (on R-MAT 2^24 at 8 ranks it carries 73-75 % of a rank's
+    # entries: tools/dist_stats.py), the rest while those panels multiply
+    shares = [float(v) for v in args.chunk_shares.split(",")] if args.chunk_shares else ([0.25, 0.75] if args.chunks == 2 else None)
     L = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, symmetric=symmetric, exchange=args.exchange, chunks=args.chunks, chunk_shares=shares)
     del I, J
     if args.exchange == "halo":
@@ -488,7 +490,7 @@ def main():
     ap.add_argument("--chunks", type=int, default=2,
                     help="N>1 halo: exchange steps per multiply -- every owner's ghost columns, hottest first, are cut into this many "
                          "chunks; the panels of chunk k are multiplied while chunk k+1 is on the wire")
-    ap.add_argument("--chunk-shares", default="", help="N>1 halo: share of every owner's ghost columns per chunk, e.g. 0.3,0.7 (default: equal)")
+    ap.add_argument("--chunk-shares", default="", help="N>1 halo: share of every owner's ghost columns per chunk, e.g. 0.3,0.7 (default: 0.25,0.75 for two chunks, else equal)")
     ap.add_argument("--exchange-mode", default="a2a", choices=["a2a", "p2p"],
                     help="N>1 halo: a2a = one all_to_all_single per exchange step; p2p = grouped isend/irecv pairs (explicit, never a fallback)")
     ap.add_argument("--verbose", action="store_true")

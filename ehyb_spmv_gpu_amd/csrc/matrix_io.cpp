@@ -536,11 +536,24 @@ int ehyb_gen_rmat_block(int scale, int64_t edges, uint64_t seed, int block, int 
                 for (int i = 0; i < n; ++i) hist[i + 1] += h[i];
     }
     for (int i = 0; i < n; ++i) hist[i + 1] += hist[i];
+    // Blocks of equal COST, not of equal samples: besides its entries a row costs its x and y entries and -- in the panel
+    // form the ranks of a power-law matrix multiply with -- about one partial sum of its own, i.e. per-row bytes.  Measured
+    // on the plans of R-MAT 2^24 at 8 ranks (tools/dist_stats.py): format bytes = 18 B per entry + 34 B per row, so that
+    // equal samples gave the rank with the 7.3 M low-degree rows 552 MB to move and the rank with the 70 k hub rows 295 MB.
+    // A row counts for two samples more.
+    auto cost_before = [&](int i) { return hist[(size_t)i] + 2 * (int64_t)i; };
     cuts[0] = 0;
     for (int b = 1; b < n_blocks; ++b) {
-        const int64_t goal = hist[n] * b / n_blocks;
-        int c = (int)(std::lower_bound(hist.begin(), hist.end(), goal) - hist.begin());
-        c = std::min(std::max(c, cuts[b - 1] + 1), n - (n_blocks - b));
+        const int64_t goal = cost_before(n) * b / n_blocks;
+        int lo = 0, hi = n;  // first row index whose cost_before reaches the goal
+        while (lo < hi) {
+            const int mid = lo + (hi - lo) / 2;
+            if (cost_before(mid) < goal)
+                lo = mid + 1;
+            else
+                hi = mid;
+        }
+        int c = std::min(std::max(lo, cuts[b - 1] + 1), n - (n_blocks - b));
         cuts[b] = c;
     }
     cuts[n_blocks] = n;

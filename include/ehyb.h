@@ -594,7 +594,7 @@ int ehyb_gen_fem3d_block(int n, int dof, int nx, int ny, int extra_ppm, int scra
 /* R-MAT (a,b,c,d)=(.57,.19,.19,.05), 2^scale rows, `edges` samples, duplicates merged */
 int ehyb_gen_rmat(int scale, int64_t edges, uint64_t seed, const ehyb_config* cfg, matrixCOO* out);
 /* The rows of row block `block` of n_blocks of that same matrix, for a process that owns one block (strong
- * scaling, one process per GPU): contiguous row ranges with about equally many edge samples; cuts
+ * scaling, one process per GPU): contiguous row ranges of about equal cost (edge samples + 2 per row); cuts
  * (n_blocks+1 ints, out) are the same on every process.  Dimension 2^scale, rows outside the block empty. */
 int ehyb_gen_rmat_block(int scale, int64_t edges, uint64_t seed, int block, int n_blocks, int* cuts, const ehyb_config* cfg,
                         matrixCOO* out);
