@@ -130,6 +130,7 @@ SIGNATURES = {
     "ehyb_plan_host_array": (C.c_int, [_vp, C.c_int, _P(_vp), _i64p]),
     "ehyb_spmv": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ehyb_spmv_phase": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
+    "ehyb_plan_tune": (C.c_int, [_vp, _vp, _vp, C.c_int, _dp, _dp]),
     "ehyb_spmv_part": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "ehyb_plan_col_segs": (C.c_int, [_vp, _ip]),
     "ehyb_gather": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),

@@ -138,6 +138,7 @@ struct EllArgs {
     const double* __restrict__ x;
     double* __restrict__ y;
     int win_cap;
+    const int* __restrict__ item_map;  // non-null (ehyb_plan_tune): workgroup b takes item item_map[b]
     int xcd_map;  // 1: workgroup b takes item xcd_item(b), so that each XCD works on one contiguous run of items
     int windowless_zero;  // 1: a partition without a window gets y = 0 here; 0: the panel residual's second pass assigns its y
     unsigned long long* __restrict__ stamps;
@@ -150,6 +151,14 @@ __device__ __forceinline__ int xcd_item(int b, int n)
 {
     const int k = b & 7, j = b >> 3, chunk = n >> 3, rem = n & 7;
     return k * chunk + min(k, rem) + j;
+}
+
+// Which work item workgroup b takes: the tuned map of the plan (ehyb_plan_tune: the heaviest items on the XCDs that were
+// measured fastest), else one contiguous run of items per XCD (plain storage), else item b.
+__device__ __forceinline__ int item_of_block(const int* __restrict__ item_map, int xcd_map)
+{
+    const int b = (int)blockIdx.x;
+    return item_map ? item_map[b] : (xcd_map ? xcd_item(b, (int)gridDim.x) : b);
 }
 
 // One entry of a slab: gather x from the window; SYM: bit 15 of the column says "this entry also
@@ -296,7 +305,7 @@ __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict
     __syncthreads();
     // diagnostic launches only (tools/stamps.py): when the first window of the item was staged
     if (A.stamps != nullptr && threadIdx.x == 0 &&
-        g == A.items[2 * (A.xcd_map ? xcd_item(blockIdx.x, gridDim.x) : (int)blockIdx.x)].x)
+        g == A.items[2 * item_of_block(A.item_map, A.xcd_map)].x)
         A.stamps[4 * blockIdx.x + 1] = wall_clock64();
     int s = sb + wave;
     while (s < se) {
@@ -328,7 +337,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(SYM ? 4
     extern __shared__ __attribute__((aligned(16))) double win[];
     int* next_slab = reinterpret_cast<int*>(win + A.win_cap);  // one word behind the window
     if (STAMP && threadIdx.x == 0) A.stamps[4 * blockIdx.x + 0] = wall_clock64();
-    const int4 it = A.items[2 * (A.xcd_map ? xcd_item(blockIdx.x, gridDim.x) : (int)blockIdx.x)];
+    const int4 it = A.items[2 * item_of_block(A.item_map, A.xcd_map)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     for (int sg = it.x; sg < it.y; ++sg) {
@@ -659,7 +668,8 @@ static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long 
     A.win_cap = ell_win_cap(P->host);
     A.stamps = stamps;
     // on by default: plain storage 143 -> 134 us on the audikw_1-like matrix; cfg.xcd_map = 2 for the A/B
-    A.xcd_map = P->host.sym ? 0 : (P->cfg.xcd_map != 2 ? 1 : 0);  // symmetric pairs: items are sorted heaviest first, dispatched in that order
+    A.xcd_map = P->host.sym ? 0 : (P->cfg.xcd_map != 2 ? 1 : 0);
+    A.item_map = P->d_item_map;  // symmetric pairs: items are sorted heaviest first, dispatched in that order
     A.windowless_zero = P->host.pb_assign ? 0 : 1;
     return A;
 }
@@ -786,7 +796,7 @@ static void free_device(ehyb_plan* P)
                      (void**)&P->d_er_seg_row, (void**)&P->d_er_col,    (void**)&P->d_er_val,     (void**)&P->d_er_blocks,
                      (void**)&P->d_slab_lrow,  (void**)&P->d_pb_val,    (void**)&P->d_pb_colf,    (void**)&P->d_pb_chunk,   (void**)&P->d_pb_jump,
                      (void**)&P->d_pb_units1,  (void**)&P->d_pb_items1,  (void**)&P->d_pb_row,    (void**)&P->d_pb_units2,  (void**)&P->d_pb_partial,
-                     (void**)&P->d_ell_src,    (void**)&P->d_ell_src2,  (void**)&P->d_er_src,     (void**)&P->d_pb_src};
+                     (void**)&P->d_item_map,   (void**)&P->d_ell_src,    (void**)&P->d_ell_src2,  (void**)&P->d_er_src,     (void**)&P->d_pb_src};
     for (void** q : ptrs) {
         if (*q) (void)hipFree(*q);
         *q = nullptr;
@@ -895,6 +905,118 @@ int ehyb_debug_ell_stamps(ehyb_plan* P, const double* x, double* y, unsigned lon
     if (rc == EHYB_OK && hipMemcpy(out_host, d, (size_t)n_items * 32, hipMemcpyDeviceToHost) != hipSuccess) rc = EHYB_ERR_HIP;
     if (rc == EHYB_ERR_HIP) set_error("ehyb_debug_ell_stamps: %s", hipGetErrorString(hipGetLastError()));
     (void)hipFree(d);
+    return rc;
+}
+
+// Tuning of the item -> workgroup map on the device the plan lives on (see ehyb.h).
+int ehyb_plan_tune(ehyb_plan* P, const double* x, double* y, int reps, double* span_before_us, double* span_after_us)
+{
+    clear_error();
+    if (!P || !P->uploaded || !x || !y) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_tune: bad arguments");
+    if (span_before_us) *span_before_us = 0;
+    if (span_after_us) *span_after_us = 0;
+    const HostLayout& H = P->host;
+    const int n_items = (int)(H.items.size() / 8);
+    const int resident = kNumCU * std::max(1, P->cfg.items_per_cu);
+    // one resident round only: with more items than slots the later ones start wherever a CU falls free
+    if (H.direct || n_items < 16 || n_items > resident || (H.pb_assign && H.segs.empty())) return EHYB_OK;
+    reps = std::min(std::max(reps, 1), 16);
+    unsigned long long* d = nullptr;
+    HIP_TRY(hipMalloc((void**)&d, (size_t)n_items * 32));
+    std::vector<unsigned long long> st((size_t)n_items * 4);
+    // cost of an item: the bytes its slabs stream (values 16 B per lane and pair + column words) + its windows
+    std::vector<double> cost((size_t)n_items, 0.0);
+    for (int i = 0; i < n_items; ++i) {
+        const int32_t* rec = &H.items[(size_t)i * 8];
+        double c = 0;
+        for (int s = rec[2]; s < rec[3]; ++s) {
+            const uint32_t w = H.slab_meta[(size_t)s * 4 + 3];
+            c += (double)(w >> 16) * (1024.0 + 4.0 * ((w & 0x3Fu) + 1));
+        }
+        for (int g = rec[0]; g < rec[1]; ++g) c += 8.0 * (H.segs[(size_t)g * 8 + 6] + H.segs[(size_t)g * 8 + 3]) + 16.0 * (H.segs[(size_t)g * 8 + 5] - H.segs[(size_t)g * 8 + 4]);
+        cost[(size_t)i] = c + 1.0;
+    }
+    auto measure = [&](std::vector<double>* dur, std::vector<int>* xcc, double* span_us) -> int {
+        // item taken by block b under the CURRENT map
+        dur->assign((size_t)n_items, 0.0);
+        xcc->assign((size_t)n_items, -1);
+        double span = 0;
+        for (int r = 0; r < reps + 1; ++r) {  // the first launch warms the caches and is not counted
+            if (hipMemset(d, 0, (size_t)n_items * 32) != hipSuccess) return EHYB_ERR_HIP;
+            const int rc = launch_ell_impl<true>(P, x, y, nullptr, H.inline_er, d);
+            if (rc != EHYB_OK) return rc;
+            if (hipDeviceSynchronize() != hipSuccess || hipMemcpy(st.data(), d, (size_t)n_items * 32, hipMemcpyDeviceToHost) != hipSuccess) return EHYB_ERR_HIP;
+            if (r == 0) continue;
+            unsigned long long t0 = ~0ull, t1 = 0;
+            for (int b = 0; b < n_items; ++b) {
+                (*dur)[(size_t)b] += (double)(st[(size_t)b * 4 + 2] - st[(size_t)b * 4 + 0]) / (100.0 * reps);  // 100 MHz clock -> us
+                const int k = (int)st[(size_t)b * 4 + 3] & 15;
+                if ((*xcc)[(size_t)b] >= 0 && (*xcc)[(size_t)b] != k) (*xcc)[(size_t)b] = -2;  // not a stable placement
+                else if ((*xcc)[(size_t)b] != -2) (*xcc)[(size_t)b] = k;
+                t0 = std::min(t0, st[(size_t)b * 4 + 0]);
+                t1 = std::max(t1, st[(size_t)b * 4 + 2]);
+            }
+            span += (double)(t1 - t0) / (100.0 * reps);
+        }
+        *span_us = span;
+        return EHYB_OK;
+    };
+    std::vector<double> dur;
+    std::vector<int> xcc;
+    double span0 = 0, span1 = 0;
+    int rc = measure(&dur, &xcc, &span0);
+    std::vector<int32_t> map_now((size_t)n_items);
+    for (int b = 0; b < n_items; ++b) map_now[(size_t)b] = P->item_map.empty() ? (P->host.sym || P->cfg.xcd_map == 2 ? b : [&] { const int k = b & 7, j = b >> 3, chunk = n_items >> 3, rem = n_items & 7; return k * chunk + std::min(k, rem) + j; }()) : P->item_map[(size_t)b];
+    bool stable = rc == EHYB_OK;
+    for (int b = 0; b < n_items && stable; ++b) stable = xcc[(size_t)b] >= 0;
+    if (stable) {
+        // how fast each XCD streamed what it was given: median over its workgroups of bytes per microsecond
+        std::vector<std::vector<double>> rates(16);
+        std::vector<std::vector<int>> slots(16);
+        for (int b = 0; b < n_items; ++b) {
+            rates[(size_t)xcc[(size_t)b]].push_back(cost[(size_t)map_now[(size_t)b]] / std::max(dur[(size_t)b], 1e-3));
+            slots[(size_t)xcc[(size_t)b]].push_back(b);
+        }
+        std::vector<std::pair<double, int>> order;  // (median rate, xcd), fastest first
+        for (int k = 0; k < 16; ++k)
+            if (!rates[(size_t)k].empty()) {
+                std::nth_element(rates[(size_t)k].begin(), rates[(size_t)k].begin() + rates[(size_t)k].size() / 2, rates[(size_t)k].end());
+                order.push_back({-rates[(size_t)k][rates[(size_t)k].size() / 2], k});
+            }
+        std::sort(order.begin(), order.end());
+        std::vector<int> by_cost((size_t)n_items);
+        for (int i = 0; i < n_items; ++i) by_cost[(size_t)i] = i;
+        std::stable_sort(by_cost.begin(), by_cost.end(), [&](int a, int b2) { return cost[(size_t)a] > cost[(size_t)b2]; });
+        // the heaviest items on the fastest XCD, and so on down: the pairing that minimises the largest cost / rate
+        std::vector<int32_t> map_new((size_t)n_items, -1);
+        size_t at = 0;
+        for (const auto& o : order)
+            for (int b : slots[(size_t)o.second]) map_new[(size_t)b] = by_cost[at++];
+        int32_t* dm = nullptr;
+        if (at == (size_t)n_items && hipMalloc((void**)&dm, (size_t)n_items * 4) == hipSuccess &&
+            hipMemcpy(dm, map_new.data(), (size_t)n_items * 4, hipMemcpyHostToDevice) == hipSuccess) {
+            int32_t* old = P->d_item_map;
+            std::vector<int32_t> old_host = P->item_map;
+            P->d_item_map = dm;
+            P->item_map = map_new;
+            std::vector<double> dur2;
+            std::vector<int> xcc2;
+            rc = measure(&dur2, &xcc2, &span1);
+            if (rc != EHYB_OK || span1 >= span0) {  // no gain on this device: the map the plan had stays
+                P->d_item_map = old;
+                P->item_map = old_host;
+                (void)hipFree(dm);
+                span1 = span0;
+            } else if (old) {
+                (void)hipFree(old);
+            }
+        } else if (dm) {
+            (void)hipFree(dm);
+        }
+    }
+    (void)hipFree(d);
+    if (span_before_us) *span_before_us = span0;
+    if (span_after_us) *span_after_us = stable ? span1 : span0;
     return rc;
 }
 
@@ -1273,6 +1395,9 @@ int spmvGPuEHYB_cfg(matrixCOO* localMatrix, const double* vectorIn, double* vect
     }
     double ms = 0;
     const int iters = std::max(1, MAXIter);
+    // part of the warm-up: the heaviest work items onto the XCDs of THIS device that stream fastest (a few stamped
+    // launches; keeps what it finds only if the launch got shorter; its failure is not the multiply's)
+    if (ehyb_plan_tune(P, dx, dy, 3, nullptr, nullptr) != EHYB_OK) clear_error();
     rc = ehyb_spmv_bench(P, dx, dy, nullptr, 10, iters, &ms, nullptr, nullptr);  // spmv.cu:100-116
     if (rc != EHYB_OK) return fail(rc);
     if (hipMemcpy(vectorOut, dy, n * 8, hipMemcpyDeviceToHost) != hipSuccess) {

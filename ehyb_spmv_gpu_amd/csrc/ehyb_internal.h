@@ -225,6 +225,8 @@ struct ehyb_plan {
     uint8_t* d_lane_group = nullptr;
     uint32_t* d_slab_meta = nullptr;
     int32_t* d_items = nullptr;
+    int32_t* d_item_map = nullptr;      // ehyb_plan_tune: item of every ELL workgroup (null: the built-in order)
+    std::vector<int32_t> item_map;      // its host copy (a property of the device the plan was tuned on: not saved)
     int64_t* d_er_seg_ptr = nullptr;
     int32_t* d_er_seg_row = nullptr;
     int32_t* d_er_col = nullptr;

@@ -384,6 +384,12 @@ class Plan:
         _check(self.lib.ehyb_spmv_phase(self.h, C.c_void_p(x_dev), C.c_void_p(y_dev), C.c_void_p(stream), phase),
                "ehyb_spmv")
 
+    def tune(self, x_dev, y_dev, reps=5):
+        """ehyb_plan_tune: the heaviest work items on the XCDs measured fastest -> (launch span before, after) in us."""
+        a, b = C.c_double(0), C.c_double(0)
+        _check(self.lib.ehyb_plan_tune(self.h, C.c_void_p(x_dev), C.c_void_p(y_dev), reps, C.byref(a), C.byref(b)), "ehyb_plan_tune")
+        return a.value, b.value
+
     def spmv_part(self, x_dev, y_dev, stream, seg_begin, seg_end, flags):
         """ehyb_spmv_part: flags 1 = the ELL launch first, 2 = the closing pass (EHYB_PART_FIRST / _LAST)."""
         _check(self.lib.ehyb_spmv_part(self.h, C.c_void_p(x_dev), C.c_void_p(y_dev), C.c_void_p(stream), seg_begin, seg_end, flags),

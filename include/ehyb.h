@@ -400,6 +400,19 @@ int ehyb_spmv(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream)
 int ehyb_spmv_phase(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream, int phase);
 
 /*
+ * Tuning on the device the plan lives on (optional; no reference counterpart).  The 8 XCDs of an MI355X do not stream at
+ * the same rate -- on every box measured two of them finish a launch 8-12 % behind the fastest at equal bytes, and which
+ * ones is a property of the box -- while the ELL launch of a plan with one resident round of workgroups lasts as long as
+ * its LAST workgroup.  This call times a few stamped launches of the ELL kernel (per-workgroup clocks, XCC id), ranks the
+ * XCDs by the rate they streamed at, and lets workgroup b take item item_map[b] with the heaviest items on the fastest XCD
+ * and so on down; it keeps the new map only if the stamped launch got shorter.  *span_before_us / *span_after_us (may be
+ * NULL): launch span before and with the map the plan ends with.  Synchronous (null stream); y is overwritten with A*x.
+ * No-op for plans whose ELL launch needs more than one round of workgroups, for the direct shape and for plans without
+ * an ELL launch.  spmvGPuEHYB does it during its warm-up; plan-API callers decide for themselves.
+ */
+int ehyb_plan_tune(ehyb_plan* plan, const double* x_dev, double* y_dev, int reps, double* span_before_us, double* span_after_us);
+
+/*
  * The multiply in PARTS, for a caller that receives x segment by segment (multi-GPU, ehyb_plan_create_host_segs):
  *   flags & EHYB_PART_FIRST   the ELL launch (window columns: all inside column segment 0) runs first;
  *   column segments [seg_begin, seg_end): pass 1 of the panel-form residual over the panels of those segments
