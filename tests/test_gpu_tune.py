@@ -7,8 +7,8 @@ pytestmark = pytest.mark.gpu
 
 
 @pytest.mark.parametrize("kw,gen", [
-    (dict(sym_pairs=1), ("fem3d", 200000, 3, 42, 42, 13500, 1, 1)),          # one workgroup per partition, one round
-    (dict(sym_pairs=0, direct=2), ("fem3d", 200000, 3, 42, 42, 13500, 1, 1)),  # plain storage: default map = one run of items per XCD
+    (dict(sym_pairs=1), ("fem3d", 196608, 3, 42, 42, 13500, 1, 1)),          # one workgroup per partition, one round
+    (dict(sym_pairs=0, direct=2), ("fem3d", 196608, 3, 42, 42, 13500, 1, 1)),  # plain storage: default map = one run of items per XCD
     (dict(sym_pairs=1, lds_doubles=2048), ("fem3d", 120000, 3, 35, 35, 13500, 1, 1)),   # several rounds of workgroups: a no-op
 ], ids=["sym-one-round", "plain-one-round", "sym-several-rounds"])
 def test_tuned_plan_multiplies_right(E, O, gpu, kw, gen):
