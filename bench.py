@@ -327,6 +327,17 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     vol[rank] = torch.from_numpy(L.recv_counts.astype(np.float64).reshape(-1)).to(dev)
     dist.all_reduce(vol)
     log(f"[bench] parity vs CPU oracle (all ranks, own rows): {bad} rows over 1e-12, worst {worst:.3e}")
+    # ---- the SAME matrix on ONE GPU, in this very run: rank 0 multiplies the whole matrix on its GPU while the others wait,
+    # so that the line carries its own N = 1 point (the N = 1 default of bench.py is BASELINE config 2, another matrix)
+    single = None
+    if not args.no_single_gpu_anchor:
+        if rank == 0:
+            t0 = time.time()
+            kw1 = {k: int(getattr(cfg, k)) for k in ("host_threads",)}
+            single = side_arm("single-GPU anchor", lambda: one_gpu_case(E, O, np, args.workload, symmetric and symmetric_storage_pays(gen, gargs), kw1,
+                                                                        min(args.steps, 50), min(args.warmup, 5), log, want_parity=False), log)
+            log(f"[bench] the same matrix on one GPU: {single.get('value')} GFLOP/s, {single.get('ms_per_step')} ms ({time.time() - t0:.1f}s incl. its pre-step)")
+        dist.barrier()
     if rank == 0:
         ms = elapsed / args.steps * 1e3
         words = int(stats[0].item()) if args.exchange == "halo" else sh.seg_len * world * (world - 1)
@@ -355,6 +366,10 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
             "phase1_share_of_local_ms": round(float(mx[3].item()) / max(float(mx[1].item()), 1e-9), 4),
             "own_columns_share_of_entries": round(float(stats[4].item()) / max(float(stats[2].item()), 1.0), 4),
             "host_us_per_step": round(args.host_us_per_step, 1),
+            # strong scaling read off ONE run: the whole job against the same matrix on rank 0's GPU alone
+            "single_gpu_same_matrix": single,
+            "speedup_vs_single_gpu_same_run": (round(2.0 * nnz * args.steps / elapsed / 1e9 / single["value"], 3)
+                                               if single and single.get("value") else None),
             "n1_equivalent": ("the N = 1 line's scaling_anchor (same matrix, one GPU)" if args.workload == "rmat-24" else
                               "the N = 1 line's value (same matrix, one GPU)" if args.workload == "audikw_1-like" else
                               f"bench.py --workload {args.workload} (N = 1)"),
@@ -494,6 +509,8 @@ def main():
     ap.add_argument("--chunk-shares", default="", help="N>1 halo: share of every owner's ghost columns per chunk, e.g. 0.3,0.7 (default: 0.25,0.75 for two chunks, else equal)")
     ap.add_argument("--exchange-mode", default="a2a", choices=["a2a", "p2p"],
                     help="N>1 halo: a2a = one all_to_all_single per exchange step; p2p = grouped isend/irecv pairs (explicit, never a fallback)")
+    ap.add_argument("--no-single-gpu-anchor", action="store_true",
+                    help="N>1 strong: skip the run of the same matrix on rank 0's GPU alone (the N = 1 point inside the N > 1 line)")
     ap.add_argument("--no-tune", action="store_true", help="N=1: skip ehyb_plan_tune (the item -> workgroup map stays the built-in one)")
     ap.add_argument("--verbose", action="store_true")
     args = ap.parse_args()

@@ -428,15 +428,18 @@ __device__ __forceinline__ double piece_sums(double prod, unsigned long long hea
 // sum back and stores it (kept as the A/B arm: the LDS pipe of a CU was what bound pass 1 -- DESIGN.md 3.2).
 // xcd_map: workgroup b takes unit xcd_item(b): the units of one panel (neighbours in the unit list) then run on ONE XCD at
 // about the same time and stage their panel from its L2 instead of each from the fabric.
-template <int THREADS, bool SUMS_DPP>
+// PROBE: the timing-diagnostics instantiation (ehyb_debug_panel_times only); the product's own launches run PROBE = false,
+// where every probe test folds away (they cost six vector instructions of ~70 per chunk).
+template <int THREADS, bool SUMS_DPP, bool PROBE>
 __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __restrict__ items, const int4* __restrict__ units,
                                                                 const double* __restrict__ val,
                                                                 const uint16_t* __restrict__ colf,
                                                                 const uint32_t* __restrict__ chunk,
                                                                 const uint32_t* __restrict__ jump,
                                                                 const double* __restrict__ x,
-                                                                double* __restrict__ partial, int panel_cols, int probe, int xcd_map)
+                                                                double* __restrict__ partial, int panel_cols, int probe_arg, int xcd_map)
 {
+    const int probe = PROBE ? probe_arg : 0;
     // probe (tools/panel_sweep.py, timing diagnostics only, results wrong): 1 no lane sums, 2 no stores,
     // 4 no LDS gather, 8 no panel staging
     extern __shared__ __attribute__((aligned(16))) double win[];
@@ -735,15 +738,19 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
         const bool wide = P->cfg.er_panel_threads ? P->cfg.er_panel_threads == 1024 : H.pb_panel_cols > 9728;
         const bool dpp = P->cfg.er_sums != 2;
         const int xcd = P->cfg.xcd_map != 2 ? 1 : 0;
-#define PB_SCALE(T, D)                                                                                                          \
-    hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D>), dim3(u1), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T))) * 8, st, (const int2*)P->d_pb_items1 + unit_begin, (const int4*)P->d_pb_units1, \
+#define PB_SCALE_P(T, D, PR)                                                                                                    \
+    hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D, PR>), dim3(u1), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T))) * 8, st, (const int2*)P->d_pb_items1 + unit_begin, (const int4*)P->d_pb_units1, \
                        P->d_pb_val, P->d_pb_colf, P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, probe, xcd)
+#define PB_SCALE(T, D)                  \
+    if (probe) PB_SCALE_P(T, D, true);  \
+    else PB_SCALE_P(T, D, false)
         if (wide) {
-            if (dpp) PB_SCALE(1024, true); else PB_SCALE(1024, false);
+            if (dpp) { PB_SCALE(1024, true); } else { PB_SCALE(1024, false); }
         } else {
-            if (dpp) PB_SCALE(512, true); else PB_SCALE(512, false);
+            if (dpp) { PB_SCALE(512, true); } else { PB_SCALE(512, false); }
         }
 #undef PB_SCALE
+#undef PB_SCALE_P
     }
     if ((which & 2) && u2 > 0)
         hipLaunchKernelGGL(ehyb_pb_reduce_kernel<512>, dim3(u2), dim3(512), (size_t)H.pb_rows_max * 8, st, (const int4*)P->d_pb_units2,
@@ -1107,10 +1114,14 @@ int ehyb_plan_upload(ehyb_plan* P)
     LDS_ATTR_T(256)
     LDS_ATTR_T(512)
     LDS_ATTR_T(1024)
-    LDS_ATTR((ehyb_pb_scale_kernel<512, true>))
-    LDS_ATTR((ehyb_pb_scale_kernel<512, false>))
-    LDS_ATTR((ehyb_pb_scale_kernel<1024, true>))
-    LDS_ATTR((ehyb_pb_scale_kernel<1024, false>))
+    LDS_ATTR((ehyb_pb_scale_kernel<512, true, false>))
+    LDS_ATTR((ehyb_pb_scale_kernel<512, false, false>))
+    LDS_ATTR((ehyb_pb_scale_kernel<1024, true, false>))
+    LDS_ATTR((ehyb_pb_scale_kernel<1024, false, false>))
+    LDS_ATTR((ehyb_pb_scale_kernel<512, true, true>))
+    LDS_ATTR((ehyb_pb_scale_kernel<512, false, true>))
+    LDS_ATTR((ehyb_pb_scale_kernel<1024, true, true>))
+    LDS_ATTR((ehyb_pb_scale_kernel<1024, false, true>))
     LDS_ATTR(ehyb_pb_reduce_kernel<512>)
 #undef LDS_ATTR_T
 #undef LDS_ATTR_S

@@ -102,6 +102,9 @@ def test_strong_bench_line_carries_the_step_anatomy(gpu):
     assert vol[0][0][0] == 0 and vol[1][0][1] == 0          # nobody receives from itself
     assert 0 < out["phase1_share_of_local_ms"] < 1 and out["host_us_per_step"] > 0
     assert 0 < out["own_columns_share_of_entries"] < 1
+    # the line carries its own N = 1 point: the same matrix on rank 0's GPU alone, in the same run
+    one = out["single_gpu_same_matrix"]
+    assert one["value"] > 0 and one["nnz"] == c["nnz"] and out["speedup_vs_single_gpu_same_run"] > 0
 
 
 @pytest.mark.parametrize("world", [1, 2])
