@@ -653,6 +653,8 @@ def main():
         span0, span1 = plan.tune(xp, yp)
         tuned = {"api": "ehyb_plan_tune: the heaviest work items on the XCDs measured fastest (stamped launches before the warm-up)",
                  "stamped_launch_span_us_before": round(span0, 2), "stamped_launch_span_us_after": round(span1, 2), "seconds": round(time.time() - t0, 3)}
+        if span0 == 0.0:
+            tuned = None    # nothing to tune: no ELL launch, or more than one round of workgroups
         log(f"[bench] item map tuned for this device: stamped launch {span0:.1f} -> {span1:.1f} us")
 
     def step():

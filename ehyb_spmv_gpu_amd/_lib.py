@@ -73,7 +73,8 @@ class Config(C.Structure):
         ("graphs", C.c_int32),
         ("er_sums", C.c_int32),
         ("er_panel_threads", C.c_int32),
-        ("reserved", C.c_int32 * 29),
+        ("er_queue", C.c_int32),
+        ("reserved", C.c_int32 * 28),
     ]
 
 

@@ -139,6 +139,7 @@ Config resolve_config(const ehyb_config* in)
     c.graphs = z.graphs == 2 ? 2 : 1;
     c.er_sums = z.er_sums == 2 ? 2 : 1;
     c.er_panel_threads = (z.er_panel_threads == 512 || z.er_panel_threads == 1024) ? z.er_panel_threads : 0;
+    c.er_queue = z.er_queue == 2 ? 2 : 1;
     // the automatic choice of the direct shape is for callers that left the window sizing alone: a caller
     // that names a window (lds_doubles / part_rows other than the defaults) gets that window
     if (c.direct == 0 && (c.lds_doubles != EHYB_LDS_MAX_DOUBLES || c.part_rows != round_down(EHYB_LDS_MAX_DOUBLES * 11 / 20, kSlabRows) ||
@@ -207,6 +208,7 @@ void ehyb_config_resolve(const ehyb_config* in, ehyb_config* out)
     r.graphs = c.graphs;
     r.er_sums = c.er_sums;
     r.er_panel_threads = c.er_panel_threads;
+    r.er_queue = c.er_queue;
     *out = r;
 }
 

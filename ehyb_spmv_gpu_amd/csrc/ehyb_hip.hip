@@ -437,20 +437,66 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
                                                                 const uint32_t* __restrict__ chunk,
                                                                 const uint32_t* __restrict__ jump,
                                                                 const double* __restrict__ x,
-                                                                double* __restrict__ partial, int panel_cols, int probe_arg, int xcd_map)
+                                                                double* __restrict__ partial, int panel_cols, int probe_arg, int xcd_map,
+                                                                int* __restrict__ queue, int n_items)
 {
     const int probe = PROBE ? probe_arg : 0;
     // probe (tools/panel_sweep.py, timing diagnostics only, results wrong): 1 no lane sums, 2 no stores,
     // 4 no LDS gather, 8 no panel staging
     extern __shared__ __attribute__((aligned(16))) double win[];
     constexpr int WAVES = THREADS / 64;
-    // one workgroup = one ITEM: a run of units of (nearly) equal total cost, cut by the host (er_panel.cpp); every unit is
-    // a stretch of one panel's entries and stages that panel once
-    const int2 it = items[xcd_map ? xcd_item(blockIdx.x, gridDim.x) : (int)blockIdx.x];
+    // An ITEM = a run of units of (nearly) equal total cost, cut by the host (er_panel.cpp); every unit is a stretch of one
+    // panel's entries and stages that panel once.
+    // queue == null: one workgroup per item (workgroup b takes item xcd_item(b) / b).
+    // queue != null (cfg.er_queue, the default): one RESIDENT round of workgroups, each taking items until none is left.  The
+    // hardware deals workgroups to the 8 XCDs round robin, so with one item per workgroup every XCD gets an eighth of the
+    // work whatever its speed -- and two of the eight XCDs of every box measured stream 8-12 % slower than the fastest, which
+    // the whole launch then waits for.  Here XCD k's workgroups take the items of the k-th contiguous eighth (queue[16 k] =
+    // items taken: the units of one panel still meet in one L2), and a workgroup whose own eighth is used up takes from the
+    // eighth with the most items left.  Exit: every workgroup leaves when every queue is empty (counts only grow); the last
+    // one to leave (queue[128] = workgroups gone) zeroes the counts for the next launch.
+    __shared__ int s_item;
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* scr = win + panel_cols + 64 * wave;  // this wave's 64 piece accumulators, behind the panel (!SUMS_DPP only)
     if (!SUMS_DPP) scr[lane] = 0.0;
+    int my_q = 0;
+    if (queue != nullptr && threadIdx.x == 0) {
+        unsigned xcc;
+        asm volatile("s_getreg_b32 %0, hwreg(HW_REG_XCC_ID)" : "=s"(xcc));
+        my_q = (int)(xcc & 7u);
+    }
+  for (;;) {
+    int2 it;
+    if (queue != nullptr) {
+        __syncthreads();  // every wave is done with the previous item's panel, and with s_item
+        if (threadIdx.x == 0) {
+            int item = -1;
+            for (;;) {
+                const int first = (int)((long long)n_items * my_q / 8), len = (int)((long long)n_items * (my_q + 1) / 8) - first;
+                const int idx = len > 0 ? atomicAdd(&queue[16 * my_q], 1) : len;
+                if (idx < len) {
+                    item = first + idx;
+                    break;
+                }
+                int best = -1, most = 0;  // own eighth used up: the one with the most items left
+                for (int k = 0; k < 8; ++k) {
+                    const int lk = (int)((long long)n_items * (k + 1) / 8) - (int)((long long)n_items * k / 8);
+                    const int left = lk - __hip_atomic_load(&queue[16 * k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    if (left > most) most = left, best = k;
+                }
+                if (best < 0) break;  // nothing left anywhere
+                my_q = best;
+            }
+            s_item = item;
+        }
+        __syncthreads();
+        const int item = s_item;
+        if (item < 0) break;
+        it = items[item];
+    } else {
+        it = items[xcd_map ? xcd_item(blockIdx.x, gridDim.x) : (int)blockIdx.x];
+    }
   for (int un = it.x; un < it.y; ++un) {
     const int4 u = units[un];
     if (un != it.x) __syncthreads();  // every wave is done with the previous panel
@@ -556,6 +602,12 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
         for (int j = 0; j < K; ++j) f0[j] = g0[j], fn[j] = gn[j];
     }
   }
+    if (queue == nullptr) break;
+  }
+    if (queue != nullptr && threadIdx.x == 0 && atomicAdd(&queue[128], 1) == (int)gridDim.x - 1) {
+        for (int k = 0; k < 8; ++k) __hip_atomic_store(&queue[16 * k], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&queue[128], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
 }
 
 // Pass 2: one workgroup per unit {first partial, end partial, first row, rows}.  The row block's
@@ -738,9 +790,14 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
         const bool wide = P->cfg.er_panel_threads ? P->cfg.er_panel_threads == 1024 : H.pb_panel_cols > 9728;
         const bool dpp = P->cfg.er_sums != 2;
         const int xcd = P->cfg.xcd_map != 2 ? 1 : 0;
+        // cfg.er_queue: one resident round of workgroups taking items from per-XCD queues (with stealing) instead of one
+        // workgroup per item; needs the XCD map's contiguous eighths, and more items than workgroups to be worth it
+        const int resident = kNumCU * (wide ? 1 : 2);
+        int* queue = (P->cfg.er_queue != 2 && xcd && u1 > resident) ? P->d_pb_queue : nullptr;
+        const int grid = queue ? resident : u1;
 #define PB_SCALE_P(T, D, PR)                                                                                                    \
-    hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D, PR>), dim3(u1), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T))) * 8, st, (const int2*)P->d_pb_items1 + unit_begin, (const int4*)P->d_pb_units1, \
-                       P->d_pb_val, P->d_pb_colf, P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, probe, xcd)
+    hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D, PR>), dim3(grid), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T))) * 8, st, (const int2*)P->d_pb_items1 + unit_begin, (const int4*)P->d_pb_units1, \
+                       P->d_pb_val, P->d_pb_colf, P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, probe, xcd, queue, u1)
 #define PB_SCALE(T, D)                  \
     if (probe) PB_SCALE_P(T, D, true);  \
     else PB_SCALE_P(T, D, false)
@@ -802,7 +859,7 @@ static void free_device(ehyb_plan* P)
                      (void**)&P->d_slab_meta,  (void**)&P->d_items,     (void**)&P->d_segs,       (void**)&P->d_er_seg_ptr,
                      (void**)&P->d_er_seg_row, (void**)&P->d_er_col,    (void**)&P->d_er_val,     (void**)&P->d_er_blocks,
                      (void**)&P->d_slab_lrow,  (void**)&P->d_pb_val,    (void**)&P->d_pb_colf,    (void**)&P->d_pb_chunk,   (void**)&P->d_pb_jump,
-                     (void**)&P->d_pb_units1,  (void**)&P->d_pb_items1,  (void**)&P->d_pb_row,    (void**)&P->d_pb_units2,  (void**)&P->d_pb_partial,
+                     (void**)&P->d_pb_units1,  (void**)&P->d_pb_items1,  (void**)&P->d_pb_queue,   (void**)&P->d_pb_row,    (void**)&P->d_pb_units2,  (void**)&P->d_pb_partial,
                      (void**)&P->d_item_map,   (void**)&P->d_ell_src,    (void**)&P->d_ell_src2,  (void**)&P->d_er_src,     (void**)&P->d_pb_src};
     for (void** q : ptrs) {
         if (*q) (void)hipFree(*q);
@@ -1086,6 +1143,10 @@ int ehyb_plan_upload(ehyb_plan* P)
         UP(d_pb_items1, pb_items1)
         UP(d_pb_row, pb_row)
         UP(d_pb_units2, pb_units2)
+        if (hipMalloc((void**)&P->d_pb_queue, 256 * sizeof(int)) != hipSuccess || hipMemset(P->d_pb_queue, 0, 256 * sizeof(int)) != hipSuccess) {
+            free_device(P);
+            EHYB_FAIL(EHYB_ERR_HIP, "ehyb_plan_upload: no device memory for the work queues");
+        }
         if (hipMalloc((void**)&P->d_pb_partial, (size_t)std::max<int64_t>(H.pb_partials, 1) * 8) != hipSuccess) {
             free_device(P);
             EHYB_FAIL(EHYB_ERR_HIP, "ehyb_plan_upload: no device memory for %lld partial sums", (long long)H.pb_partials);

@@ -61,6 +61,7 @@ struct Config {
     int graphs;             // 1 on, 2 off
     int er_sums;            // 1 DPP scan, 2 LDS words
     int er_panel_threads;   // 0 automatic, 512, 1024
+    int er_queue;           // 1 per-XCD work queues with stealing, 2 one workgroup per item
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -239,6 +240,7 @@ struct ehyb_plan {
     uint32_t* d_pb_jump = nullptr;
     int32_t* d_pb_units1 = nullptr;
     int32_t* d_pb_items1 = nullptr;
+    int* d_pb_queue = nullptr;          // pass 1 work queues: [16 k] items taken of XCD k's eighth, [128] workgroups gone
     uint16_t* d_pb_row = nullptr;
     int32_t* d_pb_units2 = nullptr;
     double* d_pb_partial = nullptr;  // [pb_partials] written by pass 1, read by pass 2: one multiply at a time per plan

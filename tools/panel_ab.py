@@ -33,6 +33,7 @@ def main():
     ap.add_argument("--xcd", default="1,2", help="cfg.xcd_map: 1 = units of a panel on one XCD, 2 = blockIdx order")
     ap.add_argument("--units1", default="0")
     ap.add_argument("--block-rows", default="2048")
+    ap.add_argument("--queue", default="1", help="cfg.er_queue: 1 = per-XCD work queues with stealing, 2 = one workgroup per item")
     ap.add_argument("--threads1", default="0", help="cfg.er_panel_threads: pass-1 workgroup size (0 automatic, 512, 1024)")
     args = ap.parse_args()
     import bench as B
@@ -58,8 +59,8 @@ def main():
             xd, yd = E.DeviceBuffer(n).upload(E.vector_reorder(x, perm)), E.DeviceBuffer(n)
             for pc, br, u1, th1 in itertools.product(ints(args.panel_cols), ints(args.block_rows), ints(args.units1), ints(args.threads1)):
                 first = True
-                for sums, xcd in itertools.product(ints(args.sums), ints(args.xcd)):
-                    cfg = E.make_config(partitioner=part, fuse_er=2, er_panel_cols=pc, er_block_rows=br, er_units1=u1, er_sums=sums, xcd_map=xcd, er_panel_threads=th1)
+                for sums, xcd, queue in itertools.product(ints(args.sums), ints(args.xcd), ints(args.queue)):
+                    cfg = E.make_config(partitioner=part, fuse_er=2, er_panel_cols=pc, er_block_rows=br, er_units1=u1, er_sums=sums, xcd_map=xcd, er_panel_threads=th1, er_queue=queue)
                     t0 = time.time()
                     plan = E.Plan(m, cfg)
                     t_plan = time.time() - t0
@@ -67,7 +68,7 @@ def main():
                     r = plan.bench(xd.ptr, yd.ptr, warmup=10, iters=args.iters)
                     bad, worst = O.check_tolerance(E.vector_recover(yd.download(), perm), y_ref, scale)
                     ms = r["ms_total"] / args.iters
-                    out = {"workload": wl, "order": part, "panel_cols": pc, "block_rows": br, "units1_aim": u1, "threads1": th1, "er_sums": sums, "xcd_map": xcd,
+                    out = {"workload": wl, "order": part, "panel_cols": pc, "block_rows": br, "units1_aim": u1, "threads1": th1, "er_sums": sums, "xcd_map": xcd, "er_queue": queue,
                            "nnz": nnz, "nnz_ell": st["nnz_ell"], "partials": st["er_partials"],
                            "items1": len(plan.array("pb_items1")) // 2 if first else None, "units1": len(plan.array("pb_units1")) // 4 if first else None, "units2": len(plan.array("pb_units2")) // 4 if first else None,
                            "us_spmv": round(ms * 1e3, 1), "GFLOPs": round(2.0 * nnz / ms / 1e6, 1), "us_ell": round(r["ms_ell_avg"] * 1e3, 1),
