@@ -455,7 +455,9 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
     // items taken: the units of one panel still meet in one L2), and a workgroup whose own eighth is used up takes from the
     // eighth with the most items left.  Exit: every workgroup leaves when every queue is empty (counts only grow); the last
     // one to leave (queue[128] = workgroups gone) zeroes the counts for the next launch.
-    __shared__ int s_item;
+    // (the item handed from thread 0 to the workgroup: one word behind the panel and the piece accumulators, in the dynamic
+    // allocation -- a static __shared__ word on top of a 160 KiB dynamic limit is refused by hipFuncSetAttribute)
+    int& s_item = *reinterpret_cast<int*>(win + panel_cols + (SUMS_DPP ? 0 : THREADS));
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* scr = win + panel_cols + 64 * wave;  // this wave's 64 piece accumulators, behind the panel (!SUMS_DPP only)
@@ -796,7 +798,7 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
         int* queue = (P->cfg.er_queue != 2 && xcd && u1 > resident) ? P->d_pb_queue : nullptr;
         const int grid = queue ? resident : u1;
 #define PB_SCALE_P(T, D, PR)                                                                                                    \
-    hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D, PR>), dim3(grid), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T))) * 8, st, (const int2*)P->d_pb_items1 + unit_begin, (const int4*)P->d_pb_units1, \
+    hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D, PR>), dim3(grid), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T)) + 1) * 8, st, (const int2*)P->d_pb_items1 + unit_begin, (const int4*)P->d_pb_units1, \
                        P->d_pb_val, P->d_pb_colf, P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, probe, xcd, queue, u1)
 #define PB_SCALE(T, D)                  \
     if (probe) PB_SCALE_P(T, D, true);  \
