@@ -448,7 +448,7 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
     // An ITEM = a run of units of (nearly) equal total cost, cut by the host (er_panel.cpp); every unit is a stretch of one
     // panel's entries and stages that panel once.
     // queue == null: one workgroup per item (workgroup b takes item xcd_item(b) / b).
-    // queue != null (cfg.er_queue, the default): one RESIDENT round of workgroups, each taking items until none is left.  The
+    // queue != null (cfg.er_queue = 1, an A/B arm -- see DESIGN.md 3.2): one RESIDENT round of workgroups, each taking items until none is left.  The
     // hardware deals workgroups to the 8 XCDs round robin, so with one item per workgroup every XCD gets an eighth of the
     // work whatever its speed -- and two of the eight XCDs of every box measured stream 8-12 % slower than the fastest, which
     // the whole launch then waits for.  Here XCD k's workgroups take the items of the k-th contiguous eighth (queue[16 k] =
@@ -795,7 +795,7 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
         // cfg.er_queue: one resident round of workgroups taking items from per-XCD queues (with stealing) instead of one
         // workgroup per item; needs the XCD map's contiguous eighths, and more items than workgroups to be worth it
         const int resident = kNumCU * (wide ? 1 : 2);
-        int* queue = (P->cfg.er_queue != 2 && xcd && u1 > resident) ? P->d_pb_queue : nullptr;
+        int* queue = (P->cfg.er_queue == 1 && xcd && u1 > resident) ? P->d_pb_queue : nullptr;
         const int grid = queue ? resident : u1;
 #define PB_SCALE_P(T, D, PR)                                                                                                    \
     hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D, PR>), dim3(grid), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T)) + 1) * 8, st, (const int2*)P->d_pb_items1 + unit_begin, (const int4*)P->d_pb_units1, \

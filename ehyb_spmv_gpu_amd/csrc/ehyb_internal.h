@@ -61,7 +61,7 @@ struct Config {
     int graphs;             // 1 on, 2 off
     int er_sums;            // 1 DPP scan, 2 LDS words
     int er_panel_threads;   // 0 automatic, 512, 1024
-    int er_queue;           // 1 per-XCD work queues with stealing, 2 one workgroup per item
+    int er_queue;           // 1 per-XCD work queues with stealing (A/B arm), 2 one workgroup per item (default)
 };
 Config resolve_config(const ehyb_config* cfg);
 

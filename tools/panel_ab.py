@@ -33,7 +33,7 @@ def main():
     ap.add_argument("--xcd", default="1,2", help="cfg.xcd_map: 1 = units of a panel on one XCD, 2 = blockIdx order")
     ap.add_argument("--units1", default="0")
     ap.add_argument("--block-rows", default="2048")
-    ap.add_argument("--queue", default="1", help="cfg.er_queue: 1 = per-XCD work queues with stealing, 2 = one workgroup per item")
+    ap.add_argument("--queue", default="2", help="cfg.er_queue: 1 = per-XCD work queues with stealing, 2 = one workgroup per item")
     ap.add_argument("--threads1", default="0", help="cfg.er_panel_threads: pass-1 workgroup size (0 automatic, 512, 1024)")
     args = ap.parse_args()
     import bench as B
