@@ -314,11 +314,13 @@ class HaloExchange:
         self.ghost_views = [x_ext[int(segs[k + 1]):int(segs[k + 1]) + sum(self.recv_counts[k])] for k in range(local.chunks)] if local.world > 1 else []
         self.send_views = [self.send_buf[int(local.send_first[k]):int(local.send_first[k + 1])] for k in range(local.chunks)] if local.world > 1 else []
         self.lib = H._lib.load()
+        self._pack_args = (C.c_void_p(self.x_ext.data_ptr()), C.c_void_p(self.send_idx.data_ptr()), C.c_void_p(self.send_buf.data_ptr()), len(local.send_idx))
 
     def pack(self, compute_stream=0, comm_stream=0):
         """send_buf[i] = x[send_idx[i]] on compute_stream (one launch for all chunks); comm_stream then waits for it."""
-        H._check(self.lib.ehyb_step_pack(C.c_void_p(self.x_ext.data_ptr()), C.c_void_p(self.send_idx.data_ptr()), C.c_void_p(self.send_buf.data_ptr()),
-                                         len(self.L.send_idx), C.c_void_p(compute_stream), C.c_void_p(comm_stream)), "ehyb_step_pack")
+        rc = self.lib.ehyb_step_pack(self._pack_args[0], self._pack_args[1], self._pack_args[2], self._pack_args[3], compute_stream, comm_stream)
+        if rc:
+            H._check(rc, "ehyb_step_pack")
 
     def transfer(self, k):
         L, dist, torch = self.L, self.dist, self.torch
@@ -374,14 +376,17 @@ class HaloSpmv:
         # a plan that multiplies in one launch (inline residual / direct shape) has no parts: plain steps only
         self.has_parts = not (st["er_inline"] > 0)
         self.lib = H._lib.load()
+        self._xp, self._yp = C.c_void_p(self.x.data_ptr()), C.c_void_p(self.y.data_ptr())
 
     def set_x_local(self, x_local):
         """x_local: this rank's x segment in global label order."""
         self.x[:self.L.n_loc].copy_(self.torch.from_numpy(self.L.x_to_plan(x_local)))
 
     def _part(self, cur, comm, wait, s0, s1, flags):
-        H._check(self.lib.ehyb_step_part(self.plan.h, C.c_void_p(self.x.data_ptr()), C.c_void_p(self.y.data_ptr()), C.c_void_p(cur), C.c_void_p(comm),
-                                         wait, s0, s1, flags), "ehyb_step_part")
+        # (x and y never move: their pointers are wrapped once -- the host side of a step is as dear as the device side)
+        rc = self.lib.ehyb_step_part(self.plan.h, self._xp, self._yp, cur, comm, wait, s0, s1, flags)
+        if rc:
+            H._check(rc, "ehyb_step_part")
 
     def step(self):
         torch = self.torch

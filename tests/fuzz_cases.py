@@ -36,9 +36,13 @@ def random_config_kwargs(rng):
                 er_seg_len=int(rng.choice([16, 64, 1024])), items_per_cu=int(rng.choice([0, 1, 2, 4])),
                 col_sharing=int(rng.choice([1, 2])), sym_pairs=int(rng.choice([0, 1])) if mode == 2 else 0,
                 cap_split=int(rng.choice([1, 2])), hub_rule=int(rng.choice([1, 2])),
-                er_mode=int(rng.choice([0, 1, 2])), er_panel_cols=int(rng.choice([256, 1024, 8192])),
+                er_mode=int(rng.choice([0, 1, 2])), er_panel_cols=int(rng.choice([256, 1024, 8192, 16384])),
                 er_block_rows=int(rng.choice([64, 1000, 8192])), direct=int(rng.choice([0, 0, 1, 2])),
-                ell_prune=int(rng.choice([1, 1, 2])))
+                ell_prune=int(rng.choice([1, 1, 2])),
+                # round 3: row order, how pass 1 of the panel form adds up, finds its work and is launched
+                partitioner=int(rng.choice([0, 0, 1, 4])), er_sums=int(rng.choice([1, 1, 2])), er_queue=int(rng.choice([1, 2])),
+                xcd_map=int(rng.choice([1, 2])), er_panel_threads=int(rng.choice([0, 512, 1024])), er_units1=int(rng.choice([0, 1, 7, 300])),
+                er_units2=int(rng.choice([0, 5])), graph_compress=int(rng.choice([0, 1, 2])))
 
 
 def build(E, O, seed):

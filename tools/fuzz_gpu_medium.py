@@ -14,7 +14,10 @@ sys.path.insert(0, ROOT)
 
 
 def pick(rng):
-    kind = rng.choice(["fem3d", "fem3d_graded", "rmat", "kkt3d", "stencil2d", "banded"])
+    kind = rng.choice(["fem3d", "fem3d_graded", "rmat", "kkt3d", "stencil2d", "banded", "mesh3d"])
+    if kind == "mesh3d":
+        nodes = int(rng.integers(8000, 200000))
+        return kind, (nodes * 3, 3, int(rng.integers(6, 26)), int(rng.choice([0, 1500, 2500])), int(rng.integers(1, 99)))
     if kind == "fem3d":
         nodes = int(rng.integers(8000, 250000))
         nx = int(rng.integers(12, 60))
@@ -45,13 +48,15 @@ def main():
     for seed in range(first, first + count):
         rng = np.random.default_rng(seed)
         kind, args = pick(rng)
-        sym_ok = kind in ("fem3d", "fem3d_graded", "kkt3d", "stencil2d")
+        sym_ok = kind in ("fem3d", "fem3d_graded", "kkt3d", "stencil2d", "mesh3d")
         kw = dict(lds_doubles=int(rng.choice([0, 0, 4096, 10240, 20480])), threads=int(rng.choice([0, 256, 512, 1024])),
                   er_mode=int(rng.choice([0, 1, 2])), er_panel_cols=int(rng.choice([0, 1024, 4096, 16384])),
                   er_block_rows=int(rng.choice([0, 512, 8192])), direct=int(rng.choice([0, 0, 2])), ell_prune=int(rng.choice([1, 2])),
                   col_sharing=int(rng.choice([1, 2])), hub_rule=int(rng.choice([1, 2])), fuse_er=int(rng.choice([0, 0, 2])),
-                  partitioner=int(rng.choice([0, 0, 1])), sym_pairs=int(rng.integers(0, 2)) if sym_ok or rng.random() < 0.2 else 0,
-                  window_mode=int(rng.choice([0, 0, 0, 1])))
+                  partitioner=int(rng.choice([0, 0, 1, 4])), sym_pairs=int(rng.integers(0, 2)) if sym_ok or rng.random() < 0.2 else 0,
+                  window_mode=int(rng.choice([0, 0, 0, 1])),
+                  er_sums=int(rng.choice([0, 0, 2])), er_queue=int(rng.choice([0, 1])), xcd_map=int(rng.choice([0, 2])),
+                  er_panel_threads=int(rng.choice([0, 512, 1024])), er_units1=int(rng.choice([0, 0, 100, 5000])), graph_compress=int(rng.choice([0, 1, 2])))
         if kw["window_mode"] == 1:
             kw["sym_pairs"] = 0
         kw = {k: v for k, v in kw.items() if v}
