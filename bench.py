@@ -333,7 +333,7 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     if not args.no_single_gpu_anchor:
         if rank == 0:
             t0 = time.time()
-            kw1 = {k: int(getattr(cfg, k)) for k in ("host_threads",)}
+            kw1 = {"host_threads": owned_cpus()}   # the other ranks wait: every CPU the job owns builds this one plan
             single = side_arm("single-GPU anchor", lambda: one_gpu_case(E, O, np, args.workload, symmetric and symmetric_storage_pays(gen, gargs), kw1,
                                                                         min(args.steps, 50), min(args.warmup, 5), log, want_parity=False), log)
             log(f"[bench] the same matrix on one GPU: {single.get('value')} GFLOP/s, {single.get('ms_per_step')} ms ({time.time() - t0:.1f}s incl. its pre-step)")
