@@ -137,6 +137,7 @@ SIGNATURES = {
     "ehyb_gather": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "ehyb_step_pack": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp]),
     "ehyb_step_part": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
+    "ehyb_halo_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp]),
     "ehyb_spmv_bench": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _dp, _dp, _dp]),
     "ehyb_spmv_host": (C.c_int, [_vp, _dp, _dp, C.c_int]),
     "ehyb_plan_set_values": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, _vp]),

@@ -974,6 +974,22 @@ int ehyb_debug_ell_stamps(ehyb_plan* P, const double* x, double* y, unsigned lon
     return rc;
 }
 
+int ehyb_halo_step(ehyb_plan* P, const double* x, double* y, const int32_t* send_idx, double* send_buf, int64_t n_send, int n_chunks,
+                   ehyb_exchange_fn exchange, void* user, void* compute_stream, void* comm_stream)
+{
+    if (!P || !exchange || n_chunks < 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_halo_step: bad arguments");
+    int n_segs = 1;
+    (void)ehyb_plan_col_segs(P, &n_segs);
+    if (n_segs != n_chunks + 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_halo_step: the plan has %d column segments, %d chunks need %d", n_segs, n_chunks, n_chunks + 1);
+    int rc = ehyb_step_pack(x, send_idx, send_buf, n_send, compute_stream, comm_stream);
+    if (rc == EHYB_OK) rc = ehyb_step_part(P, x, y, compute_stream, comm_stream, 0, 0, 1, EHYB_PART_FIRST);
+    for (int k = 0; k < n_chunks && rc == EHYB_OK; ++k) {
+        if (exchange(k, comm_stream, user) != 0) EHYB_FAIL(EHYB_ERR_STATE, "ehyb_halo_step: the caller's exchange of chunk %d failed", k);
+        rc = ehyb_step_part(P, x, y, compute_stream, comm_stream, 1, 1 + k, 2 + k, k == n_chunks - 1 ? EHYB_PART_LAST : 0);
+    }
+    return rc;
+}
+
 // Tuning of the item -> workgroup map on the device the plan lives on (see ehyb.h).
 int ehyb_plan_tune(ehyb_plan* P, const double* x, double* y, int reps, double* span_before_us, double* span_after_us)
 {

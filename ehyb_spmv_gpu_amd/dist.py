@@ -361,11 +361,15 @@ class HaloSpmv:
     collectives on a side stream.  pipelined=False: pack, every chunk, then the whole multiply in one call (the plain step
     the pipelined one is checked against)."""
 
-    def __init__(self, local, device, overlap=True, stage_on_cpu=False, mode="a2a"):
+    def __init__(self, local, device, overlap=True, stage_on_cpu=False, mode="a2a", c_step=False):
+        """c_step: the pipelined step through ONE C call (ehyb_halo_step) that calls back for every collective -- what a
+        C caller with its own RCCL communicator would use; here the callback is Python, so it saves nothing and serves as
+        the test of that entry point."""
         import torch
 
         self.torch = torch
         self.L = local
+        self.c_step = c_step
         self.plan = local.plan()
         self.x = torch.zeros(local.n_loc + local.n_ext, dtype=torch.float64, device=device)
         self.y = torch.zeros(local.n_loc, dtype=torch.float64, device=device)
@@ -405,6 +409,20 @@ class HaloSpmv:
             return
         comm = self.comm_stream.cuda_stream
         K = L.chunks
+        if self.c_step:
+            if not hasattr(self, "_cb"):
+                def exchange(k, _comm, _user):
+                    try:
+                        self.halo.transfer(k)
+                        return 0
+                    except Exception:          # noqa: BLE001  (reported by the C side as EHYB_ERR_STATE)
+                        return 1
+                self._cb = C.CFUNCTYPE(C.c_int, C.c_int, C.c_void_p, C.c_void_p)(exchange)
+            a = self.halo._pack_args
+            with torch.cuda.stream(self.comm_stream):
+                H._check(self.lib.ehyb_halo_step(self.plan.h, self._xp, self._yp, a[1], a[2], a[3], K, C.cast(self._cb, C.c_void_p), None, cur, comm),
+                         "ehyb_halo_step")
+            return
         self.halo.pack(cur, comm)                      # comm waits for the packed send buffer
         self._part(cur, comm, 0, 0, 1, 1)              # own columns: ELL + their panels, while chunk 0 travels
         with torch.cuda.stream(self.comm_stream):

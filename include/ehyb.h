@@ -443,6 +443,17 @@ int ehyb_gather(const double* src_dev, const int32_t* idx_dev, double* dst_dev, 
 int ehyb_step_pack(const double* x_dev, const int32_t* idx_dev, double* send_buf_dev, int64_t n, void* compute_stream, void* comm_stream);
 int ehyb_step_part(ehyb_plan* plan, const double* x_dev, double* y_dev, void* compute_stream, void* comm_stream, int wait_comm,
                    int seg_begin, int seg_end, int flags);
+/*
+ * The whole exchange step as ONE call, for a caller that issues its collectives from C (RCCL: ncclGroupStart / ncclSend /
+ * ncclRecv / ncclGroupEnd) -- no reference counterpart.  The plan was made by ehyb_plan_create_host_segs with 1 + n_chunks
+ * column segments (own columns, then one per chunk).  Sequence: ehyb_step_pack; own columns (EHYB_PART_FIRST); then for
+ * k = 0 .. n_chunks-1: exchange(k, comm_stream, user) -- the caller ENQUEUES on comm_stream the collective that fills chunk k's
+ * ghost columns of x_dev (0 = ok; anything else aborts the step with EHYB_ERR_STATE) -- and the panels of chunk k on
+ * compute_stream behind it, the last one with EHYB_PART_LAST.  Everything asynchronous.
+ */
+typedef int (*ehyb_exchange_fn)(int chunk, void* comm_stream, void* user);
+int ehyb_halo_step(ehyb_plan* plan, const double* x_dev, double* y_dev, const int32_t* send_idx_dev, double* send_buf_dev, int64_t n_send,
+                   int n_chunks, ehyb_exchange_fn exchange, void* user, void* compute_stream, void* comm_stream);
 
 /*
  * Timed loop on device-resident vectors: `warmup` untimed multiplies, then `iters`

@@ -86,7 +86,7 @@ def test_pipelined_step_equals_plain_step(gpu, world):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "pipeline_worker.py")]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ), cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    assert "PIPE_OK" in p.stdout and p.stdout.count("PIPE_CASE") == 4, p.stdout[-2000:]
+    assert "PIPE_OK" in p.stdout and p.stdout.count("PIPE_CASE") == 5, p.stdout[-2000:]
 
 
 def test_strong_bench_line_carries_the_step_anatomy(gpu):
