@@ -867,6 +867,9 @@ static void free_device(ehyb_plan* P)
         if (*q) (void)hipFree(*q);
         *q = nullptr;
     }
+    for (int32_t* q : P->retired_item_maps) (void)hipFree(q);
+    P->retired_item_maps.clear();
+    P->item_map.clear();
     P->uploaded = false;
 }
 
@@ -1090,7 +1093,7 @@ int ehyb_plan_tune(ehyb_plan* P, const double* x, double* y, int reps, double* s
                 (void)hipFree(dm);
                 span1 = span0;
             } else if (old) {
-                (void)hipFree(old);
+                P->retired_item_maps.push_back(old);  // a hipGraph captured earlier may still name it: freed with the plan
             }
         } else if (dm) {
             (void)hipFree(dm);

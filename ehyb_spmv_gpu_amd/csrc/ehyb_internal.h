@@ -228,6 +228,7 @@ struct ehyb_plan {
     int32_t* d_items = nullptr;
     int32_t* d_item_map = nullptr;      // ehyb_plan_tune: item of every ELL workgroup (null: the built-in order)
     std::vector<int32_t> item_map;      // its host copy (a property of the device the plan was tuned on: not saved)
+    std::vector<int32_t*> retired_item_maps;  // maps a later ehyb_plan_tune replaced: kept until the plan goes (captured graphs)
     int64_t* d_er_seg_ptr = nullptr;
     int32_t* d_er_seg_row = nullptr;
     int32_t* d_er_col = nullptr;

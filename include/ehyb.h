@@ -412,7 +412,9 @@ int ehyb_spmv_phase(ehyb_plan* plan, const double* x_dev, double* y_dev, void* s
  * and so on down; it keeps the new map only if the stamped launch got shorter.  *span_before_us / *span_after_us (may be
  * NULL): launch span before and with the map the plan ends with.  Synchronous (null stream); y is overwritten with A*x.
  * No-op for plans whose ELL launch needs more than one round of workgroups, for the direct shape and for plans without
- * an ELL launch.  spmvGPuEHYB does it during its warm-up; plan-API callers decide for themselves.
+ * an ELL launch.  spmvGPuEHYB does it during its warm-up; plan-API callers decide for themselves -- before they capture
+ * multiplies of the plan into a hipGraph (a captured launch keeps the map it was captured with; replaced maps stay
+ * allocated until the plan is destroyed, so such a graph stays valid).
  */
 int ehyb_plan_tune(ehyb_plan* plan, const double* x_dev, double* y_dev, int reps, double* span_before_us, double* span_after_us);
 
