@@ -148,3 +148,37 @@ def test_rows_of_partitions_without_a_window_are_assigned_by_pass_2(E, O, mixed)
         assert st["n_items"] > 1 and len(segs) > 0 and np.all(wl[segs[:, 0]] > 0) and st["nnz_ell"] * 4 >= st["nnz"]
     else:
         assert st["nnz_ell"] == 0 and st["n_items"] == 1 and len(segs) == 0
+
+
+def test_column_segments_cut_the_panels_and_the_items(E, O):
+    """ehyb_plan_create_host_segs (multi-GPU: the ghost columns arrive segment by segment): a panel never straddles a
+    segment boundary, the pass-1 items of a segment are a run of the item list, every entry is still multiplied once
+    (oracle walk), and malformed segment lists are refused."""
+    import ctypes as C
+
+    cfg = E.make_config(er_mode=2, fuse_er=2, er_panel_cols=1024, direct=2, partitioner=E.EHYB_PART_DEGREE)
+    c = Case(E, O, "rmat", (15, 1 << 18, 4), cfg)
+    n = c.n
+    segs = np.array([0, 4098, 4098, 20000, n], dtype=np.int32)      # an empty segment among them; starts even
+    plan = E.Plan(c.m, cfg, upload=False, col_segs=segs)
+    assert plan.col_segs == 4 and np.array_equal(plan.array("col_seg_first"), segs)
+    u1 = plan.array("pb_units1").reshape(-1, 4)
+    it1 = plan.array("pb_items1").reshape(-1, 2)
+    si = plan.array("pb_seg_item")
+    assert len(si) == 5 and si[0] == 0 and si[-1] == len(it1) and si[1] < si[-1] and si[2] == si[1]
+    for s in range(4):
+        if si[s + 1] > si[s]:
+            uu = u1[it1[si[s], 0]:it1[si[s + 1] - 1, 1]]
+            assert np.all(uu[:, 0] >= segs[s]) and np.all(uu[:, 0] + uu[:, 1] <= segs[s + 1])
+            assert np.all((uu[:, 0] - segs[s]) % 1024 == 0)           # panels restart at the segment's first column
+    y, written = O.walk_plan(plan, c.xp)
+    assert written[:n].min() == 1 and c.check(y)[0] == 0
+    # the same plan without segments holds the same entries in (possibly) fewer panels
+    whole = E.Plan(c.m, cfg, upload=False)
+    assert whole.stats["nnz_er"] == plan.stats["nnz_er"] and whole.stats["er_partials"] <= plan.stats["er_partials"]
+    lib = E.host._lib.load()
+    h = C.c_void_p()
+    for bad in ([0, 4097, n], [0, 9000, 4096, n], [2, n], [0, n - 2]):
+        arr = np.asarray(bad, dtype=np.int32)
+        assert lib.ehyb_plan_create_host_segs(C.byref(c.m.c), 0, n, C.byref(cfg), len(arr) - 1, arr.ctypes.data_as(C.POINTER(C.c_int)), C.byref(h)) == 1
+        assert not h.value
