@@ -223,8 +223,9 @@ class RankLocalMatrix:
         pos = np.arange(self.n_ghost) - np.repeat(first_of, per_owner)       # rank inside the owner's list
         frac = (pos + 0.5) / np.maximum(1, np.repeat(per_owner, per_owner))
         chunk_sorted = np.searchsorted(edges, frac, side="right")            # chunk of every slot, in by_owner order
-        order = by_owner[np.lexsort((np.arange(self.n_ghost), chunk_sorted))]  # stable: chunk major, the rest as it was
-        chunk_of = chunk_sorted[np.lexsort((np.arange(self.n_ghost), chunk_sorted))]
+        by_chunk = np.argsort(chunk_sorted, kind="stable")                    # chunk major, the rest as it was
+        order = by_owner[by_chunk]
+        chunk_of = chunk_sorted[by_chunk]
         self.ghost_cols = gcols[order]                                       # global label of every slot, slot order
         owner_s = owner[order]
         self.chunks = chunks
@@ -260,10 +261,7 @@ class RankLocalMatrix:
             # every owner tells me where, in ITS plan order, the columns I asked for sit: the reverse all-to-all
             places, _ = alltoallv(self.send_idx.astype(np.int64), self.send_counts[0], group)
             # ghost column of remote entry j of owner p: behind my padded segment, inside p's segment of the gathered buffer
-            own_first = np.concatenate(([0], np.cumsum(self.recv_counts[0])))[:-1]
-            p_of = owner_s
-            slot_col = self.n_loc + (self.seg_len - self.n_loc) + p_of * self.seg_len + places
-            del own_first
+            slot_col = self.n_loc + (self.seg_len - self.n_loc) + owner_s * self.seg_len + places
             self.n_ext = (self.seg_len - self.n_loc) + world * self.seg_len
             self.col_segs = None
             self.m.append_ghosts(self.n_ext, self.perm[I[off] - r0], (slot_col - self.n_loc)[slot_of_entry[inv]], V[off])
