@@ -74,7 +74,8 @@ class Config(C.Structure):
         ("er_sums", C.c_int32),
         ("er_panel_threads", C.c_int32),
         ("er_queue", C.c_int32),
-        ("reserved", C.c_int32 * 28),
+        ("symbolic", C.c_int32),
+        ("reserved", C.c_int32 * 27),
     ]
 
 
@@ -123,6 +124,7 @@ SIGNATURES = {
     "ehyb_plan_create_host_segs": (C.c_int, [_mp, C.c_int, C.c_int, _cfgp, C.c_int, _ip, _P(_vp)]),
     "ehyb_plan_upload": (C.c_int, [_vp]),
     "ehyb_plan_create": (C.c_int, [_mp, _cfgp, _P(_vp)]),
+    "ehyb_plan_create_segs": (C.c_int, [_mp, C.c_int, C.c_int, _cfgp, C.c_int, _ip, _P(_vp)]),
     "ehyb_plan_destroy": (None, [_vp]),
     "ehyb_matrix_key": (C.c_uint64, [_mp]),
     "ehyb_plan_save": (C.c_int, [_vp, _ip, C.c_uint64, C.c_char_p]),

@@ -145,8 +145,10 @@ extern "C" int ehyb_plan_set_values(ehyb_plan* P, const double* values, int64_t 
     if (!P->d_ell_src && (rc = to_device(&P->d_ell_src, H.ell_src.data(), H.ell_src.size())) != EHYB_OK) return rc;
     if (H.sym && !P->d_ell_src2 && (rc = to_device(&P->d_ell_src2, H.ell_src2.data(), H.ell_src2.size())) != EHYB_OK) return rc;
     if (P->d_er_val && !P->d_er_src && (rc = to_device(&P->d_er_src, H.er_src.data(), H.er_src.size())) != EHYB_OK) return rc;
+    // (a panel form built on the device left its slot map there: H.pb_host_missing)
+    if (P->d_pb_val && H.pb_host_missing && !P->d_pb_src) EHYB_FAIL(EHYB_ERR_STATE, "ehyb_plan_set_values: the device-built panel form kept no slot map");
     if (P->d_pb_val && !P->d_pb_src && (rc = to_device(&P->d_pb_src, H.pb_src.data(), H.pb_src.size())) != EHYB_OK) return rc;
-    if ((P->d_er_val && H.er_src.size() != H.er_val.size()) || (P->d_pb_val && H.pb_src.size() != H.pb_val.size()))
+    if ((P->d_er_val && H.er_src.size() != H.er_val.size()) || (P->d_pb_val && !H.pb_host_missing && H.pb_src.size() != H.pb_val.size()))
         EHYB_FAIL(EHYB_ERR_INTERNAL, "ehyb_plan_set_values: slot maps do not match the value streams");
 
     Temp T;
@@ -182,7 +184,7 @@ extern "C" int ehyb_plan_set_values(ehyb_plan* P, const double* values, int64_t 
         long long n;
     } jobs[3] = {{P->d_ell_val, P->d_ell_src, (long long)H.ell_src.size()},
                  {P->d_er_val, P->d_er_src, P->d_er_val ? (long long)H.er_src.size() : 0},
-                 {P->d_pb_val, P->d_pb_src, P->d_pb_val ? (long long)H.pb_src.size() : 0}};
+                 {P->d_pb_val, P->d_pb_src, P->d_pb_val ? (long long)H.pb_padded : 0}};
     for (const Job& j : jobs) {
         if (!j.dst || j.n == 0) continue;
         hipLaunchKernelGGL(ehyb_fill_kernel, dim3(grid_for(j.n)), dim3(kFillThreads), 0, st, j.dst, j.src, j.n, dV, dOrder);

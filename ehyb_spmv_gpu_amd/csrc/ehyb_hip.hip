@@ -842,7 +842,7 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
 static int launch_er(ehyb_plan* P, const double* x, double* y, hipStream_t st)
 {
     const HostLayout& H = P->host;
-    if (H.er_bins[3] == 0) return EHYB_OK;
+    if (H.er_bins[3] == 0 && !H.er_panel) return EHYB_OK;  // (er_bins[3] = CSR segments: a device-built panel form has none)
     if (H.er_panel) {  // panel form: scale (x panels in LDS) then reduce (y blocks in LDS)
         return launch_panel(P, x, y, st, 0, 3);  // (probe arms only through ehyb_debug_panel_times)
     }
@@ -1161,6 +1161,7 @@ int ehyb_plan_upload(ehyb_plan* P)
         EHYB_FAIL(EHYB_ERR_NO_DEVICE, "ehyb_plan_upload: no HIP device visible (the EHYB multiply has no CPU fallback)");
     HIP_TRY(hipGetDevice(&P->device));
     const HostLayout& H = P->host;
+    if (H.deferred.pending) EHYB_FAIL(EHYB_ERR_STATE, "ehyb_plan_upload: the plan's panel form was left to the device and never built");
     int rc;
 #define UP(dst, src)                           \
     if ((rc = upload(&P->dst, H.src)) != EHYB_OK) { \
@@ -1177,13 +1178,15 @@ int ehyb_plan_upload(ehyb_plan* P)
     UP(d_slab_lrow, slab_lrow)
     if (H.er_panel) {
         // the residual launch runs the panel form: the CSR segments stay on the host
-        UP(d_pb_val, pb_val)
-        UP(d_pb_colf, pb_colf)
-        UP(d_pb_chunk, pb_chunk)
-        UP(d_pb_jump, pb_jump)
+        if (!H.pb_host_missing) {  // (else: built where they are, er_panel_dev.hip)
+            UP(d_pb_val, pb_val)
+            UP(d_pb_colf, pb_colf)
+            UP(d_pb_chunk, pb_chunk)
+            UP(d_pb_jump, pb_jump)
+            UP(d_pb_row, pb_row)
+        }
         UP(d_pb_units1, pb_units1)
         UP(d_pb_items1, pb_items1)
-        UP(d_pb_row, pb_row)
         UP(d_pb_units2, pb_units2)
         if (hipMalloc((void**)&P->d_pb_queue, 256 * sizeof(int)) != hipSuccess || hipMemset(P->d_pb_queue, 0, 256 * sizeof(int)) != hipSuccess) {
             free_device(P);
@@ -1278,7 +1281,7 @@ int ehyb_spmv_part(ehyb_plan* P, const double* x, double* y, void* stream, int s
     hipStream_t st = (hipStream_t)stream;
     int rc = EHYB_OK;
     if (flags & EHYB_PART_FIRST) rc = launch_ell(P, x, y, st, false);
-    if (rc != EHYB_OK || H.er_bins[3] == 0) return rc;
+    if (rc != EHYB_OK || (H.er_bins[3] == 0 && !H.er_panel)) return rc;
     if (!H.er_panel) return (flags & EHYB_PART_LAST) ? launch_er(P, x, y, st) : EHYB_OK;  // CSR residual: one launch, needs all of x
     if (seg_end > seg_begin) {
         const int ub = H.pb_seg_item.empty() ? 0 : H.pb_seg_item[(size_t)seg_begin];
@@ -1462,13 +1465,36 @@ int ehyb_spmv_host(ehyb_plan* P, const double* x_host, double* y_host, int iters
 int ehyb_plan_create(const matrixCOO* m, const ehyb_config* cfg, ehyb_plan** plan)
 {
     if (!m) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_create: null matrix");
-    int rc = ehyb_plan_create_host(m, 0, m->dimension, cfg, plan);
+    return ehyb_plan_create_segs(m, 0, m->dimension, cfg, 0, nullptr, plan);
+}
+
+// Build + upload.  What the device can build is left to it (cfg.symbolic): the host lays out the windows and leaves a
+// panel-form residual as the entries in row order; the device deals them out (er_panel_dev.hip).
+int ehyb_plan_create_segs(const matrixCOO* m, int row_begin, int row_end, const ehyb_config* cfg, int n_col_segs, const int* col_seg_first,
+                          ehyb_plan** plan)
+{
+    clear_error();
+    if (!plan) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_create: null output");
+    *plan = nullptr;
+    int count = 0;
+    if (hipGetDeviceCount(&count) != hipSuccess || count < 1)
+        EHYB_FAIL(EHYB_ERR_NO_DEVICE, "ehyb_plan_create: no HIP device visible (the EHYB multiply has no CPU fallback)");
+    const double t0 = wall_seconds();
+    int rc = create_host_plan(m, row_begin, row_end, cfg, n_col_segs, col_seg_first, true, plan);
     if (rc != EHYB_OK) return rc;
-    rc = ehyb_plan_upload(*plan);
+    const double t1 = wall_seconds();
+    const bool on_device = (*plan)->host.deferred.pending;
+    if (on_device) rc = build_panel_on_device(*plan);
+    const double t2 = wall_seconds();
+    if (rc == EHYB_OK) rc = ehyb_plan_upload(*plan);
     if (rc != EHYB_OK) {
         ehyb_plan_destroy(*plan);
         *plan = nullptr;
+        return rc;
     }
+    if ((*plan)->cfg.verbose)
+        printf("plan: host layout %.3f s, panel form %s %.3f s, upload %.3f s\n", t1 - t0, on_device ? "on the device" : "(host, included)", t2 - t1,
+               wall_seconds() - t2);
     return rc;
 }
 

@@ -62,6 +62,7 @@ struct Config {
     int er_sums;            // 1 DPP scan, 2 LDS words
     int er_panel_threads;   // 0 automatic, 512, 1024
     int er_queue;           // 1 per-XCD work queues with stealing (A/B arm), 2 one workgroup per item (default)
+    int symbolic;           // where the panel form is built by ehyb_plan_create[_segs]: 1 host, 2 device (default)
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -130,6 +131,7 @@ struct HostLayout {
     int pb_rows_max = 0;              // rows of the largest row block (LDS of pass 2)
     int64_t pb_partials = 0;
     int64_t pb_bytes = 0;             // bytes both passes move per multiply
+    int64_t pb_padded = 0;            // length of pb_val / pb_col / pb_dst / pb_src (panels padded to multiples of 64 entries)
     std::vector<double> pb_val;       // pass-1 order, panels padded to multiples of 64 entries
     std::vector<uint16_t> pb_col;     // column - panel start
     std::vector<uint32_t> pb_dst;     // partial slot; 0xFFFFFFFF = padding
@@ -159,11 +161,49 @@ struct HostLayout {
     std::vector<int32_t> pb_src;      // like pb_val
     int64_t src_entries = 0;          // entries of the source matrix (length ehyb_plan_set_values expects)
 
+    // Panel form left to the device (ehyb_plan_create with cfg.symbolic = 2, er_panel_dev.hip): the residual entries in
+    // ROW order, as the layout builder met them -- either views into the caller's matrix (every entry is residual: R-MAT)
+    // or the builder's own row-order copies.  `pending` until the device has dealt them out; after that the pb_*
+    // streams live on the device alone until somebody asks for them (pb_host_missing, materialize_panel_host).
+    struct Deferred {
+        bool pending = false;
+        int64_t nnz_er = 0;
+        std::vector<int64_t> er_rp;   // [rows + 1] first residual entry of every row
+        const int32_t* col = nullptr;
+        const double* val = nullptr;
+        const int32_t* src = nullptr; // source entry of every residual entry; null: src_base + its position
+        int64_t src_base = 0;
+        bool want_src = false;        // cfg.value_map: keep the slot map of pb_val
+        std::vector<int32_t> own_col, own_src;
+        std::vector<double> own_val;
+    } deferred;
+    bool pb_host_missing = false;
+
     ehyb_stats stats{};
 };
 
+// The host's share of the panel builder (er_panel.cpp), common to the host and the device route
+struct PanelGeometry {
+    int W = 0;
+    std::vector<int32_t> seg_first;    // [segments + 1] column segments
+    std::vector<int32_t> seg_panel0;   // [segments + 1] first panel of every segment
+    std::vector<int32_t> panel_first;  // [panels + 1] first column of every panel
+    std::vector<int32_t> rb_first;     // [row blocks + 1] first row of every row block of pass 2
+    std::vector<uint8_t> row_assign;   // [rows] pb_assign only: the row's partition has no window
+};
+int panel_geometry(const Config& cfg, const HostLayout& L, const int32_t* cnt_row, int64_t nnz_er, PanelGeometry* G);
+int64_t panel_pass1_items(const Config& cfg, const PanelGeometry& G, const std::vector<int64_t>& pstart, int64_t nnz_er, HostLayout* L);
+void panel_finish(const PanelGeometry& G, const std::vector<int64_t>& rb_count, int64_t staged, int64_t padded, int64_t n_pieces, int64_t n_jumps,
+                  HostLayout* L);
+
+// defer_panel: a panel form that is certain (cfg.er_mode = 2, or partitions given up) is left to the device --
+// out->deferred.pending, no CSR segments either; the views of out->deferred may point into *m
 int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* out,
-                 const std::vector<uint8_t>* part_to_er = nullptr, int local_lo = -1, int local_hi = -1);
+                 const std::vector<uint8_t>* part_to_er = nullptr, int local_lo = -1, int local_hi = -1, bool defer_panel = false);
+int create_host_plan(const matrixCOO* m, int row_begin, int row_end, const ehyb_config* cfg, int n_col_segs, const int* col_seg_first,
+                     bool defer_panel, ehyb_plan** plan);                         // plan.cpp
+int build_panel_on_device(ehyb_plan* P);              // er_panel_dev.hip: P->host.deferred -> the d_pb_* arrays
+int materialize_panel_host(ehyb_plan* P);             // er_panel_dev.hip: pb_* streams of a device-built plan back to the host
 int build_panel_residual(const Config& cfg, HostLayout* L);  // er_panel.cpp; reads the CSR residual of *L
 void encode_panel_slots(HostLayout* L);                      // er_panel.cpp; pb_col + pb_dst -> pb_colf, pb_chunk, pb_jump
 bool sym_storage_suits(const matrixCOO* m);  // spmvGPuEHYB's own choice of the storage (plan.cpp)

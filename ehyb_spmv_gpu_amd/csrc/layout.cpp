@@ -159,7 +159,7 @@ void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64
 // part_to_er (may be null): partitions (by their index in the layout's own partition list) whose rows go
 // to the residual whole -- no window, no halo, zero-width slabs (plan.cpp decides, see ell_pays()).
 int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* L,
-                 const std::vector<uint8_t>* part_to_er, int local_lo, int local_hi)
+                 const std::vector<uint8_t>* part_to_er, int local_lo, int local_hi, bool defer_panel)
 {
     // multi-GPU (cfg.n_top > 1): the columns a window may hold are the rank's own, [local_lo, local_hi) -- the plan's
     // rows unless the caller lays out a SAMPLE of a rank's partitions (plan.cpp) and names the rank's range
@@ -325,13 +325,22 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                         cand.push_back(j);
                     }
                 if (hcap > 0 && !cand.empty()) {
-                    std::sort(cand.begin(), cand.end());
                     uniq.clear();
-                    for (size_t a = 0; a < cand.size();) {
-                        size_t b = a;
-                        while (b < cand.size() && cand[b] == cand[a]) ++b;
-                        uniq.push_back({(int32_t)(b - a), cand[a]});
-                        a = b;
+                    if (cand.size() > (size_t)n / 4) {
+                        // a hub partition (millions of candidates): counted in a dense array instead of sorted -- the same
+                        // (count, column) list, columns ascending (R-MAT 2^24: 25 M candidates, 2 s of sort on one thread)
+                        std::vector<int32_t> dense((size_t)n, 0);
+                        for (int32_t j : cand) ++dense[(size_t)j];
+                        for (int j = 0; j < n; ++j)
+                            if (dense[(size_t)j]) uniq.push_back({dense[(size_t)j], j});
+                    } else {
+                        std::sort(cand.begin(), cand.end());
+                        for (size_t a = 0; a < cand.size();) {
+                            size_t b = a;
+                            while (b < cand.size() && cand[b] == cand[a]) ++b;
+                            uniq.push_back({(int32_t)(b - a), cand[a]});
+                            a = b;
+                        }
                     }
                     if ((int)uniq.size() > hcap) {
                         // most referenced first; ties: lower column
@@ -523,6 +532,15 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         if (cfg.fuse_er != 1 && padded * 100 > nnz) L->inline_er = false;  // the slices would add > 1 % (x 2: 24 B each) traffic
     }
 
+    // The panel form left to the device (ehyb_plan_create, cfg.symbolic): only where it is certain to be used -- partitions
+    // were given up, or the caller asked for it -- because the automatic choice reads the CSR segments this route never
+    // builds.  Where EVERY entry is residual (R-MAT: all partitions given up) the device reads the caller's arrays and
+    // not even the row-order copies are made.
+    L->deferred = HostLayout::Deferred();
+    L->pb_host_missing = false;
+    const bool defer = defer_panel && cfg.symbolic != 1 && !L->inline_er && !direct && nnz_er > 0 && (cfg.er_mode == 2 || assign_mode);
+    const bool view_m = defer && nnz_er == nnz && !sym;
+
     // ---- pass 2: prefix sums
     L->halo_ptr.assign(np + 1, 0);
     std::vector<int64_t> slab_base(np + 1, 0);
@@ -590,11 +608,11 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     L->lane_group.assign((size_t)nslabs * kSlabRows, 0);
     // symmetric pairs: which row (place in the partition's LDS image) a lane works on; 0xFFFF = none
     L->slab_lrow.assign(sym ? (size_t)nslabs * kSlabRows : 0, (uint16_t)0xFFFF);
-    std::vector<int32_t> tcol((size_t)nnz_er);
-    std::vector<double> tval((size_t)nnz_er);
+    std::vector<int32_t> tcol(view_m ? 0 : (size_t)nnz_er);
+    std::vector<double> tval(view_m ? 0 : (size_t)nnz_er);
     // slot maps (cfg.value_map): the entry every slot of a value stream is filled from, so that the numeric
     // phase can be repeated on the device for new values (ehyb_plan_set_values)
-    std::vector<int32_t> tsrc(vmap ? (size_t)nnz_er : 0);
+    std::vector<int32_t> tsrc(vmap && !view_m ? (size_t)nnz_er : 0);
     L->ell_src.assign(vmap ? (size_t)size_stream : 0, -1);
     L->ell_src2.assign(vmap && sym ? (size_t)size_stream : 0, -1);
     L->er_src.clear();
@@ -624,8 +642,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             if (t + 1 == e - s)  // lanes past the last row of the partition read the last group (values 0)
                 for (int l2 = lane + 1; l2 < kSlabRows; ++l2) L->lane_group[(size_t)sidx * kSlabRows + l2] = (uint8_t)gid;
             uint32_t k_ell = 0;
-            int64_t k_er = er_rp[r - row_begin];
-            for (int k = rp[r]; k < rp[r + 1]; ++k) {
+            int64_t k_er = view_m ? er_rp[r - row_begin + 1] : er_rp[r - row_begin];  // (view_m: nothing to copy)
+            for (int k = view_m ? rp[r + 1] : rp[r]; k < rp[r + 1]; ++k) {
                 int j = m->J[k];
                 int local = -1;
                 const uint8_t st8 = sym ? state[k - k0] : 0;
@@ -818,7 +836,35 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     };
     std::vector<Seg> segs;
     int64_t rows_er = 0;
-    {
+    if (defer) {
+        for (int rr = 0; rr < nrows; ++rr) rows_er += er_rp[rr + 1] > er_rp[rr];
+        HostLayout::Deferred& D = L->deferred;
+        D.pending = true;
+        D.nnz_er = nnz_er;
+        if (view_m) {
+            D.col = m->J + k0;
+            D.val = m->V + k0;
+            D.src = nullptr;
+            D.src_base = k0;
+            D.want_src = vmap;
+        } else {
+            D.own_col = std::move(tcol);
+            D.own_val = std::move(tval);
+            D.own_src = std::move(tsrc);
+            D.col = D.own_col.data();
+            D.val = D.own_val.data();
+            D.src = vmap ? D.own_src.data() : nullptr;
+            D.want_src = vmap;
+        }
+        D.er_rp = std::move(er_rp);
+        L->er_seg_ptr.assign(1, 0);
+        L->er_seg_row.clear();
+        L->er_col.clear();
+        L->er_val.clear();
+        L->er_blocks.clear();
+        L->pb_assign = assign_mode;
+        L->er_panel = false;  // until the device has built it
+    } else {
         // segments per row first (the partitions tile the rows in order), then every row fills its own: parallel
         auto pieces_of = [&](int64_t len) { return (len == 0 && !direct) ? 0 : (direct ? 1 : (int)((len + cfg.er_seg_len - 1) / cfg.er_seg_len)); };
         std::vector<int64_t> seg_first((size_t)nrows + 1, 0);
@@ -851,6 +897,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                                 [](const Seg& a, const Seg& b) { return a.item != b.item ? a.item < b.item : a.len > b.len; });
     const int64_t nseg = (int64_t)segs.size();
     if (nseg > 0x7FFFFFFFll) EHYB_FAIL(EHYB_ERR_ARG, "build_layout: too many residual segments");
+    if (!defer) {
     L->er_seg_ptr.assign(nseg + 1, 0);
     L->er_seg_row.resize(nseg);
     for (int64_t i = 0; i < nseg; ++i) {
@@ -883,6 +930,9 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             rec[7] = (int32_t)i;
         }
         if (i != nseg) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: residual segments not covered by the work items");
+    }
+    }  // (!defer)
+    {
         L->er_bins[0] = 0;
         L->er_bins[3] = (int32_t)nseg;
         // Flat block list for the stand-alone residual kernel (two-launch form): every block of
@@ -932,12 +982,13 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         want_panel = lines * 2 > nwin * win;  // more than one new line per two entries: no locality to speak of
         if (cfg.verbose) printf("residual locality: %.3f distinct x lines per entry -> %s form\n", (double)lines / (double)(nwin * win), want_panel ? "panel" : "CSR");
     }
-    if (!L->inline_er && !direct && nnz_er > 0 && want_panel) {
+    if (!defer && !L->inline_er && !direct && nnz_er > 0 && want_panel) {
         L->pb_assign = assign_mode;
         const int rc_pb = build_panel_residual(cfg, L);
         if (rc_pb != EHYB_OK) return rc_pb;
         if (!L->er_panel) L->pb_assign = false;
     }
+    if (defer) L->pb_assign = assign_mode;
     if (assign_mode && !L->pb_assign) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: partitions were given up but the residual did not end in panel form");
     lap("panel form");
     // ---- statistics (convert.c:140,310; spmv.cu:82)

@@ -90,17 +90,42 @@ static bool windows_will_not_pay(const matrixCOO* m, int row_begin, int row_end,
     quiet.value_map = 0;
     quiet.direct = 2;
     int64_t seen = 0, kept_first = 0, kept_rest = 0;
-    for (int p : pick) {
-        HostLayout S;
-        if (build_layout(m, m->partBoundary[p], m->partBoundary[p + 1], quiet, &S, nullptr, row_begin, row_end) != EHYB_OK) {
-            clear_error();
-            return false;
+    // the samples are laid out side by side (a one-partition layout runs on one thread; the hub partition -- first in the
+    // list, a fifth of a degree-ordered R-MAT -- takes as long as the 23 others together)
+    std::vector<int64_t> s_nnz(pick.size(), 0), s_kept(pick.size(), 0);
+    bool failed = false;
+    quiet.host_threads = 1;
+    {
+        OmpScope omp_scope(cfg.host_threads);
+#pragma omp parallel for schedule(dynamic, 1)
+        for (size_t i = 0; i < pick.size(); ++i) {
+            const int p = pick[i];
+            HostLayout S;
+            int rc;
+            try {
+                rc = build_layout(m, m->partBoundary[p], m->partBoundary[p + 1], quiet, &S, nullptr, row_begin, row_end);
+            } catch (const std::bad_alloc&) {
+                rc = EHYB_ERR_ALLOC;
+            }
+            if (rc != EHYB_OK) {
+#pragma omp atomic write
+                failed = true;
+                continue;
+            }
+            std::vector<uint8_t> to_er;
+            int64_t moved = 0;
+            windows_that_do_not_pay(S, cfg.prune_pct, &to_er, &moved);
+            s_nnz[i] = S.stats.nnz;
+            s_kept[i] = S.stats.nnz_ell - moved;
         }
-        std::vector<uint8_t> to_er;
-        int64_t moved = 0;
-        windows_that_do_not_pay(S, cfg.prune_pct, &to_er, &moved);
-        seen += S.stats.nnz;
-        (p == pick[0] ? kept_first : kept_rest) += S.stats.nnz_ell - moved;
+    }
+    if (failed) {
+        clear_error();
+        return false;
+    }
+    for (size_t i = 0; i < pick.size(); ++i) {
+        seen += s_nnz[i];
+        (i == 0 ? kept_first : kept_rest) += s_kept[i];
     }
     // the first partition counts for itself, the others for their share of the rest
     const double kept_est = (double)kept_first + (double)kept_rest * (double)(parts.size() - 1) / (double)std::max<size_t>(1, pick.size() - 1);
@@ -159,6 +184,16 @@ int ehyb_plan_create_host(const matrixCOO* m, int row_begin, int row_end, const 
 int ehyb_plan_create_host_segs(const matrixCOO* m, int row_begin, int row_end, const ehyb_config* cfg,
                                int n_col_segs, const int* col_seg_first, ehyb_plan** plan)
 {
+    return ehyb::create_host_plan(m, row_begin, row_end, cfg, n_col_segs, col_seg_first, false, plan);
+}
+
+}  // extern "C"
+
+// defer_panel (ehyb_plan_create[_segs] only): a panel form that is certain is left to the device -- the plan comes back with
+// host.deferred.pending, whose views may point into *m: the caller finishes it (build_panel_on_device) before m can change
+int ehyb::create_host_plan(const matrixCOO* m, int row_begin, int row_end, const ehyb_config* cfg, int n_col_segs, const int* col_seg_first,
+                           bool defer_panel, ehyb_plan** plan)
+{
     clear_error();
     if (!plan) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_create_host: null output");
     *plan = nullptr;
@@ -184,18 +219,19 @@ int ehyb_plan_create_host_segs(const matrixCOO* m, int row_begin, int row_end, c
             // (the layout's own partition list may be longer than the caller's -- partitions cut down to the window --
             // so the flags cover any index: every partition goes)
             all.assign((size_t)(row_end - row_begin) / kSlabRows + (size_t)m->nParts + 64, 1);
-            const int rc0 = build_layout(m, row_begin, row_end, P->cfg, &direct_to, &all);
-            if (rc0 == EHYB_OK && direct_to.er_panel) {
+            const int rc0 = build_layout(m, row_begin, row_end, P->cfg, &direct_to, &all, -1, -1, defer_panel);
+            if (rc0 == EHYB_OK && (direct_to.er_panel || direct_to.deferred.pending)) {
                 P->host = std::move(direct_to);
                 decided = true;
             } else {
                 clear_error();
             }
         }
-        rc = decided ? EHYB_OK : build_layout(m, row_begin, row_end, P->cfg, &P->host);
+        // (the first build of the two-build route needs no panel form to judge the windows: deferred as well when certain)
+        rc = decided ? EHYB_OK : build_layout(m, row_begin, row_end, P->cfg, &P->host, nullptr, -1, -1, defer_panel);
         // Where the residual runs in panel form (a large residual without locality: R-MAT), a partition
         // whose window does not pay is better off in the residual whole: built a second time with those.
-        if (!decided && rc == EHYB_OK && P->host.er_panel && !P->host.sym && P->cfg.er_mode != 1 && P->cfg.ell_prune != 2) {
+        if (!decided && rc == EHYB_OK && (P->host.er_panel || P->host.deferred.pending) && !P->host.sym && P->cfg.er_mode != 1 && P->cfg.ell_prune != 2) {
             std::vector<uint8_t> to_er;
             int64_t moved = 0;
             if (windows_that_do_not_pay(P->host, P->cfg.prune_pct, &to_er, &moved) > 0) {
@@ -217,11 +253,11 @@ int ehyb_plan_create_host_segs(const matrixCOO* m, int row_begin, int row_end, c
                 again.col_seg_first = P->host.col_seg_first;
                 int rc2;
                 try {
-                    rc2 = build_layout(m, row_begin, row_end, P->cfg, &again, &to_er);
+                    rc2 = build_layout(m, row_begin, row_end, P->cfg, &again, &to_er, -1, -1, defer_panel);
                 } catch (const std::bad_alloc&) {
                     rc2 = EHYB_ERR_ALLOC;
                 }
-                if (rc2 == EHYB_OK && again.er_panel)
+                if (rc2 == EHYB_OK && (again.er_panel || again.deferred.pending))
                     P->host = std::move(again);
                 else if (P->cfg.verbose)
                     printf("rebuild without those windows failed (%d): keeping the first layout\n", rc2);
@@ -240,6 +276,8 @@ int ehyb_plan_create_host_segs(const matrixCOO* m, int row_begin, int row_end, c
     return EHYB_OK;
 }
 
+extern "C" {
+
 int ehyb_plan_stats(const ehyb_plan* plan, ehyb_stats* out)
 {
     if (!plan || !out) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_stats: null argument");
@@ -250,6 +288,12 @@ int ehyb_plan_stats(const ehyb_plan* plan, ehyb_stats* out)
 int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int64_t* count)
 {
     if (!plan || !ptr || !count) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_host_array: null argument");
+    // a plan whose panel form was built on the device fetches those streams the first time anybody asks (the plan is
+    // logically unchanged: const for the caller)
+    if (plan->host.pb_host_missing && which >= EHYB_ARR_PB_VAL) {
+        const int rc = materialize_panel_host(const_cast<ehyb_plan*>(plan));
+        if (rc != EHYB_OK) return rc;
+    }
     const HostLayout& H = plan->host;
 #define VIEW(v)                      \
     *ptr = (const void*)(v).data(); \

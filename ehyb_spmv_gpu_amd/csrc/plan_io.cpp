@@ -141,6 +141,10 @@ int ehyb_plan_save(const ehyb_plan* plan, const int* reorder_list, uint64_t matr
     if (!plan || !path) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_save: null argument");
     if (plan->host_values_stale)
         EHYB_FAIL(EHYB_ERR_STATE, "ehyb_plan_save: the plan's values were replaced on the device (ehyb_plan_set_values); its host copy is stale");
+    if (plan->host.pb_host_missing) {  // a panel form built on the device: its streams come back first
+        const int rc = materialize_panel_host(const_cast<ehyb_plan*>(plan));
+        if (rc != EHYB_OK) return rc;
+    }
     HostLayout& H = const_cast<HostLayout&>(plan->host);  // each_array takes non-const; nothing is modified
     File f(fopen(path, "wb"));
     if (!f) EHYB_FAIL(EHYB_ERR_IO, "ehyb_plan_save: cannot create %s", path);
@@ -195,6 +199,7 @@ int ehyb_plan_load(const char* path, uint64_t expect_key, ehyb_plan** plan, int*
     H.sym = s.sym != 0, H.yacc_doubles = s.yacc_doubles;
     H.er_panel = s.er_panel != 0, H.pb_panel_cols = s.pb_panel_cols, H.pb_rows_max = s.pb_rows_max, H.direct = s.direct != 0;
     H.pb_partials = s.pb_partials, H.pb_bytes = s.pb_bytes;
+    H.pb_padded = (int64_t)H.pb_val.size();
     H.pb_assign = s.pb_assign != 0 && H.er_panel;
     memcpy(H.er_bins, s.er_bins, sizeof s.er_bins);
     // the sizes the kernels rely on must fit together -- a damaged file must not reach the GPU

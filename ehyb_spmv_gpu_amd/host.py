@@ -324,15 +324,14 @@ class Plan:
         self.n = matrix.n
         r0, r1 = (0, matrix.n) if rows is None else rows
         self.rows = (r0, r1)
-        if col_segs is None:
-            _check(self.lib.ehyb_plan_create_host(C.byref(matrix.c), r0, r1, C.byref(cfg) if cfg else None,
-                                                  C.byref(self.h)), "ehyb_plan_create_host")
-        else:
-            segs = np.ascontiguousarray(col_segs, dtype=np.int32)
-            _check(self.lib.ehyb_plan_create_host_segs(C.byref(matrix.c), r0, r1, C.byref(cfg) if cfg else None, len(segs) - 1,
-                                                       _ptr(segs, C.c_int), C.byref(self.h)), "ehyb_plan_create_host_segs")
+        segs = None if col_segs is None else np.ascontiguousarray(col_segs, dtype=np.int32)
+        args = (C.byref(matrix.c), r0, r1, C.byref(cfg) if cfg else None, 0 if segs is None else len(segs) - 1,
+                None if segs is None else _ptr(segs, C.c_int), C.byref(self.h))
         if upload:
-            self.upload()
+            # build + upload in one call: what the device can build (cfg.symbolic: the panel form of a residual) is built there
+            _check(self.lib.ehyb_plan_create_segs(*args), "ehyb_plan_create_segs")
+        else:
+            _check(self.lib.ehyb_plan_create_host_segs(*args), "ehyb_plan_create_host_segs")
 
     def upload(self):
         _check(self.lib.ehyb_plan_upload(self.h), "ehyb_plan_upload")

@@ -181,7 +181,13 @@ typedef struct ehyb_config {
                               takes the items from per-XCD queues, an XCD whose own eighth is used up helping the one with
                               the most left (the 8 XCDs do not stream equally fast) -- measured + 1.6 % on R-MAT 2^24 and
                               - 6 % on 2^22, kept as an A/B arm                                                   */
-    int32_t reserved[28];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
+    int32_t symbolic;      /* ehyb_plan_create / ehyb_plan_create_segs (the calls that build AND upload): where the panel form
+                              of a residual is built when it is certain to be used (R-MAT: every partition given up, or
+                              er_mode = 2).  0/2 = on the DEVICE, from the entries in row order (radix sort by panel, row,
+                              column; scans for the partial sums and their slots): the arrays are the host builder's, entry
+                              for entry, where the rows arrive in column order; 1 = on the host.  ehyb_plan_create_host never
+                              leaves anything to the device                                                        */
+    int32_t reserved[27];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);
@@ -262,8 +268,14 @@ int ehyb_plan_create_host_segs(const matrixCOO* m, int row_begin, int row_end, c
                                int n_col_segs, const int* col_seg_first, ehyb_plan** plan);
 /* Allocate device arrays and copy the layout (cudaMallocTransDataEHYB, spmv.cu:6-60). */
 int ehyb_plan_upload(ehyb_plan* plan);
-/* create_host + upload */
+/* Build + upload in one call, for the rows [0, dimension).  Unlike ehyb_plan_create_host followed by ehyb_plan_upload
+ * this call may build on the DEVICE what it can (cfg.symbolic: the panel form of a residual without locality -- the
+ * part of the symbolic phase that costs a power-law matrix seconds on the host).  Such a plan keeps the
+ * pb_* streams on the device; ehyb_plan_host_array and ehyb_plan_save fetch them when asked. */
 int ehyb_plan_create(const matrixCOO* m, const ehyb_config* cfg, ehyb_plan** plan);
+/* The same for a row range and column segments (ehyb_plan_create_host_segs' arguments). */
+int ehyb_plan_create_segs(const matrixCOO* m, int row_begin, int row_end, const ehyb_config* cfg, int n_col_segs, const int* col_seg_first,
+                          ehyb_plan** plan);
 void ehyb_plan_destroy(ehyb_plan* plan);
 
 /*
