@@ -600,9 +600,19 @@ void initial_partition(const GView& g, int k, int64_t cap, uint64_t& rng, std::v
 // Vertices in order of falling degree, ties in the given numbering (EHYB_PART_DEGREE).
 void degree_order(int n, const int64_t* xadj, std::vector<int>* order)
 {
+    // falling degree, ties in the given numbering: a counting sort (R-MAT 2^24: std::stable_sort of 16.8 M rows took 1.5 s)
     order->resize((size_t)n);
-    std::iota(order->begin(), order->end(), 0);
-    std::stable_sort(order->begin(), order->end(), [&](int a, int b) { return xadj[a + 1] - xadj[a] > xadj[b + 1] - xadj[b]; });
+    int64_t maxd = 0;
+    for (int v = 0; v < n; ++v) maxd = std::max(maxd, xadj[v + 1] - xadj[v]);
+    std::vector<int64_t> first((size_t)maxd + 2, 0);  // first[d] = rows of degree > d, after the prefix sum
+    for (int v = 0; v < n; ++v) ++first[(size_t)(xadj[v + 1] - xadj[v])];
+    int64_t before = 0;
+    for (int64_t d = maxd; d >= 0; --d) {
+        const int64_t c = first[(size_t)d];
+        first[(size_t)d] = before;
+        before += c;
+    }
+    for (int v = 0; v < n; ++v) (*order)[(size_t)first[(size_t)(xadj[v + 1] - xadj[v])]++] = v;
 }
 
 int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vwgt, int nparts,

@@ -527,6 +527,7 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
         inpart[i] = c.sym_pairs == 1 ? (cnt + 3) / 2 : cnt;
     }
 
+    if (c.verbose > 1) printf("  row order: in-partition counts %ld us\n", (long)((wall_seconds() - t_sort) * 1e6));
     // rows of each partition, old order, then stable sort by inpart descending (reordering.c:334)
     std::vector<int> rows_of(n);
     {
@@ -540,13 +541,63 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
         // The sort key is "entries the ELL kernel will take".  With a halo window that is the
         // in-partition count plus the entries whose column is among the partition's most
         // referenced outside columns (same selection rule as build_layout).
+        // Partitions with millions of candidates first, one at a time with every thread on it: the hub partition of a
+        // degree-ordered power-law matrix references a fifth of all entries (R-MAT 2^24: 25 M candidates; one thread counted
+        // and looked them up for 1.5 s while the others waited).  Reference counts by column in one dense array (atomic
+        // increments), the same selection rule, the chosen columns flagged in the array for the second pass.
+        std::vector<uint8_t> done((size_t)nparts, 0);
+        {
+            std::vector<int> dense;
+            std::vector<std::pair<int, int>> uniq;
+            const auto by_count = [](const std::pair<int, int>& x, const std::pair<int, int>& y) { return x.first != y.first ? x.first > y.first : x.second < y.second; };
+            for (int p = 0; p < nparts; ++p) {
+                int64_t entries = 0;
+                for (int q = pb[p]; q < pb[p + 1]; ++q) entries += m->rowIdx[rows_of[q] + 1] - m->rowIdx[rows_of[q]];
+                if (entries <= ((int64_t)1 << 21)) continue;
+                done[(size_t)p] = 1;
+                const int own = pb[p + 1] - pb[p];
+                const int hcap = c.lds_doubles - 2 - (own + (pb[p] & 1)) * (c.sym_pairs == 1 ? 2 : 1);
+                if (hcap <= 0) continue;
+                if (dense.empty()) dense.assign((size_t)n, 0);
+#pragma omp parallel for schedule(dynamic, 64)
+                for (int q = pb[p]; q < pb[p + 1]; ++q) {
+                    const int i = rows_of[q];
+                    for (int k = m->rowIdx[i]; k < m->rowIdx[i + 1]; ++k)
+                        if (m->I[k] == i && part[m->J[k]] != p) {
+#pragma omp atomic
+                            ++dense[(size_t)m->J[k]];
+                        }
+                }
+                uniq.clear();
+                for (int j = 0; j < n; ++j)
+                    if (dense[(size_t)j]) {
+                        uniq.push_back({dense[(size_t)j], j});
+                        dense[(size_t)j] = 0;
+                    }
+                if ((int)uniq.size() > hcap) {
+                    std::nth_element(uniq.begin(), uniq.begin() + hcap, uniq.end(), by_count);
+                    uniq.resize((size_t)hcap);
+                }
+                for (const auto& u : uniq) dense[(size_t)u.second] = -1;  // chosen
+#pragma omp parallel for schedule(dynamic, 64)
+                for (int q = pb[p]; q < pb[p + 1]; ++q) {
+                    const int i = rows_of[q];
+                    int add = 0;
+                    for (int k = m->rowIdx[i]; k < m->rowIdx[i + 1]; ++k) add += m->I[k] == i && part[m->J[k]] != p && dense[(size_t)m->J[k]] < 0;
+                    inpart[i] += add;
+                }
+                for (const auto& u : uniq) dense[(size_t)u.second] = 0;
+            }
+        }
+        if (c.verbose > 1) printf("  row order: hub partitions done at %ld us\n", (long)((wall_seconds() - t_sort) * 1e6));
 #pragma omp parallel
         {
             std::vector<int> cand;
             std::vector<std::pair<int, int>> uniq;
-            std::vector<int> dense;  // reference counts by column, for partitions with millions of candidates (made on first use)
+            std::vector<int> hkey, hcnt;
 #pragma omp for schedule(dynamic, 1)
             for (int p = 0; p < nparts; ++p) {
+                if (done[(size_t)p]) continue;
                 const int own = pb[p + 1] - pb[p];
                 // 2 doubles hold the kernel's slab counter; symmetric pair storage keeps y accumulators too
                 const int hcap = c.lds_doubles - 2 - (own + (pb[p] & 1)) * (c.sym_pairs == 1 ? 2 : 1);
@@ -559,26 +610,26 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                 }
                 if (cand.empty()) continue;
                 uniq.clear();
-                if (cand.size() > ((size_t)1 << 20)) {
-                    // the hub partition of a degree-ordered power-law matrix references a third of all entries: counted, not
-                    // sorted (one thread sorted 10 M candidates for a second while the others waited)
-                    if (dense.empty()) dense.assign((size_t)n, 0);
-                    size_t distinct = 0;
-                    for (int cc : cand)
-                        if (dense[(size_t)cc]++ == 0) cand[distinct++] = cc;  // the distinct columns, compacted in front
-                    for (size_t a = 0; a < distinct; ++a) {
-                        uniq.push_back({dense[(size_t)cand[a]], cand[a]});
-                        dense[(size_t)cand[a]] = 0;
-                    }
-                } else {
-                    std::sort(cand.begin(), cand.end());
-                    for (size_t a = 0; a < cand.size();) {
-                        size_t b = a;
-                        while (b < cand.size() && cand[b] == cand[a]) ++b;
-                        uniq.push_back({(int)(b - a), cand[a]});
-                        a = b;
-                    }
+                // reference counts by column in an open-addressing table of this thread (the candidates of a partition of a
+                // matrix without locality are ~10^5 random columns: sorting them was most of this step); the chosen
+                // columns keep their slot with the count turned negative, which is what the second pass looks up
+                size_t cap = 64;
+                while (cap < 2 * cand.size()) cap <<= 1;
+                hkey.assign(cap, -1);
+                hcnt.assign(cap, 0);
+                const size_t mask = cap - 1;
+                auto slot_of_col = [&](int col) {
+                    size_t h = ((uint32_t)col * 2654435761u) & mask;
+                    while (hkey[h] != -1 && hkey[h] != col) h = (h + 1) & mask;
+                    return h;
+                };
+                for (int cc : cand) {
+                    const size_t h = slot_of_col(cc);
+                    hkey[h] = cc;
+                    ++hcnt[h];
                 }
+                for (size_t h = 0; h < cap; ++h)
+                    if (hkey[h] != -1) uniq.push_back({hcnt[h], hkey[h]});
                 if ((int)uniq.size() > hcap) {
                     std::nth_element(uniq.begin(), uniq.begin() + hcap, uniq.end(),
                                      [](const std::pair<int, int>& x, const std::pair<int, int>& y) {
@@ -586,18 +637,16 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                                      });
                     uniq.resize(hcap);
                 }
-                cand.resize(uniq.size());
-                for (size_t a = 0; a < uniq.size(); ++a) cand[a] = uniq[a].second;
-                std::sort(cand.begin(), cand.end());
+                for (const auto& u : uniq) hcnt[slot_of_col(u.second)] = -1;  // chosen
                 for (int q = pb[p]; q < pb[p + 1]; ++q) {
                     int i = rows_of[q];
                     for (int k = m->rowIdx[i]; k < m->rowIdx[i + 1]; ++k)
-                        if (m->I[k] == i && part[m->J[k]] != p && std::binary_search(cand.begin(), cand.end(), m->J[k]))
-                            inpart[i]++;
+                        if (m->I[k] == i && part[m->J[k]] != p && hcnt[slot_of_col(m->J[k])] < 0) inpart[i]++;
                 }
             }
         }
     }
+    if (c.verbose > 1) printf("  row order: halo counts done at %ld us\n", (long)((wall_seconds() - t_sort) * 1e6));
 #pragma omp parallel for schedule(dynamic, 8)
     for (int p = 0; p < nparts; ++p)
         std::stable_sort(rows_of.begin() + pb[p], rows_of.begin() + pb[p + 1],

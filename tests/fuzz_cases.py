@@ -42,7 +42,9 @@ def random_config_kwargs(rng):
                 # round 3: row order, how pass 1 of the panel form adds up, finds its work and is launched
                 partitioner=int(rng.choice([0, 0, 1, 4])), er_sums=int(rng.choice([1, 1, 2])), er_queue=int(rng.choice([1, 2])),
                 xcd_map=int(rng.choice([1, 2])), er_panel_threads=int(rng.choice([0, 512, 1024])), er_units1=int(rng.choice([0, 1, 7, 300])),
-                er_units2=int(rng.choice([0, 5])), graph_compress=int(rng.choice([0, 1, 2])))
+                er_units2=int(rng.choice([0, 5])), graph_compress=int(rng.choice([0, 1, 2])),
+                # where the panel form is built when the plan is created and uploaded in one call (1 host, 2 device)
+                symbolic=int(rng.choice([1, 2])))
 
 
 def build(E, O, seed):

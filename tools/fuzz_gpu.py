@@ -18,7 +18,7 @@ def main():
     from oracle import oracle as O
 
     bad_seeds = []
-    kinds = {"direct": 0, "panel": 0, "inline": 0, "csr": 0, "sym": 0, "empty_residual": 0}
+    kinds = {"direct": 0, "panel": 0, "panel_built_on_device": 0, "inline": 0, "csr": 0, "sym": 0, "empty_residual": 0}
     for seed in range(first, first + count):
         m, cfg, kw, x, y_ref, scale = build(E, O, seed)
         cfg.value_map = 1   # slot maps, for the refill below
@@ -34,6 +34,7 @@ def main():
         direct = st["nnz_ell"] == 0 and st["nnz_er"] == st["nnz"] and st["er_segments"] == m.n
         kinds["direct"] += direct
         kinds["panel"] += st["er_partials"] > 0
+        kinds["panel_built_on_device"] += st["er_partials"] > 0 and st["er_segments"] == 0
         kinds["inline"] += st["er_inline"] > 0
         kinds["csr"] += (not direct) and st["nnz_er"] > 0 and st["er_partials"] == 0 and st["er_inline"] == 0
         kinds["sym"] += st["sym_pairs"] > 0

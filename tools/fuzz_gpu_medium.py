@@ -56,7 +56,8 @@ def main():
                   partitioner=int(rng.choice([0, 0, 1, 4])), sym_pairs=int(rng.integers(0, 2)) if sym_ok or rng.random() < 0.2 else 0,
                   window_mode=int(rng.choice([0, 0, 0, 1])),
                   er_sums=int(rng.choice([0, 0, 2])), er_queue=int(rng.choice([0, 1])), xcd_map=int(rng.choice([0, 2])),
-                  er_panel_threads=int(rng.choice([0, 512, 1024])), er_units1=int(rng.choice([0, 0, 100, 5000])), graph_compress=int(rng.choice([0, 1, 2])))
+                  er_panel_threads=int(rng.choice([0, 512, 1024])), er_units1=int(rng.choice([0, 0, 100, 5000])), graph_compress=int(rng.choice([0, 1, 2])),
+                  symbolic=int(rng.choice([0, 1])))   # 0: a certain panel form is built on the device, 1: on the host
         if kw["window_mode"] == 1:
             kw["sym_pairs"] = 0
         kw = {k: v for k, v in kw.items() if v}
@@ -93,7 +94,8 @@ def main():
         bad3, _ = O.check_tolerance(y3, -2.0 * y_ref, 2.0 * scale)
         bad2 += bad3
         form = ("direct" if st["nnz_ell"] == 0 and st["er_segments"] == n else "panel" if st["er_partials"] else
-                "inline" if st["er_inline"] else "csr" if st["nnz_er"] else "pure-ell") + ("+sym" if st["sym_pairs"] else "")
+                "inline" if st["er_inline"] else "csr" if st["nnz_er"] else "pure-ell") + ("+sym" if st["sym_pairs"] else "") + (
+                    "@dev" if st["er_partials"] and st["er_segments"] == 0 else "")
         print(f"seed {seed:4d} {kind:12s} n={n:8d} nnz={m.nnz:10d} {form:12s} bad={bad} bad2={bad2} worst={worst:.1e} {time.time() - t0:5.1f}s {kw}", flush=True)
         fails += (bad > 0) + (bad2 > 0)
         plan.destroy()
