@@ -538,43 +538,34 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
     __syncthreads();
     const int c0 = u.z >> 6, c1 = u.w >> 6;  // chunks of 64 entries
     constexpr int K = 8;  // chunks per wave and step: 24 independent vector loads in flight per lane
-    // The jump-list range of a chunk is known from the chunk records alone (wave-uniform, scalar loads), so that the jump
-    // entries travel together with the values and column words instead of behind them (a gather that waits for the flags
-    // doubled the latency per step: 345 -> 470 us on R-MAT 2^24).
-    // Software pipeline (round 3): the loads of step i+1 are issued BEFORE step i is computed -- with one 1024-thread workgroup
-    // per CU there are 4 waves per SIMD, too few for the other waves alone to cover a wave's memory latency -- and the chunk
-    // records are fetched two steps ahead, so that step i+1's jump loads can be formed when step i begins.
-    auto load_records = [&](int cbase, uint32_t (&r0)[K], uint32_t (&rn)[K]) {
+    // The jump-list range of a chunk is known from the chunk records alone (wave-uniform, scalar loads): they are
+    // fetched one step ahead, so that the jump entries travel together with the values and column words instead
+    // of behind them (a gather that waits for the flags doubled the latency per step: 345 -> 470 us on R-MAT 2^24).
+    uint32_t f0[K], fn[K];
 #pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const int cj = min(cbase + j, c1 - 1);
-            r0[j] = chunk[cj];
-            rn[j] = chunk[cj + 1] - r0[j];
-        }
-    };
-    auto load_entries = [&](int cbase, const uint32_t (&r0)[K], const uint32_t (&rn)[K], double (&lv)[K], uint32_t (&lcw)[K], uint32_t (&ljv)[K]) {
-#pragma unroll
-        for (int j = 0; j < K; ++j) {
-            const int cj = cbase + j < c1 ? cbase + j : cbase;  // wave-uniform
-            const size_t pos = (size_t)cj * 64 + lane;
-            lv[j] = val[pos];
-            lcw[j] = colf[pos];
-            ljv[j] = (uint32_t)lane < rn[j] ? jump[r0[j] + lane] : 0u;  // lane l: the chunk's l-th jump entry
-        }
-    };
-    uint32_t f0[K], fn[K], g0[K], gn[K];
-    double v[K];
-    uint32_t cw[K], jv[K];
-    load_records(c0 + K * wave, f0, fn);
-    if (c0 + K * wave < c1) load_entries(c0 + K * wave, f0, fn, v, cw, jv);
-    load_records(c0 + K * wave + K * WAVES, g0, gn);
+    for (int j = 0; j < K; ++j) {
+        const int cj = min(c0 + K * wave + j, c1 - 1);
+        f0[j] = chunk[cj];
+        fn[j] = chunk[cj + 1] - f0[j];
+    }
     for (int c = c0 + K * wave; c < c1; c += K * WAVES) {
-        const int cn = c + K * WAVES;
-        double v2[K];
-        uint32_t cw2[K], jv2[K];
-        if (cn < c1) load_entries(cn, g0, gn, v2, cw2, jv2);  // in flight while this step is computed
-        uint32_t h0[K], hn[K];
-        load_records(cn + K * WAVES, h0, hn);
+        double v[K];
+        uint32_t cw[K], jv[K];
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int cj = c + j < c1 ? c + j : c;  // wave-uniform
+            const size_t pos = (size_t)cj * 64 + lane;
+            v[j] = val[pos];
+            cw[j] = colf[pos];
+            jv[j] = (uint32_t)lane < fn[j] ? jump[f0[j] + lane] : 0u;  // lane l: the chunk's l-th jump entry
+        }
+        uint32_t g0[K], gn[K];  // the records of the next step
+#pragma unroll
+        for (int j = 0; j < K; ++j) {
+            const int cj = min(c + K * WAVES + j, c1 - 1);
+            g0[j] = chunk[cj];
+            gn[j] = chunk[cj + 1] - g0[j];
+        }
         uint32_t slot[K], piece[K];
         unsigned long long hd[K];
         double xw[K];
@@ -622,7 +613,7 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
             }
         }
 #pragma unroll
-        for (int j = 0; j < K; ++j) v[j] = v2[j], cw[j] = cw2[j], jv[j] = jv2[j], g0[j] = h0[j], gn[j] = hn[j];
+        for (int j = 0; j < K; ++j) f0[j] = g0[j], fn[j] = gn[j];
     }
   }
     if (queue == nullptr) break;
