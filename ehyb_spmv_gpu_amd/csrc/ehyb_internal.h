@@ -199,7 +199,8 @@ void panel_finish(const PanelGeometry& G, const std::vector<int64_t>& rb_count, 
 // defer_panel: a panel form that is certain (cfg.er_mode = 2, or partitions given up) is left to the device --
 // out->deferred.pending, no CSR segments either; the views of out->deferred may point into *m
 int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* out,
-                 const std::vector<uint8_t>* part_to_er = nullptr, int local_lo = -1, int local_hi = -1, bool defer_panel = false);
+                 const std::vector<uint8_t>* part_to_er = nullptr, int local_lo = -1, int local_hi = -1, bool defer_panel = false,
+                 bool stats_only = false);  // stats_only: stop after the windows and slab widths (plan.cpp's sample)
 int create_host_plan(const matrixCOO* m, int row_begin, int row_end, const ehyb_config* cfg, int n_col_segs, const int* col_seg_first,
                      bool defer_panel, ehyb_plan** plan);                         // plan.cpp
 int build_panel_on_device(ehyb_plan* P);              // er_panel_dev.hip: P->host.deferred -> the d_pb_* arrays

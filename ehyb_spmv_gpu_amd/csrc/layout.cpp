@@ -159,7 +159,7 @@ void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64
 // part_to_er (may be null): partitions (by their index in the layout's own partition list) whose rows go
 // to the residual whole -- no window, no halo, zero-width slabs (plan.cpp decides, see ell_pays()).
 int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& cfg, HostLayout* L,
-                 const std::vector<uint8_t>* part_to_er, int local_lo, int local_hi, bool defer_panel)
+                 const std::vector<uint8_t>* part_to_er, int local_lo, int local_hi, bool defer_panel, bool stats_only)
 {
     // multi-GPU (cfg.n_top > 1): the columns a window may hold are the rank's own, [local_lo, local_hi) -- the plan's
     // rows unless the caller lays out a SAMPLE of a rank's partitions (plan.cpp) and names the rank's range
@@ -296,10 +296,12 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     {
         std::vector<int32_t> cand;
         std::vector<std::pair<int32_t, int32_t>> uniq;  // (count, col)
+        std::vector<int32_t> dense;                       // by column, hub partitions only
 #pragma omp for schedule(dynamic, 4)
         for (int p = 0; p < np; ++p) {
             const int s = pb[p], e = pb[p + 1];
             const int own = e - s;
+            std::vector<int32_t>().swap(dense);
             int wlen;
             PartScratch& S = ps[p];
             const bool whole_to_er = part_to_er && (size_t)p < part_to_er->size() && (*part_to_er)[p] != 0 && !sym;
@@ -329,10 +331,13 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                     if (cand.size() > (size_t)n / 4) {
                         // a hub partition (millions of candidates): counted in a dense array instead of sorted -- the same
                         // (count, column) list, columns ascending (R-MAT 2^24: 25 M candidates, 2 s of sort on one thread)
-                        std::vector<int32_t> dense((size_t)n, 0);
+                        dense.assign((size_t)n, 0);
                         for (int32_t j : cand) ++dense[(size_t)j];
                         for (int j = 0; j < n; ++j)
-                            if (dense[(size_t)j]) uniq.push_back({dense[(size_t)j], j});
+                            if (dense[(size_t)j]) {
+                                uniq.push_back({dense[(size_t)j], j});
+                                dense[(size_t)j] = 0;
+                            }
                     } else {
                         std::sort(cand.begin(), cand.end());
                         for (size_t a = 0; a < cand.size();) {
@@ -353,6 +358,9 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                     S.halo.resize(uniq.size());
                     for (size_t a = 0; a < uniq.size(); ++a) S.halo[a] = uniq[a].second;
                     std::sort(S.halo.begin(), S.halo.end());
+                    // (the count below asks 25 M times whether a column was chosen: flags in the same array, where it exists)
+                    if (!dense.empty())
+                        for (int32_t j : S.halo) dense[(size_t)j] = 1;
                 }
             }
             L->win_len[p] = wlen;
@@ -371,7 +379,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                     if (sym && state[k - k0] == 2) continue;  // its partner carries it
                     if (j >= s && j < s + wlen)
                         ++c;
-                    else if (halo_mode && !S.halo.empty() && halo_lookup(S.halo, j) >= 0)
+                    else if (halo_mode && !S.halo.empty() && (dense.empty() ? halo_lookup(S.halo, j) >= 0 : dense[(size_t)j] != 0))
                         ++c;
                 }
                 // A slab is walked by ONE wave, four pairs per memory round trip: a slab of rows with
@@ -596,6 +604,15 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         }
         L->slab_pair_ptr[nslabs] = (uint32_t)acc;
         L->slab_col_ptr[nslabs] = (uint32_t)acc_c;
+    }
+    if (stats_only) {
+        // (the window sample of plan.cpp: what the windows would hold and cost -- no value is filled, no residual built)
+        L->stats.nnz = nnz;
+        L->stats.nnz_ell = nnz_ell;
+        L->stats.nnz_er = nnz_er;
+        L->stats.n_parts = np;
+        L->stats.n_slabs = nslabs;
+        return EHYB_OK;
     }
     const int64_t size_ell = ell_pairs * 2 * kSlabRows;                   // ELL elements incl. padding
     const int64_t size_stream = (int64_t)L->slab_pair_ptr[nslabs] * 2 * kSlabRows;  // + inline residual pairs

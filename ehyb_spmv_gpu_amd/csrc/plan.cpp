@@ -103,7 +103,7 @@ static bool windows_will_not_pay(const matrixCOO* m, int row_begin, int row_end,
             HostLayout S;
             int rc;
             try {
-                rc = build_layout(m, m->partBoundary[p], m->partBoundary[p + 1], quiet, &S, nullptr, row_begin, row_end);
+                rc = build_layout(m, m->partBoundary[p], m->partBoundary[p + 1], quiet, &S, nullptr, row_begin, row_end, false, true);
             } catch (const std::bad_alloc&) {
                 rc = EHYB_ERR_ALLOC;
             }
