@@ -392,6 +392,9 @@ enum {
     EHYB_ARR_PB_ITEMS1     = 36 /* int32  [2*items] {first unit, end unit}: the work of one pass-1 workgroup -- consecutive
                                    units of (nearly) equal total cost (entries streamed + panels staged)                */
 };
+/* Read-only view of one array of the plan's host layout.  A plan whose panel form was built on the device (ehyb_plan_create,
+ * cfg.symbolic) downloads the PB_* streams on the first call that asks for one; it has no CSR form of that residual
+ * (ER_SEG_*, ER_COL, ER_VAL empty, er_segments = 0). */
 int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int64_t* count);
 
 /* ------------------------------------------------------------ multiply (GPU) */
