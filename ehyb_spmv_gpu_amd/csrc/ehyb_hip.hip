@@ -1471,7 +1471,16 @@ int ehyb_plan_create_segs(const matrixCOO* m, int row_begin, int row_end, const 
     if (hipGetDeviceCount(&count) != hipSuccess || count < 1)
         EHYB_FAIL(EHYB_ERR_NO_DEVICE, "ehyb_plan_create: no HIP device visible (the EHYB multiply has no CPU fallback)");
     const double t0 = wall_seconds();
-    int rc = create_host_plan(m, row_begin, row_end, cfg, n_col_segs, col_seg_first, true, plan);
+    // The device builder holds ~80 bytes of temporaries per residual entry at its peak (sort keys and payloads twice, rows,
+    // columns, values, the streams): where the device has not got that free -- every entry of the rows taken as residual, the
+    // most it can be -- the panel form is built on the host instead (same arrays, slower).
+    bool on_device_ok = true;
+    if (m && m->rowIdx && row_begin >= 0 && row_end <= m->dimension && row_begin < row_end) {
+        size_t free_b = 0, total_b = 0;
+        const double need = 80.0 * (double)((int64_t)m->rowIdx[row_end] - m->rowIdx[row_begin]) + (256.0 << 20);
+        if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < need) on_device_ok = false;
+    }
+    int rc = create_host_plan(m, row_begin, row_end, cfg, n_col_segs, col_seg_first, on_device_ok, plan);
     if (rc != EHYB_OK) return rc;
     const double t1 = wall_seconds();
     const bool on_device = (*plan)->host.deferred.pending;
