@@ -1477,7 +1477,7 @@ int ehyb_plan_create_segs(const matrixCOO* m, int row_begin, int row_end, const 
     bool on_device_ok = true;
     if (m && m->rowIdx && row_begin >= 0 && row_end <= m->dimension && row_begin < row_end) {
         size_t free_b = 0, total_b = 0;
-        const double need = 80.0 * (double)((int64_t)m->rowIdx[row_end] - m->rowIdx[row_begin]) + (256.0 << 20);
+        const double need = 80.0 * (double)((int64_t)m->rowIdx[row_end] - m->rowIdx[row_begin]) + 268435456.0;
         if (hipMemGetInfo(&free_b, &total_b) != hipSuccess || (double)free_b < need) on_device_ok = false;
     }
     int rc = create_host_plan(m, row_begin, row_end, cfg, n_col_segs, col_seg_first, on_device_ok, plan);
