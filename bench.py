@@ -124,6 +124,58 @@ def pmc_traffic(workload, sym, kernel, st=None):
     return e.get("hbm_bytes_per_launch")
 
 
+def live_pmc_traffic(workload, sym, kname, st, log, timeout_s=300):
+    """HBM bytes per launch of the dominant kernel MEASURED BY THIS RUN, not looked up: two child processes -- tools/pmc_run.py
+    (the same generator, reorder and plan, a 1 GiB streaming read for the calibration of FETCH_SIZE, ten multiplies) under
+    `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace`, separate passes as MI355X_MICROARCH.md
+    prescribes -- parsed by tools/pmc_parse.py.  Quoted only if the child's plan has this plan's layout fingerprint.
+    -> (bytes or None, what happened)"""
+    import shutil
+    import tempfile
+
+    if any("rocprof" in os.environ.get(k, "").lower() for k in ("LD_PRELOAD", "ROCP_TOOL_LIBRARIES", "HSA_TOOLS_LIB")):
+        return None, "this process runs under a profiler itself"
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None, "rocprofv3 not found"
+    if workload not in WORKLOADS:
+        return None, "not a generator workload"
+    tools = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools")
+    tmp = tempfile.mkdtemp(prefix="ehyb_pmc_", dir="/tmp")
+    env = dict(os.environ, TMPDIR="/tmp")
+    t0 = time.time()
+    try:
+        for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
+            cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, sub), "--",
+                   sys.executable, os.path.join(tools, "pmc_run.py"), "--workload", workload] + ([] if sym else ["--plain"])
+            if sub == "fetch":
+                cmd += ["--layout-out", os.path.join(tmp, "layout.json")]
+            p = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout_s)
+            if p.returncode != 0:
+                return None, f"rocprofv3 --pmc {counter} failed ({p.returncode}): {p.stderr[-200:]}"
+        out = os.path.join(tmp, "traffic.json")
+        p = subprocess.run([sys.executable, os.path.join(tools, "pmc_parse.py"), os.path.join(tmp, "fetch"), os.path.join(tmp, "write"), out,
+                            "--workload", workload, "--storage", "sym" if sym else "plain", "--layout", os.path.join(tmp, "layout.json")],
+                           capture_output=True, text=True, timeout=120)
+        if p.returncode != 0:
+            return None, "pmc_parse.py failed: " + p.stderr[-200:]
+        res = json.load(open(out))
+        if res.get("layout") != layout_fingerprint(st):
+            return None, "the profiled child built another layout (bench options the child does not take)"
+        parts = [k for name, k in res["kernels"].items() if ("ehyb_pb_" in name if kname.startswith("ehyb_pb_") else kname in name) and k.get("hbm_bytes_per_launch")]
+        want = 2 if kname.startswith("ehyb_pb_") else 1
+        if len(parts) != want:
+            return None, f"{len(parts)} kernels named {kname} in the counter files"
+        total = float(sum(k["hbm_bytes_per_launch"] for k in parts))
+        factor = (res.get("fetch_calibration") or {}).get("factor")
+        log(f"[bench] PMC traffic of {kname} measured by this run: {total / 1e6:.2f} MB per launch (FETCH_SIZE x {factor:.5f} + WRITE_SIZE; {time.time() - t0:.1f}s)")
+        return total, {"fetch_factor": factor, "launches": min(k["launches"] for k in parts), "seconds": round(time.time() - t0, 1)}
+    except (OSError, ValueError, KeyError, subprocess.TimeoutExpired) as e:
+        return None, f"{type(e).__name__}: {e}"
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+
 def self_launch(args):
     """`python bench.py --gpus N` invoked plainly: start the N ranks as a CHILD process
     (torch.distributed.run) before this process has touched a GPU, relay rank 0's JSON line."""
@@ -491,6 +543,8 @@ def main():
     ap.add_argument("--no-plain-arm", action="store_true",
                     help="N=1 with symmetric pair storage: skip the extra plain-storage measurement of the same matrix")
     ap.add_argument("--no-dropin-arm", action="store_true", help="N=1: skip the run through the reference-named calls")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic live (the table entry of the layout, else format bytes, is quoted)")
     ap.add_argument("--no-refill-arm", action="store_true",
                     help="N=1: build the plan without slot maps and skip the timing of the numeric phase on the device (ehyb_plan_set_values)")
     ap.add_argument("--no-scaling-anchor", action="store_true", help="N=1: skip the one-GPU run of the N>1 default workload")
@@ -690,12 +744,23 @@ def main():
     else:
         kname, k_ms, k_alg, k_fmt = "ehyb_ell_kernel", ell_ms, alg_ell, fmt_ell
     traffic = pmc_traffic(args.workload, st["sym_pairs"] > 0, kname, st)
+    traffic_table, live_detail = traffic, None
+    if not args.no_live_pmc and not args.mtx:
+        # the counters taken by THIS run (child processes under rocprofv3, after the timed loop: nothing of it is inside `value`)
+        live, live_detail = live_pmc_traffic(args.workload, st["sym_pairs"] > 0, kname, st, log)
+        if live:
+            traffic = live
+        else:
+            log(f"[bench] no live PMC measurement ({live_detail}): " + ("the table entry of this layout is quoted" if traffic else "format bytes are quoted"))
     real_bytes = traffic if traffic else k_fmt
     achieved = real_bytes / (k_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "bytes_basis": ("rocprofv3 PMC bytes per launch of this workload, storage and kernel (profiles/pmc_traffic.json)"
+                "bytes_basis": ("rocprofv3 PMC bytes per launch measured by this run (tools/pmc_run.py under --pmc FETCH_SIZE and --pmc WRITE_SIZE, "
+                                "separate passes, FETCH_SIZE calibrated on a 1 GiB streaming read in the same process)" if (traffic and traffic is not traffic_table) else
+                                "rocprofv3 PMC bytes per launch of this workload, storage and kernel (profiles/pmc_traffic.json)"
                                 if traffic else "format bytes per launch (what this layout makes the kernel move; no PMC measurement of exactly this layout on file)"),
+                "traffic_table": traffic_table, "traffic_live": live_detail if isinstance(live_detail, dict) else None,
                 "format_bytes_per_launch": k_fmt, "avg_launch_ms": round(k_ms, 5),
                 "alg_bytes_per_launch": k_alg, "alg_GBps": round(k_alg / (k_ms * 1e-3) / 1e9, 1),
                 "alg_frac": round(k_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

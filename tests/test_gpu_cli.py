@@ -84,7 +84,7 @@ def test_bench_vendor_baseline_arm(gpu):
     import sys
 
     p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "small", "--steps", "20", "--warmup", "3",
-                        "--vendor-baseline", "--no-cpu-baseline", "--no-plain-arm"], capture_output=True, text=True, timeout=900, cwd=ROOT)
+                        "--vendor-baseline", "--no-cpu-baseline", "--no-plain-arm", "--no-live-pmc"], capture_output=True, text=True, timeout=900, cwd=ROOT)
     assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-2500:]
     lines = [ln for ln in p.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1
@@ -94,3 +94,23 @@ def test_bench_vendor_baseline_arm(gpu):
     assert out["parity"]["rows_over_1e-12"] == 0 and out["scaling"] == "none"
     ldd = subprocess.run(["ldd", os.path.join(ROOT, "ehyb_spmv_gpu_amd", "libehyb.so")], capture_output=True, text=True).stdout
     assert "rocsparse" not in ldd
+
+
+def test_bench_measures_its_traffic_in_the_run(gpu):
+    """roofline.traffic is MEASURED by the run that prints it: bench.py starts tools/pmc_run.py twice under
+    `rocprofv3 --pmc` (FETCH_SIZE, WRITE_SIZE; separate passes, with --kernel-trace), after the timed loop, and quotes the
+    bytes only for a child plan with its own layout fingerprint."""
+    import json
+    import sys
+
+    p = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--workload", "small", "--steps", "20", "--warmup", "3",
+                        "--no-cpu-baseline", "--no-plain-arm", "--no-dropin-arm", "--no-scaling-anchor", "--no-refill-arm"],
+                       capture_output=True, text=True, timeout=900, cwd=ROOT)
+    assert p.returncode == 0, p.stdout[-1500:] + p.stderr[-2500:]
+    out = json.loads([ln for ln in p.stdout.splitlines() if ln.startswith("{")][0])
+    r = out["roofline"]
+    assert r["bytes_basis"].startswith("rocprofv3 PMC bytes per launch measured by this run"), (r["bytes_basis"], p.stderr[-1500:])
+    assert r["traffic_live"]["launches"] >= 5 and 1.9 < r["traffic_live"]["fetch_factor"] < 2.1
+    # what the counters see is what the format says the kernel moves, to the partial cache lines at the ends of its streams
+    assert 0.9 * r["format_bytes_per_launch"] < r["traffic"] < 1.25 * r["format_bytes_per_launch"], (r["traffic"], r["format_bytes_per_launch"])
+    assert out["parity"]["rows_over_1e-12"] == 0

@@ -12,7 +12,7 @@ export TMPDIR=/tmp
 O=gpurun_out
 python bench.py --steps 200 --warmup 20 --workload "$WL" "${EXTRA[@]}" > $O/${TAG}_bench.json 2> $O/${TAG}_bench.err || { tail -20 $O/${TAG}_bench.err; exit 1; }
 tail -1 $O/${TAG}_bench.json | cut -c1-600
-rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- python3 bench.py --steps 200 --warmup 20 --workload "$WL" --no-cpu-baseline --no-plain-arm --no-dropin-arm --no-scaling-anchor "${EXTRA[@]}" > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_prof.err
+rocprofv3 --kernel-trace --stats --output-format csv -d $O/${TAG}_prof -- python3 bench.py --steps 200 --warmup 20 --workload "$WL" --no-cpu-baseline --no-plain-arm --no-dropin-arm --no-scaling-anchor --no-live-pmc "${EXTRA[@]}" > $O/${TAG}_bench_under_rocprof.json 2> $O/${TAG}_prof.err
 cp "$(find $O/${TAG}_prof -name '*kernel_stats.csv' | head -1)" $O/${TAG}_kernel_stats.csv
 head -5 $O/${TAG}_kernel_stats.csv
 STORAGE=$(python - "$O/${TAG}_bench.json" <<'PY'
