@@ -75,7 +75,8 @@ class Config(C.Structure):
         ("er_panel_threads", C.c_int32),
         ("er_queue", C.c_int32),
         ("symbolic", C.c_int32),
-        ("reserved", C.c_int32 * 27),
+        ("cg_fused_dot", C.c_int32),
+        ("reserved", C.c_int32 * 26),
     ]
 
 

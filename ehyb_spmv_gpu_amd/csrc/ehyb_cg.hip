@@ -205,10 +205,17 @@ extern "C" int ehyb_pcg(ehyb_plan* P, const double* dinv, const double* b, doubl
     const double bb0 = read_scalar(A_BB), bb = bb0 > 0 ? bb0 : 1.0;
     double rs = read_scalar(A_RR);  // ||r||^2 (the preconditioned product r.z drives the recurrences, not the stop test)
 
+    // p . q as a by-product of the multiply where one window launch writes all of q (the rows' p sits in its LDS window): the
+    // launch leaves one partial per workgroup in the slot the dot kernel would fill -- at most `grid` of them, the rest of the
+    // slot stays zero, and the update kernel adds the slot up in the same fixed order as ever.
+    const int xy_parts = P->cfg.cg_fused_dot != 2 ? spmv_xy_partials(P) : 0;
+    const bool fused = xy_parts > 0 && xy_parts <= grid;
+    if (fused) HIP_TRY(hipMemsetAsync(s + (size_t)A_PQ * kMaxGrid, 0, kMaxGrid * sizeof(double), st));
     auto enqueue_iteration = [&](int cur) -> int {
-        const int e = ehyb_spmv(P, p, q, stream);  // q = A p: x of the multiply changes every time
+        // q = A p: x of the multiply changes every time
+        const int e = fused ? spmv_xy(P, p, q, stream, s + (size_t)A_PQ * kMaxGrid) : ehyb_spmv(P, p, q, stream);
         if (e != EHYB_OK) return e;
-        hipLaunchKernelGGL(cg_dot_kernel, dim3(grid), dim3(kThreads), 0, st, n, p, q, s);
+        if (!fused) hipLaunchKernelGGL(cg_dot_kernel, dim3(grid), dim3(kThreads), 0, st, n, p, q, s);
         hipLaunchKernelGGL(cg_update_kernel, dim3(grid), dim3(kThreads), 0, st, n, p, q, dinv, x, r, s, cur);
         hipLaunchKernelGGL(cg_direction_kernel, dim3(grid), dim3(kThreads), 0, st, n, r, dinv, p, s, cur);
         return EHYB_OK;

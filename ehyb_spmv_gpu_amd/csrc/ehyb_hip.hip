@@ -142,6 +142,9 @@ struct EllArgs {
     int xcd_map;  // 1: workgroup b takes item xcd_item(b), so that each XCD works on one contiguous run of items
     int windowless_zero;  // 1: a partition without a window gets y = 0 here; 0: the panel residual's second pass assigns its y
     unsigned long long* __restrict__ stamps;
+    // non-null (ehyb_cg): the workgroup also leaves sum over its rows of y[row] * x[row] in xy_out[blockIdx.x] -- the p.q of
+    // a conjugate-gradient step falls out of the multiply (the rows' x sits in the window, y in registers or accumulators)
+    double* __restrict__ xy_out;
 };
 
 // Workgroups are handed to the 8 XCDs round robin (b mod 8).  With this map XCD k gets the k-th
@@ -200,7 +203,7 @@ __device__ __forceinline__ void ell_entry(double v, uint32_t col16, const double
 
 template <bool INLINE_ER, bool SYM>
 __device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restrict__ win, double* yacc, int s, int base,
-                                         int pe, int lane)
+                                         int pe, int lane, double& xy)
 {
     // slab record {first value pair, first column word, first row, pairs << 16 | residual pairs << 8 | groups - 1}
     const uint4 sm = A.slab_meta[s];
@@ -264,8 +267,10 @@ __device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restr
     if (has_row) {
         if (SYM)
             unsafeAtomicAdd(&yacc[lrow], acc0 + acc1);  // other lanes scatter into the same accumulator
-        else
+        else {
             A.y[row] = acc0 + acc1;
+            if (A.xy_out != nullptr) xy = fma(acc0 + acc1, win[lrow], xy);  // (own rows are in the window)
+        }
     }
 }
 
@@ -275,7 +280,7 @@ __device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restr
 // written to y in one coalesced sweep at the end.
 template <int THREADS, bool DYN, bool INLINE_ER, bool SYM>
 __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict__ win, int* __restrict__ next_slab,
-                                            int g, int lane, int wave)
+                                            int g, int lane, int wave, double& xy)
 {
     constexpr int WAVES = THREADS / 64;
     const int4 a = A.segs[2 * g], b = A.segs[2 * g + 1];
@@ -309,7 +314,7 @@ __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict
         A.stamps[4 * blockIdx.x + 1] = wall_clock64();
     int s = sb + wave;
     while (s < se) {
-        ell_slab<INLINE_ER, SYM>(A, win, yacc, s, base, pe, lane);
+        ell_slab<INLINE_ER, SYM>(A, win, yacc, s, base, pe, lane, xy);
         if (DYN) {
             int nx = 0;
             if (lane == 0) nx = atomicAdd(next_slab, 1);
@@ -323,7 +328,14 @@ __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict
         // (Folding the pairs that straddle two partitions as well -- 13 % fewer bytes on the bench
         // matrix -- would need y zeroed first and this write-out plus one add per halo column done
         // with global atomics: that alone was measured at +12.5 us per launch, more than the bytes save.)
-        for (int i = threadIdx.x + (ps & 1); i < cnt; i += THREADS) A.y[base + i] = yacc[i];
+        if (A.xy_out != nullptr) {
+            for (int i = threadIdx.x + (ps & 1); i < cnt; i += THREADS) {
+                A.y[base + i] = yacc[i];
+                xy = fma(yacc[i], win[i], xy);
+            }
+        } else {
+            for (int i = threadIdx.x + (ps & 1); i < cnt; i += THREADS) A.y[base + i] = yacc[i];
+        }
     }
 }
 
@@ -340,8 +352,21 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(SYM ? 4
     const int4 it = A.items[2 * item_of_block(A.item_map, A.xcd_map)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    double xy = 0.0;
     for (int sg = it.x; sg < it.y; ++sg) {
-        ell_segment<THREADS, DYN, INLINE_ER, SYM>(A, win, next_slab, sg, lane, wave);
+        ell_segment<THREADS, DYN, INLINE_ER, SYM>(A, win, next_slab, sg, lane, wave, xy);
+    }
+    if (A.xy_out != nullptr) {  // (wave-uniform: a kernel argument)
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) xy += __shfl_xor(xy, off, 64);
+        __syncthreads();  // every wave is done with the last window
+        if (lane == 0) win[wave] = xy;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            double t = 0.0;
+            for (int w = 0; w < THREADS / 64; ++w) t += win[w];  // fixed order
+            A.xy_out[blockIdx.x] = t;
+        }
     }
     if (STAMP) {
         __syncthreads();
@@ -721,7 +746,7 @@ __global__ __launch_bounds__(256) void ehyb_read_kernel(const double2* __restric
 static size_t ell_lds_bytes(const HostLayout& H) { return ((size_t)H.lds_doubles + 1) / 2 * 16 + 16; }
 static int ell_win_cap(const HostLayout& H) { return (H.lds_doubles + 1) / 2 * 2; }
 
-static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long long* stamps)
+static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long long* stamps, double* xy_out = nullptr)
 {
     EllArgs A;
     A.items = (const int4*)P->d_items;
@@ -736,6 +761,7 @@ static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long 
     A.y = y;
     A.win_cap = ell_win_cap(P->host);
     A.stamps = stamps;
+    A.xy_out = xy_out;
     // on by default: plain storage 143 -> 134 us on the audikw_1-like matrix; cfg.xcd_map = 2 for the A/B
     A.xcd_map = P->host.sym ? 0 : (P->cfg.xcd_map != 2 ? 1 : 0);
     A.item_map = P->d_item_map;  // symmetric pairs: items are sorted heaviest first, dispatched in that order
@@ -746,7 +772,7 @@ static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long 
 // ell_variant: 0/1 = LDS slab counter (default), 3 = static round-robin (A/B arm, tools/sweep.py --variants)
 
 template <bool STAMP>
-static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t st, bool inl, unsigned long long* stamps)
+static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t st, bool inl, unsigned long long* stamps, double* xy_out = nullptr)
 {
     const HostLayout& H = P->host;
     const int n_items = (int)(H.items.size() / 8);
@@ -754,7 +780,7 @@ static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t
     if (H.pb_assign && H.segs.empty()) return EHYB_OK;  // no partition kept its window: pass 2 of the panel residual assigns every row
     const size_t lds = ell_lds_bytes(H);
     const bool dyn = P->cfg.ell_variant != 3;
-    const EllArgs A = ell_args(P, x, y, stamps);
+    const EllArgs A = ell_args(P, x, y, stamps, xy_out);
     const bool sym = H.sym;
 #define ELL_GO(T, M, I, S)                                                                                  \
     {                                                                                                        \
@@ -788,6 +814,23 @@ static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t
 static int launch_ell(ehyb_plan* P, const double* x, double* y, hipStream_t st, bool inl)
 {
     return launch_ell_impl<false>(P, x, y, st, inl, nullptr);
+}
+
+// y = A x with x . y as a by-product (ehyb_cg.hip): possible where ONE ELL launch writes the final y of every row from a
+// window that holds the row's own x -- no residual launch of its own (empty or inline residual), halo windows, not the direct
+// shape.  -> number of partial sums the launch leaves (one per workgroup), 0 = not this plan.
+int ehyb::spmv_xy_partials(const ehyb_plan* P)
+{
+    const HostLayout& H = P->host;
+    const int n_items = (int)(H.items.size() / 8);
+    if (!P->uploaded || H.direct || n_items == 0 || H.pb_assign || P->cfg.window_mode != EHYB_WINDOW_HALO) return 0;
+    if (H.stats.nnz_er > 0 && !H.inline_er) return 0;
+    return n_items;
+}
+int ehyb::spmv_xy(ehyb_plan* P, const double* x, double* y, void* stream, double* xy_partials)
+{
+    if (spmv_xy_partials(P) == 0 || !x || !y || !xy_partials) EHYB_FAIL(EHYB_ERR_STATE, "spmv_xy: not a plan that multiplies in one window launch");
+    return launch_ell_impl<false>(P, x, y, (hipStream_t)stream, P->host.inline_er, nullptr, xy_partials);
 }
 
 // which: 1 = pass 1 (scale), 2 = pass 2 (reduce), 3 = both; pass 1 over the items [unit_begin, unit_end) (-1: all)

@@ -63,6 +63,7 @@ struct Config {
     int er_panel_threads;   // 0 automatic, 512, 1024
     int er_queue;           // 1 per-XCD work queues with stealing (A/B arm), 2 one workgroup per item (default)
     int symbolic;           // where the panel form is built by ehyb_plan_create[_segs]: 1 host, 2 device (default)
+    int cg_fused_dot;       // 1 on (default), 2 off
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -203,6 +204,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                  bool stats_only = false);  // stats_only: stop after the windows and slab widths (plan.cpp's sample)
 int create_host_plan(const matrixCOO* m, int row_begin, int row_end, const ehyb_config* cfg, int n_col_segs, const int* col_seg_first,
                      bool defer_panel, ehyb_plan** plan);                         // plan.cpp
+int spmv_xy_partials(const ehyb_plan* P);            // ehyb_hip.hip: y = A x with x . y on the side -- partials it leaves, 0 = not this plan
+int spmv_xy(ehyb_plan* P, const double* x, double* y, void* stream, double* xy_partials);
 int build_panel_on_device(ehyb_plan* P);              // er_panel_dev.hip: P->host.deferred -> the d_pb_* arrays
 int materialize_panel_host(ehyb_plan* P);             // er_panel_dev.hip: pb_* streams of a device-built plan back to the host
 int build_panel_residual(const Config& cfg, HostLayout* L);  // er_panel.cpp; reads the CSR residual of *L

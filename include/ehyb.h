@@ -187,7 +187,9 @@ typedef struct ehyb_config {
                               column; scans for the partial sums and their slots): the arrays are the host builder's, entry
                               for entry, where the rows arrive in column order; 1 = on the host.  ehyb_plan_create_host never
                               leaves anything to the device                                                        */
-    int32_t reserved[27];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
+    int32_t cg_fused_dot;  /* ehyb_cg / ehyb_pcg: 0/1 = p . (A p) is left by the multiply itself where the plan multiplies in one
+                              window launch (one vector kernel fewer per iteration), 2 = always the separate dot kernel (A/B) */
+    int32_t reserved[26];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);

@@ -150,3 +150,32 @@ def test_cg_is_reproducible_and_graph_replay_changes_nothing(E, O, gpu, monkeypa
     assert it1 == it2 == it3 == 41
     assert np.array_equal(x1, x2) and rel1 == rel2
     assert np.array_equal(x1, x3) and rel1 == rel3
+
+
+@pytest.mark.parametrize("sym", [0, 1], ids=["plain", "symmetric-pairs"])
+def test_dot_product_left_by_the_multiply(E, O, gpu, sym):
+    """p . (A p) as a by-product of the multiply (one partial per workgroup of the window launch, cfg.cg_fused_dot) against the
+    separate dot kernel (cfg.cg_fused_dot = 2): the same solve to the rounding of the two summation orders, both at the CPU's
+    iteration count; a matrix whose plan has a residual launch of its own keeps the dot kernel (nothing to compare: same code)."""
+    A = spd_matrix(120, 100, 3000, 7)
+    n = A.shape[0]
+    kw = dict(lds_doubles=2048, sym_pairs=sym, direct=2)
+    cfg = E.make_config(**kw)
+    m = E.Matrix.from_csr(A.indptr, A.indices, A.data, cfg, symmetric=True)
+    m.reorder(cfg)
+    perm = m.reorder_list.copy()
+    fused, separate = E.Plan(m, cfg), E.Plan(m, E.make_config(cg_fused_dot=2, **kw))
+    st = fused.stats
+    assert st["nnz_er"] == 0 or st["er_inline"] > 0, "this matrix must multiply in one window launch"
+    b = E.vector_reorder(O.x_glibc(n) + 0.3, perm)
+    x1, it1, rel1 = fused.cg(b, max_iter=400, rtol=1e-10, check_every=2)
+    x2, it2, rel2 = separate.cg(b, max_iter=400, rtol=1e-10, check_every=2)
+    _, it_cpu, _ = cpu_cg(A, O.x_glibc(n) + 0.3, 400, 1e-10)
+    assert rel1 <= 1e-10 and rel2 <= 1e-10 and abs(it1 - it_cpu) <= 2 and abs(it2 - it_cpu) <= 2, (it1, it2, it_cpu)
+    assert np.linalg.norm(x1 - x2) <= 1e-9 * np.linalg.norm(x2)
+    x = E.vector_recover(x1, perm)
+    assert np.linalg.norm(A @ x - (O.x_glibc(n) + 0.3)) <= 2e-10 * np.linalg.norm(O.x_glibc(n) + 0.3)
+    # fixed summation order in both: a second solve repeats the first bit for bit on plain storage
+    if not sym:
+        x1b, _, rel1b = fused.cg(b, max_iter=400, rtol=1e-10, check_every=2)
+        assert np.array_equal(x1, x1b) and rel1 == rel1b
