@@ -117,7 +117,30 @@ __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, const double
 {
     const double alpha = sum_partials(s + (A_RZ0 + 2 * cur) * kMaxGrid) / sum_partials(s + A_PQ * kMaxGrid);
     double rz = 0.0, rr = 0.0;
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads) {
+    // four grid strides per trip: sixteen (twenty with a preconditioner) loads in flight per thread instead of four -- a thread
+    // sees only seven elements of the bench matrix's vectors, and one load round trip per element was most of this kernel's time
+    const int stride = (int)gridDim.x * kThreads;
+    int i = blockIdx.x * kThreads + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {
+        double pv[4], qv[4], xv[4], rv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pv[u] = p[i + u * stride];
+            qv[u] = q[i + u * stride];
+            xv[u] = x[i + u * stride];
+            rv[u] = r[i + u * stride];
+            dv[u] = dinv ? dinv[i + u * stride] : 1.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            x[i + u * stride] = fma(alpha, pv[u], xv[u]);
+            const double ri = fma(-alpha, qv[u], rv[u]);
+            r[i + u * stride] = ri;
+            rz = fma(ri, dinv ? ri * dv[u] : ri, rz);
+            rr = fma(ri, ri, rr);
+        }
+    }
+    for (; i < n; i += stride) {
         x[i] = fma(alpha, p[i], x[i]);
         const double ri = fma(-alpha, q[i], r[i]);
         r[i] = ri;
@@ -134,8 +157,20 @@ __global__ __launch_bounds__(kThreads) void cg_direction_kernel(int n, const dou
                                                                 const double* __restrict__ s, int cur)
 {
     const double beta = sum_partials(s + (A_RZ0 + 2 * (cur ^ 1)) * kMaxGrid) / sum_partials(s + (A_RZ0 + 2 * cur) * kMaxGrid);
-    for (int i = blockIdx.x * kThreads + threadIdx.x; i < n; i += gridDim.x * kThreads)
-        p[i] = fma(beta, p[i], dinv ? r[i] * dinv[i] : r[i]);
+    const int stride = (int)gridDim.x * kThreads;
+    int i = blockIdx.x * kThreads + threadIdx.x;
+    for (; i + 3 * stride < n; i += 4 * stride) {  // (as in the update kernel: the loads of four strides in flight together)
+        double pv[4], rv[4], dv[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+            pv[u] = p[i + u * stride];
+            rv[u] = r[i + u * stride];
+            dv[u] = dinv ? dinv[i + u * stride] : 1.0;
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) p[i + u * stride] = fma(beta, pv[u], dinv ? rv[u] * dv[u] : rv[u]);
+    }
+    for (; i < n; i += stride) p[i] = fma(beta, p[i], dinv ? r[i] * dinv[i] : r[i]);
 }
 
 // everything a solve owns; released on every way out
