@@ -153,6 +153,7 @@ SIGNATURES = {
     "ehyb_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
     "ehyb_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
     "ehyb_dev_sync": (C.c_int, []),
+    "ehyb_dev_mem_info": (C.c_int, [_P(C.c_size_t), _P(C.c_size_t)]),
     "ehyb_measure_read_bw": (C.c_int, [C.c_size_t, C.c_int, _dp]),
     "ehyb_cg": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp, _ip, _dp]),
     "ehyb_pcg": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp, _ip, _dp]),

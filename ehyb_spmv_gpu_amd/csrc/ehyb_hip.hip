@@ -982,6 +982,12 @@ int ehyb_d2h(void* dst, const void* src, size_t bytes)
     HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
     return EHYB_OK;
 }
+int ehyb_dev_mem_info(size_t* free_bytes, size_t* total_bytes)
+{
+    if (!free_bytes || !total_bytes) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_dev_mem_info: null argument");
+    HIP_TRY(hipMemGetInfo(free_bytes, total_bytes));
+    return EHYB_OK;
+}
 int ehyb_dev_sync(void)
 {
     HIP_TRY(hipDeviceSynchronize());

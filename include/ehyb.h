@@ -533,6 +533,8 @@ int ehyb_dev_free(void* ptr);
 int ehyb_h2d(void* dst_dev, const void* src_host, size_t bytes);
 int ehyb_d2h(void* dst_host, const void* src_dev, size_t bytes);
 int ehyb_dev_sync(void);
+/* free and total device memory in bytes (hipMemGetInfo): what a harness checks a plan's life cycle against */
+int ehyb_dev_mem_info(size_t* free_bytes, size_t* total_bytes);
 /* Streaming-read ceiling of this device: sums `bytes` of doubles `iters` times, returns GB/s. */
 int ehyb_measure_read_bw(size_t bytes, int iters, double* gbps);
 

@@ -140,3 +140,31 @@ def test_rows_that_are_not_in_column_order(E, O, gpu):
     for plan in (host, dev):
         bad, worst = O.check_tolerance(plan.spmv_host(x), y_ref, scale)
         assert bad == 0, worst
+
+
+def test_device_builder_gives_its_memory_back(E, O, gpu):
+    """Gigabytes of temporaries for a large matrix: after a plan is built on the device and destroyed again, the device has what
+    it had before (dozens of temporaries and seven arrays that stay: none may be left behind)."""
+    import ctypes as C
+
+    lib = E.host._lib.load()
+
+    def free_bytes():
+        f, t = C.c_size_t(), C.c_size_t()
+        lib.ehyb_dev_sync()
+        assert lib.ehyb_dev_mem_info(C.byref(f), C.byref(t)) == 0
+        return f.value
+
+    kw = dict(er_mode=2, fuse_er=2, direct=2, value_map=1)
+    cfg = E.make_config(symbolic=2, **kw)
+    m = E.Matrix.generate("rmat", 17, 1 << 20, 9, cfg=cfg)
+    m.reorder(cfg)
+    E.Plan(m, cfg).destroy()                     # first use: kernels loaded
+    free0 = free_bytes()
+    for _ in range(6):
+        plan = E.Plan(m, cfg)
+        assert plan.stats["er_partials"] > 0 and plan.stats["er_segments"] == 0
+        plan.array("pb_dst")                     # the streams fetched to the host as well
+        plan.destroy()
+    free1 = free_bytes()
+    assert free0 - free1 < (32 << 20), (free0, free1)
