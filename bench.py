@@ -753,6 +753,13 @@ def main():
         else:
             log(f"[bench] no live PMC measurement ({live_detail}): " + ("the table entry of this layout is quoted" if traffic else "format bytes are quoted"))
     real_bytes = traffic if traffic else k_fmt
+    # Successive multiplies of a plan walk every partition in alternating directions (cfg.ell_alternate), so a launch finds the
+    # tail of the one before it in the 256 MB Infinity Cache: the counters then see FEWER HBM bytes than the kernel consumes.
+    # `achieved` stays the rate at which the kernel consumed its streams (format bytes where the counters are below them),
+    # `traffic` / `hbm_GBps` say how much of it HBM delivered.
+    cache_share = max(0.0, 1.0 - traffic / k_fmt) if (traffic and k_fmt) else 0.0
+    if cache_share > 0.03:
+        real_bytes = k_fmt
     achieved = real_bytes / (k_ms * 1e-3) / 1e9
     roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
@@ -761,6 +768,10 @@ def main():
                                 "rocprofv3 PMC bytes per launch of this workload, storage and kernel (profiles/pmc_traffic.json)"
                                 if traffic else "format bytes per launch (what this layout makes the kernel move; no PMC measurement of exactly this layout on file)"),
                 "traffic_table": traffic_table, "traffic_live": live_detail if isinstance(live_detail, dict) else None,
+                "hbm_GBps": round(traffic / (k_ms * 1e-3) / 1e9, 1) if traffic else None,
+                "infinity_cache_share": round(cache_share, 4),
+                "achieved_basis": ("format bytes per launch: the counters show %.0f %% of them coming from the Infinity Cache (alternating walk of successive launches), "
+                                   "not from HBM" % (100 * cache_share)) if cache_share > 0.03 else "the bytes of bytes_basis",
                 "format_bytes_per_launch": k_fmt, "avg_launch_ms": round(k_ms, 5),
                 "alg_bytes_per_launch": k_alg, "alg_GBps": round(k_alg / (k_ms * 1e-3) / 1e9, 1),
                 "alg_frac": round(k_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),

@@ -76,7 +76,8 @@ class Config(C.Structure):
         ("er_queue", C.c_int32),
         ("symbolic", C.c_int32),
         ("cg_fused_dot", C.c_int32),
-        ("reserved", C.c_int32 * 26),
+        ("ell_alternate", C.c_int32),
+        ("reserved", C.c_int32 * 25),
     ]
 
 

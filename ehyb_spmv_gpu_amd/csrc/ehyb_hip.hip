@@ -145,6 +145,9 @@ struct EllArgs {
     // non-null (ehyb_cg): the workgroup also leaves sum over its rows of y[row] * x[row] in xy_out[blockIdx.x] -- the p.q of
     // a conjugate-gradient step falls out of the multiply (the rows' x sits in the window, y in registers or accumulators)
     double* __restrict__ xy_out;
+    // 1: the workgroup walks the slabs of a segment last to first.  Back-to-back multiplies of one plan alternate (cfg.ell_alternate):
+    // what the previous launch streamed LAST is what still sits in the 256 MB Infinity Cache, and this launch reads it FIRST.
+    int reverse;
 };
 
 // Workgroups are handed to the 8 XCDs round robin (b mod 8).  With this map XCD k gets the k-th
@@ -312,9 +315,9 @@ __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict
     if (A.stamps != nullptr && threadIdx.x == 0 &&
         g == A.items[2 * item_of_block(A.item_map, A.xcd_map)].x)
         A.stamps[4 * blockIdx.x + 1] = wall_clock64();
-    int s = sb + wave;
+    int s = sb + wave;  // (logical position in the segment's walk; the slab it stands for depends on the direction)
     while (s < se) {
-        ell_slab<INLINE_ER, SYM>(A, win, yacc, s, base, pe, lane, xy);
+        ell_slab<INLINE_ER, SYM>(A, win, yacc, A.reverse ? se - 1 - (s - sb) : s, base, pe, lane, xy);
         if (DYN) {
             int nx = 0;
             if (lane == 0) nx = atomicAdd(next_slab, 1);
@@ -475,7 +478,7 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
                                                                 const uint32_t* __restrict__ jump,
                                                                 const double* __restrict__ x,
                                                                 double* __restrict__ partial, int panel_cols, int probe_arg, int xcd_map,
-                                                                int* __restrict__ queue, int n_items)
+                                                                int* __restrict__ queue, int n_items, int reverse)
 {
     const int probe = PROBE ? probe_arg : 0;
     // probe (tools/panel_sweep.py, timing diagnostics only, results wrong): 1 no lane sums, 2 no stores,
@@ -534,11 +537,15 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
         if (item < 0) break;
         it = items[item];
     } else {
-        it = items[xcd_map ? xcd_item(blockIdx.x, gridDim.x) : (int)blockIdx.x];
+        // reverse (successive launches alternate, as the ELL launch does): the items last to first, the units of an item last to
+        // first, a unit's chunks last to first -- this launch starts with what the one before it left in the Infinity Cache
+        const int idx = xcd_map ? xcd_item(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+        it = items[reverse ? (int)gridDim.x - 1 - idx : idx];
     }
-  for (int un = it.x; un < it.y; ++un) {
+  for (int ui = it.x; ui < it.y; ++ui) {
+    const int un = reverse ? it.y - 1 - (ui - it.x) : ui;
     const int4 u = units[un];
-    if (un != it.x) __syncthreads();  // every wave is done with the previous panel
+    if (ui != it.x) __syncthreads();  // every wave is done with the previous panel
     // stage the panel: all of a thread's loads in flight before the first store (a 64 KiB panel is 16
     // double2 loads per thread; one load per loop trip would pay the memory latency 16 times)
     if (!(probe & 8)) {
@@ -567,13 +574,19 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
     // fetched one step ahead, so that the jump entries travel together with the values and column words instead
     // of behind them (a gather that waits for the flags doubled the latency per step: 345 -> 470 us on R-MAT 2^24).
     uint32_t f0[K], fn[K];
+    // the wave's steps: chunks c0 + K (wave + t WAVES) .., t = 0 .. steps - 1, walked up or down
+    const int first = c0 + K * wave;
+    const int steps = first < c1 ? (c1 - first + K * WAVES - 1) / (K * WAVES) : 0;
+    const int dc = reverse ? -K * WAVES : K * WAVES;
+    const int cstart = reverse ? first + (steps - 1) * K * WAVES : first;
 #pragma unroll
     for (int j = 0; j < K; ++j) {
-        const int cj = min(c0 + K * wave + j, c1 - 1);
+        const int cj = max(c0, min(cstart + j, c1 - 1));
         f0[j] = chunk[cj];
         fn[j] = chunk[cj + 1] - f0[j];
     }
-    for (int c = c0 + K * wave; c < c1; c += K * WAVES) {
+    int c = cstart;
+    for (int t = 0; t < steps; ++t, c += dc) {
         double v[K];
         uint32_t cw[K], jv[K];
 #pragma unroll
@@ -587,7 +600,7 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
         uint32_t g0[K], gn[K];  // the records of the next step
 #pragma unroll
         for (int j = 0; j < K; ++j) {
-            const int cj = min(c + K * WAVES + j, c1 - 1);
+            const int cj = max(c0, min(c + dc + j, c1 - 1));
             g0[j] = chunk[cj];
             gn[j] = chunk[cj + 1] - g0[j];
         }
@@ -762,6 +775,7 @@ static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long 
     A.win_cap = ell_win_cap(P->host);
     A.stamps = stamps;
     A.xy_out = xy_out;
+    A.reverse = 0;
     // on by default: plain storage 143 -> 134 us on the audikw_1-like matrix; cfg.xcd_map = 2 for the A/B
     A.xcd_map = P->host.sym ? 0 : (P->cfg.xcd_map != 2 ? 1 : 0);
     A.item_map = P->d_item_map;  // symmetric pairs: items are sorted heaviest first, dispatched in that order
@@ -780,7 +794,14 @@ static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t
     if (H.pb_assign && H.segs.empty()) return EHYB_OK;  // no partition kept its window: pass 2 of the panel residual assigns every row
     const size_t lds = ell_lds_bytes(H);
     const bool dyn = P->cfg.ell_variant != 3;
-    const EllArgs A = ell_args(P, x, y, stamps, xy_out);
+    EllArgs A = ell_args(P, x, y, stamps, xy_out);
+    // (automatic: where the stream does not fit the cache but the cache is still a fair share of it -- the walk from the short slabs
+    // up costs the tail of a workgroup a few per cent: audikw_1-like, 439 MB, 83.5 -> 76.0 us; every entry stored, 729 MB, 143.3 ->
+    // 136.8; 120 k rows, 65 MB, 15.4 -> 16.2; kkt3d-200, 2.56 GB, 481 -> 487)
+    if (!STAMP && (P->cfg.ell_alternate == 1 || (P->cfg.ell_alternate == 0 && H.stats.bytes_format_ell > (256ll << 20) && H.stats.bytes_format_ell <= (2048ll << 20)))) {
+        A.reverse = P->launch_parity;
+        P->launch_parity ^= 1;
+    }
     const bool sym = H.sym;
 #define ELL_GO(T, M, I, S)                                                                                  \
     {                                                                                                        \
@@ -852,9 +873,15 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
         const int resident = kNumCU * (wide ? 1 : 2);
         int* queue = (P->cfg.er_queue == 1 && xcd && u1 > resident) ? P->d_pb_queue : nullptr;
         const int grid = queue ? resident : u1;
+        // successive launches walk the entry stream in alternating directions (cfg.ell_alternate) where it does not fit the cache
+        int rev = 0;
+        if (!queue && !probe && (P->cfg.ell_alternate == 1 || (P->cfg.ell_alternate == 0 && H.pb_bytes > (256ll << 20)))) {
+            rev = P->panel_parity;
+            P->panel_parity ^= 1;
+        }
 #define PB_SCALE_P(T, D, PR)                                                                                                    \
     hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D, PR>), dim3(grid), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T)) + 1) * 8, st, (const int2*)P->d_pb_items1 + unit_begin, (const int4*)P->d_pb_units1, \
-                       P->d_pb_val, P->d_pb_colf, P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, probe, xcd, queue, u1)
+                       P->d_pb_val, P->d_pb_colf, P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, probe, xcd, queue, u1, rev)
 #define PB_SCALE(T, D)                  \
     if (probe) PB_SCALE_P(T, D, true);  \
     else PB_SCALE_P(T, D, false)

@@ -64,6 +64,7 @@ struct Config {
     int er_queue;           // 1 per-XCD work queues with stealing (A/B arm), 2 one workgroup per item (default)
     int symbolic;           // where the panel form is built by ehyb_plan_create[_segs]: 1 host, 2 device (default)
     int cg_fused_dot;       // 1 on (default), 2 off
+    int ell_alternate;      // 0 automatic (streams that do not fit the Infinity Cache), 1 on, 2 off
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -295,4 +296,6 @@ struct ehyb_plan {
     int32_t* d_er_src = nullptr;
     int32_t* d_pb_src = nullptr;
     bool host_values_stale = false;  // the device values were refilled: the host copy no longer matches
+    int launch_parity = 0;           // direction of the next ELL launch's walk (cfg.ell_alternate)
+    int panel_parity = 0;            // the same for pass 1 of the panel residual
 };
