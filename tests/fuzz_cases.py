@@ -44,7 +44,9 @@ def random_config_kwargs(rng):
                 xcd_map=int(rng.choice([1, 2])), er_panel_threads=int(rng.choice([0, 512, 1024])), er_units1=int(rng.choice([0, 1, 7, 300])),
                 er_units2=int(rng.choice([0, 5])), graph_compress=int(rng.choice([0, 1, 2])),
                 # where the panel form is built when the plan is created and uploaded in one call (1 host, 2 device)
-                symbolic=int(rng.choice([1, 2])))
+                symbolic=int(rng.choice([1, 2])),
+                # successive multiplies walking the streams in alternating directions (0 by size, 1 always, 2 never)
+                ell_alternate=int(rng.choice([0, 1, 1, 2])))
 
 
 def build(E, O, seed):
