@@ -148,6 +148,7 @@ struct EllArgs {
     // 1: the workgroup walks the slabs of a segment last to first.  Back-to-back multiplies of one plan alternate (cfg.ell_alternate):
     // what the previous launch streamed LAST is what still sits in the 256 MB Infinity Cache, and this launch reads it FIRST.
     int reverse;
+    int reverse_items;  // with reverse, and more items than resident workgroups: workgroup b takes the items from the far end too
 };
 
 // Workgroups are handed to the 8 XCDs round robin (b mod 8).  With this map XCD k gets the k-th
@@ -161,9 +162,9 @@ __device__ __forceinline__ int xcd_item(int b, int n)
 
 // Which work item workgroup b takes: the tuned map of the plan (ehyb_plan_tune: the heaviest items on the XCDs that were
 // measured fastest), else one contiguous run of items per XCD (plain storage), else item b.
-__device__ __forceinline__ int item_of_block(const int* __restrict__ item_map, int xcd_map)
+__device__ __forceinline__ int item_of_block(const int* __restrict__ item_map, int xcd_map, int from_the_end = 0)
 {
-    const int b = (int)blockIdx.x;
+    const int b = from_the_end ? (int)gridDim.x - 1 - (int)blockIdx.x : (int)blockIdx.x;
     return item_map ? item_map[b] : (xcd_map ? xcd_item(b, (int)gridDim.x) : b);
 }
 
@@ -352,7 +353,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(SYM ? 4
     extern __shared__ __attribute__((aligned(16))) double win[];
     int* next_slab = reinterpret_cast<int*>(win + A.win_cap);  // one word behind the window
     if (STAMP && threadIdx.x == 0) A.stamps[4 * blockIdx.x + 0] = wall_clock64();
-    const int4 it = A.items[2 * item_of_block(A.item_map, A.xcd_map)];
+    const int4 it = A.items[2 * item_of_block(A.item_map, A.xcd_map, A.reverse_items)];
     const int lane = threadIdx.x & 63;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double xy = 0.0;
@@ -776,6 +777,7 @@ static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long 
     A.stamps = stamps;
     A.xy_out = xy_out;
     A.reverse = 0;
+    A.reverse_items = 0;
     // on by default: plain storage 143 -> 134 us on the audikw_1-like matrix; cfg.xcd_map = 2 for the A/B
     A.xcd_map = P->host.sym ? 0 : (P->cfg.xcd_map != 2 ? 1 : 0);
     A.item_map = P->d_item_map;  // symmetric pairs: items are sorted heaviest first, dispatched in that order
@@ -797,9 +799,11 @@ static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t
     EllArgs A = ell_args(P, x, y, stamps, xy_out);
     // (automatic: where the stream does not fit the cache but the cache is still a fair share of it -- the walk from the short slabs
     // up costs the tail of a workgroup a few per cent: audikw_1-like, 439 MB, 83.5 -> 76.0 us; every entry stored, 729 MB, 143.3 ->
-    // 136.8; 120 k rows, 65 MB, 15.4 -> 16.2; kkt3d-200, 2.56 GB, 481 -> 487)
-    if (!STAMP && (P->cfg.ell_alternate == 1 || (P->cfg.ell_alternate == 0 && H.stats.bytes_format_ell > (256ll << 20) && H.stats.bytes_format_ell <= (2048ll << 20)))) {
+    // 136.8; 120 k rows, 65 MB, 15.4 -> 16.2; kkt3d-200, 2.56 GB, 501.9 -> 473.7 once the items are taken from the far end too)
+    if (!STAMP && (P->cfg.ell_alternate == 1 || (P->cfg.ell_alternate == 0 && H.stats.bytes_format_ell > (256ll << 20) && H.stats.bytes_format_ell <= (8192ll << 20)))) {
         A.reverse = P->launch_parity;
+        // more than one round of workgroups: what ran in the last round is what the cache holds, so it runs first now
+        A.reverse_items = (A.reverse && n_items > kNumCU * (lds > 80 * 1024 ? 1 : 2)) ? 1 : 0;
         P->launch_parity ^= 1;
     }
     const bool sym = H.sym;

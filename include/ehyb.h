@@ -192,8 +192,9 @@ typedef struct ehyb_config {
     int32_t ell_alternate; /* successive multiplies of a plan walk the slabs of every partition in alternating directions, so that a
                               launch starts with what the one before it left in the 256 MB Infinity Cache (a solver multiplies with
                               the same matrix again and again): 0 = where the plan's stream is larger than that cache and at most
-                              2 GB (a smaller one stays resident anyway, of a larger one the cache holds too little to pay for the
-                              walk from the short slabs up), 1 = always, 2 = never (always first to last).  Pass 1 of the panel
+                              8 GB (a smaller one stays resident anyway, of a far larger one the cache holds too little to pay for
+                              the walk from the short slabs up), 1 = always, 2 = never (always first to last).  With more work items
+                              than resident workgroups the items are taken from the far end as well.  Pass 1 of the panel
                               residual alternates the same way                                                        */
     int32_t reserved[25];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
 } ehyb_config;
