@@ -543,6 +543,8 @@ def main():
     ap.add_argument("--no-plain-arm", action="store_true",
                     help="N=1 with symmetric pair storage: skip the extra plain-storage measurement of the same matrix")
     ap.add_argument("--no-dropin-arm", action="store_true", help="N=1: skip the run through the reference-named calls")
+    ap.add_argument("--ell-alternate", type=int, default=0,
+                    help="cfg.ell_alternate: 0 = automatic (successive multiplies walk streams of 256 MB - 8 GB in alternating directions), 1 = always, 2 = never")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic live (the table entry of the layout, else format bytes, is quoted)")
     ap.add_argument("--no-refill-arm", action="store_true",
@@ -611,7 +613,8 @@ def main():
 
     kw = {}
     for k, v in (("lds_doubles", args.lds_doubles), ("part_rows", args.part_rows), ("threads", args.threads),
-                 ("items_per_cu", args.items_per_cu), ("window_mode", args.window_mode), ("er_mode", args.er_mode)):
+                 ("items_per_cu", args.items_per_cu), ("window_mode", args.window_mode), ("er_mode", args.er_mode),
+                 ("ell_alternate", args.ell_alternate)):
         if v:
             kw[k] = v
     if world > 1 and os.environ.get("OMP_NUM_THREADS") == "1":
