@@ -545,6 +545,7 @@ def main():
     ap.add_argument("--no-dropin-arm", action="store_true", help="N=1: skip the run through the reference-named calls")
     ap.add_argument("--ell-alternate", type=int, default=0,
                     help="cfg.ell_alternate: 0 = automatic (successive multiplies walk streams of 256 MB - 8 GB in alternating directions), 1 = always, 2 = never")
+    ap.add_argument("--no-walk-arm", action="store_true", help="skip the side arm that times the same plan with every launch walking first to last")
     ap.add_argument("--no-live-pmc", action="store_true",
                     help="skip the two rocprofv3 --pmc child runs that measure roofline.traffic live (the table entry of the layout, else format bytes, is quoted)")
     ap.add_argument("--no-refill-arm", action="store_true",
@@ -831,6 +832,25 @@ def main():
                     "parity_after": {"rows_over_1e-12": b2, "worst_rel": w2}}
         refill = side_arm("numeric-phase arm", refill_case, log)
         log(f"[bench] numeric phase on the device: {refill}")
+    # ---- for the record: the same matrix and permutation with every launch walking its streams FIRST TO LAST (cfg.ell_alternate = 2).
+    # `value` is measured with the library's default, where successive multiplies of a plan alternate the direction and a launch
+    # starts with what the one before it left in the 256 MB Infinity Cache.
+    walk = None
+    if not args.no_walk_arm and args.ell_alternate == 0:
+        def walk_case():
+            cfg2 = E.make_config(partitioner=partitioner_for(E, gen), value_map=0, ell_alternate=2, **kw)
+            p2 = E.Plan(m, cfg2)
+            try:
+                if not args.no_tune:
+                    p2.tune(xp, yp)
+                r2 = p2.bench(xp, yp, stream, warmup=args.warmup, iters=args.steps, per_kernel=False)
+            finally:
+                p2.destroy()
+            t2 = r2["ms_total"] / args.steps
+            return {"first_to_last_GFLOPs": round(2.0 * nnz / t2 / 1e6, 2), "first_to_last_ms_per_step": round(t2, 5),
+                    "alternating_is_the_default": "cfg.ell_alternate = 0: successive multiplies of a plan walk streams of 256 MB - 8 GB in alternating directions"}
+        walk = side_arm("first-to-last arm", walk_case, log)
+        log(f"[bench] every launch first to last (ell_alternate = 2): {walk}")
     plan.destroy()
     del x_d, y_d
     m.free()
@@ -883,7 +903,7 @@ def main():
                    "sym_pairs": st["sym_pairs"], "stored_values": st["size_block_ell"],
                    "alg_bytes_per_spmv": st["bytes_alg"], "exchange": "none"},
         "alg_GBps": round((12 * nnz + 4 * (n + 1) + 16 * n) / (elapsed / args.steps) / 1e9, 1),
-        "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity,
+        "roofline": roofline, "cpu_baseline": cpu_baseline, "parity": parity, "walk": walk,
     }
     if tuned:
         out["tuned_item_map"] = tuned
