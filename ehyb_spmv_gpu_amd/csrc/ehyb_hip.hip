@@ -880,8 +880,10 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
         // successive launches walk the entry stream in alternating directions (cfg.ell_alternate) where it does not fit the cache
         int rev = 0;
         if (!queue && !probe && (P->cfg.ell_alternate == 1 || (P->cfg.ell_alternate == 0 && H.pb_bytes > (256ll << 20)))) {
+            // one direction per MULTIPLY: a multiply in parts (ehyb_spmv_part: one pass-1 launch per column segment) turns around
+            // with its first part
+            if (unit_begin == 0) P->panel_parity ^= 1;
             rev = P->panel_parity;
-            P->panel_parity ^= 1;
         }
 #define PB_SCALE_P(T, D, PR)                                                                                                    \
     hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D, PR>), dim3(grid), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T)) + 1) * 8, st, (const int2*)P->d_pb_items1 + unit_begin, (const int4*)P->d_pb_units1, \
