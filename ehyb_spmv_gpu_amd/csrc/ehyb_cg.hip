@@ -126,14 +126,14 @@ __global__ __launch_bounds__(kThreads) void cg_update_kernel(int n, const double
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
             pv[u] = p[i + u * stride];
-            qv[u] = q[i + u * stride];
-            xv[u] = x[i + u * stride];
+            qv[u] = __builtin_nontemporal_load(&q[i + u * stride]);   // q is dead after this kernel, x is not read again before the next
+            xv[u] = __builtin_nontemporal_load(&x[i + u * stride]);   // update: streamed past the caches, which hold the matrix's tail
             rv[u] = r[i + u * stride];
             dv[u] = dinv ? dinv[i + u * stride] : 1.0;
         }
 #pragma unroll
         for (int u = 0; u < 4; ++u) {
-            x[i + u * stride] = fma(alpha, pv[u], xv[u]);
+            __builtin_nontemporal_store(fma(alpha, pv[u], xv[u]), &x[i + u * stride]);
             const double ri = fma(-alpha, qv[u], rv[u]);
             r[i + u * stride] = ri;
             rz = fma(ri, dinv ? ri * dv[u] : ri, rz);
