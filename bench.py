@@ -28,9 +28,12 @@ N > 1  one process per GPU (the driver launches them with torch.distributed.run;
                halo exchange.
 
 Output: ONE JSON line on rank 0 with the contract's keys plus
-  roofline      the dominant kernel: real bytes (PMC traffic if profiles/pmc_traffic.json holds a
-                measurement of this workload, storage and kernel, else the format's bytes) / its mean launch
-                time (HIP events) / 8 TB/s; the algorithmic-byte rate beside it as alg_frac
+  roofline      the dominant kernel (roofline_block): frac = the counters' bytes per launch (rocprofv3 --pmc FETCH_SIZE /
+                WRITE_SIZE taken by this run, else the table entry of exactly this layout, else the format's bytes)
+                / the launch's share of one multiply in the graph-replayed loop (HIP events on the launch stream)
+                / 8 TB/s.  The counters see what the L2s request from the fabric -- HBM and Infinity-Cache hits alike --
+                so the rate is reported as fabric_GBps; frac_first_to_last is the same bytes on the cold-cache clock
+                (cfg.ell_alternate = 2), alg_frac SURVEY 8d's 12 nnz + 4 (rows + 1) + 8 cols + 8 rows on the same clock
   cpu_baseline  the CPU oracle (a port of the reference's CPU product) timed on this host.
 """
 import argparse
@@ -150,9 +153,9 @@ def live_pmc_traffic(workload, sym, kname, st, log, timeout_s=300):
                    sys.executable, os.path.join(tools, "pmc_run.py"), "--workload", workload] + ([] if sym else ["--plain"])
             if sub == "fetch":
                 cmd += ["--layout-out", os.path.join(tmp, "layout.json")]
-            p = subprocess.run(cmd, env=env, cwd="/tmp", capture_output=True, text=True, timeout=timeout_s)
-            if p.returncode != 0:
-                return None, f"rocprofv3 --pmc {counter} failed ({p.returncode}): {p.stderr[-200:]}"
+            rc, err = run_in_own_group(cmd, env, "/tmp", timeout_s)
+            if rc != 0:
+                return None, f"rocprofv3 --pmc {counter} failed ({rc}): {err[-200:]}"
         out = os.path.join(tmp, "traffic.json")
         p = subprocess.run([sys.executable, os.path.join(tools, "pmc_parse.py"), os.path.join(tmp, "fetch"), os.path.join(tmp, "write"), out,
                             "--workload", workload, "--storage", "sym" if sym else "plain", "--layout", os.path.join(tmp, "layout.json")],
@@ -168,12 +171,32 @@ def live_pmc_traffic(workload, sym, kname, st, log, timeout_s=300):
             return None, f"{len(parts)} kernels named {kname} in the counter files"
         total = float(sum(k["hbm_bytes_per_launch"] for k in parts))
         factor = (res.get("fetch_calibration") or {}).get("factor")
+        if not factor:
+            return None, "no calibration kernel in the counter files (FETCH_SIZE uncalibrated: not quoted)"
         log(f"[bench] PMC traffic of {kname} measured by this run: {total / 1e6:.2f} MB per launch (FETCH_SIZE x {factor:.5f} + WRITE_SIZE; {time.time() - t0:.1f}s)")
         return total, {"fetch_factor": factor, "launches": min(k["launches"] for k in parts), "seconds": round(time.time() - t0, 1)}
-    except (OSError, ValueError, KeyError, subprocess.TimeoutExpired) as e:
+    except Exception as e:  # noqa: BLE001  (a side diagnostic must never cost the headline its line)
         return None, f"{type(e).__name__}: {e}"
     finally:
         shutil.rmtree(tmp, ignore_errors=True)
+
+
+def run_in_own_group(cmd, env, cwd, timeout_s):
+    """A child in its own process group, so that a timeout ends the profiler AND the program it started (the group this
+    call created, nothing else).  -> (return code, tail of stderr)"""
+    import signal
+
+    p = subprocess.Popen(cmd, env=env, cwd=cwd, stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True, start_new_session=True)
+    try:
+        _, err = p.communicate(timeout=timeout_s)
+        return p.returncode, err or ""
+    except subprocess.TimeoutExpired:
+        try:
+            os.killpg(p.pid, signal.SIGKILL)
+        except OSError:
+            pass
+        p.wait()
+        return -9, f"timed out after {timeout_s}s"
 
 
 def self_launch(args):
@@ -462,9 +485,16 @@ def one_gpu_case(E, O, np, workload, sym, kw, steps, warmup, log, want_parity=Tr
            "er_kernel_avg_launch_ms": round(r["ms_er_avg"], 5) if (st["nnz_er"] and not st["er_inline"]) else None,
            "nnz_ell": st["nnz_ell"], "nnz_er": st["nnz_er"], "stored_values": st["size_block_ell"],
            "format_bytes_per_spmv": st["bytes_format"], "alg_bytes_per_spmv": st["bytes_alg"],
-           "real_frac_of_8TBps": round(st["bytes_format"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+           # what the FORMAT makes the kernels move (an upper bound of the traffic: units of one panel share an XCD's L2) ...
+           "format_frac_of_8TBps": round(st["bytes_format"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+           # ... SURVEY 8d's algorithmic bytes ...
            "alg_frac_of_8TBps": round(st["bytes_alg"] / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
            "pre_step_s": round(t_pre, 1)}
+    # ... and the counters' bytes where profiles/pmc_traffic.json holds a measurement of exactly this layout
+    pmc = pmc_traffic(workload, st["sym_pairs"] > 0, dominant_kernel(st, r["ms_ell_avg"], r["ms_er_avg"]), st)
+    if pmc and (st["nnz_ell"] == 0 or st["nnz_er"] == 0 or st["er_inline"] > 0):   # one kernel (pair) is the whole multiply
+        out["pmc_bytes_per_spmv"] = pmc
+        out["pmc_frac_of_8TBps"] = round(pmc / (ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
     if want_parity:
         bad, worst = O.check_tolerance(E.vector_recover(yd.download(), m.reorder_list), y_cpu, scale)
         out["parity"] = {"rows_over_1e-12": bad, "worst_rel": worst}
@@ -521,6 +551,101 @@ def side_arm(name, fn, log):
     except (Exception, SystemExit) as err:  # noqa: BLE001
         log(f"[bench] {name} FAILED: {err}")
         return {"error": str(err) or type(err).__name__}
+
+
+def side_arm_pair(name, fn, log):
+    """side_arm for a measurement that returns (value or None, detail): a failure of any kind becomes (None, what happened)."""
+    try:
+        return fn()
+    except (Exception, SystemExit) as err:  # noqa: BLE001
+        log(f"[bench] {name} FAILED: {err}")
+        return None, f"{type(err).__name__}: {err}"
+
+
+def alg_bytes_split(st):
+    """SURVEY 8d's algorithmic bytes of ONE SpMV, B_alg = 12 nnz + 4 (rows + 1) + 8 cols + 8 rows, split over the launches of
+    a multiply so that the shares add up to B_alg: the launch that writes every row of y (the ELL launch -- or the residual
+    launch(es) of a plan without one: R-MAT in panel form) carries the row-pointer and vector terms, a residual launch
+    BESIDE an ELL launch carries 12 B per entry of its own.  -> (ell share, residual share)"""
+    rows, cols = int(st["n_rows"]), int(st["n_cols"])
+    vec = 4 * (rows + 1) + 8 * cols + 8 * rows
+    inline = st["er_inline"] > 0
+    nnz_er = int(st["nnz_er"])
+    if inline or nnz_er == 0:
+        return 12 * (int(st["nnz_ell"]) + nnz_er) + vec, 0
+    if int(st["nnz_ell"]) == 0 and int(st["n_items"]) == 0:
+        return 0, 12 * nnz_er + vec          # no ELL launch at all: the residual launches are the whole multiply
+    return 12 * int(st["nnz_ell"]) + vec, 12 * nnz_er
+
+
+def dominant_kernel(st, ell_ms, er_ms):
+    """Name of the launch (pair) a multiply spends most of its time in."""
+    if st["er_inline"] > 0 or st["nnz_er"] == 0 or er_ms <= ell_ms:
+        return "ehyb_ell_kernel"
+    return "ehyb_pb_scale_kernel+ehyb_pb_reduce_kernel" if st["er_partials"] > 0 else "ehyb_er_kernel"
+
+
+def roofline_block(st, ell_ms, er_ms, step_ms, traffic, bytes_basis, first_to_last_step_ms=None):
+    """The `roofline` object of the JSON line for the dominant launch of a multiply.
+      st        ehyb_plan_stats of the plan
+      ell_ms, er_ms   per-launch averages between HIP event pairs (second pass of ehyb_spmv_bench): used for the SHARES only
+      step_ms   mean time of one multiply in the graph-replayed loop between two HIP events on the launch stream; the launch
+                time the fractions are taken on is its share of THAT, so `frac` follows from the loop, not from a pass that
+                pays an event pair per launch
+      traffic   bytes per launch from the PMC counters (FETCH_SIZE x calibration + WRITE_SIZE) or None
+    frac      = traffic (else format bytes) / launch time / 8 TB/s -- ALWAYS on the counters when they exist.  FETCH_SIZE counts what
+                the L2s request from the fabric, whether HBM or the 256 MB Infinity Cache answers (MI355X_MICROARCH.md), so this is a
+                FABRIC rate (`fabric_GBps`), an upper bound of the HBM rate; counters below the format's bytes mean L2 hits (`l2_share`).
+    alg_frac  = SURVEY 8d's bytes (alg_bytes_split) / launch time / 8 TB/s."""
+    inline = st["er_inline"] > 0
+    empty = st["nnz_er"] == 0
+    if inline or empty:
+        er_ms = 0.0   # no residual launch: the interval between the two events is event overhead
+    alg_ell, alg_er = alg_bytes_split(st)
+    fmt_ell = int(st["bytes_format_ell"])
+    fmt_er = int(st["bytes_format"]) - fmt_ell
+    kname = dominant_kernel(st, ell_ms, er_ms)
+    tot = ell_ms + er_ms
+    if kname == "ehyb_ell_kernel":
+        share, k_alg, k_fmt, k_event_ms = (ell_ms / tot if tot > 0 else 1.0), alg_ell, fmt_ell, ell_ms
+    else:
+        share, k_alg, k_fmt, k_event_ms = er_ms / tot, alg_er, fmt_er, er_ms
+    k_ms = step_ms * share
+    real_bytes = traffic if traffic else k_fmt
+    achieved = real_bytes / (k_ms * 1e-3) / 1e9
+    out = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+           "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic, "bytes_basis": bytes_basis,
+           "fabric_GBps": round(traffic / (k_ms * 1e-3) / 1e9, 1) if traffic else None,
+           "fabric_note": "FETCH_SIZE counts L2 misses served by the fabric: HBM and Infinity-Cache hits alike (no counter of this rocprofv3 tells them apart)",
+           "l2_share": round(max(0.0, 1.0 - traffic / k_fmt), 4) if (traffic and k_fmt) else None,
+           "format_bytes_per_launch": k_fmt, "avg_launch_ms": round(k_ms, 5), "avg_launch_ms_basis": "graph-replayed loop between two HIP events x the launch's share of a multiply",
+           "event_bracketed_launch_ms": round(k_event_ms, 5),
+           "alg_bytes_per_launch": k_alg, "alg_GBps": round(k_alg / (k_ms * 1e-3) / 1e9, 1),
+           "alg_frac": round(k_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+           "ell_kernel_avg_launch_ms": round(step_ms * (ell_ms / tot if tot > 0 else 1.0), 5),
+           "er_kernel_avg_launch_ms": None if (inline or empty) else round(step_ms * er_ms / tot, 5),
+           "residual": "empty" if empty else ("inline in the ELL launch" if inline else
+                                              ("panel form: two launches (x panels, then y blocks in LDS)" if st["er_partials"] > 0 else "own launch (CSR segments)")),
+           "format_bytes_per_spmv": int(st["bytes_format"]),
+           "whole_spmv_real_frac": round(int(st["bytes_format"]) / (step_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
+           "whole_spmv_alg_GBps": round(int(st["bytes_alg"]) / (step_ms * 1e-3) / 1e9, 1)}
+    if kname != "ehyb_ell_kernel":
+        # what round 3 printed as alg bytes of the residual: 12 B per entry + the 8 B gathered x entry of a CSR walk -- a model of
+        # that kernel's traffic, not SURVEY 8d's figure
+        out["gather_model_bytes_per_launch"] = 20 * int(st["nnz_er"]) + 16 * int(st["rows_er"])
+    if first_to_last_step_ms:
+        add_first_to_last(out, first_to_last_step_ms, step_ms)
+    return out
+
+
+def add_first_to_last(roofline, first_to_last_step_ms, step_ms):
+    """`frac` is the steady state of a loop of multiplies (cfg.ell_alternate: a launch starts with what the one before it left in the
+    Infinity Cache); a single multiply after other work gets the cold-cache time.  Same bytes, the other clock."""
+    k_ms = roofline["avg_launch_ms"] * first_to_last_step_ms / step_ms
+    b = roofline["traffic"] if roofline["traffic"] else roofline["format_bytes_per_launch"]
+    roofline["first_to_last_launch_ms"] = round(k_ms, 5)
+    roofline["frac_first_to_last"] = round(b / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
+    roofline["alg_frac_first_to_last"] = round(roofline["alg_bytes_per_launch"] / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4)
 
 
 def main():
@@ -735,57 +860,25 @@ def main():
     empty = st["nnz_er"] == 0
     if inline or empty:
         er_ms = 0.0  # no residual launch: the interval between the two events is event overhead
-    rows, cols = st["n_rows"], st["n_cols"]
-    nnz_ell_launch = st["nnz_ell"] + (st["nnz_er"] if inline else 0)
-    alg_ell = 12 * nnz_ell_launch + 4 * (rows + 1) + 8 * cols + 8 * rows
-    alg_er = 0 if (inline or empty) else 12 * st["nnz_er"] + 8 * st["nnz_er"] + 16 * st["rows_er"]
-    fmt_ell = st["bytes_format_ell"]
-    fmt_er = st["bytes_format"] - fmt_ell
-    if er_ms > ell_ms:
-        # the residual launch(es): ehyb_er_kernel (CSR segments) or the two passes of the panel form
-        kname = "ehyb_pb_scale_kernel+ehyb_pb_reduce_kernel" if st["er_partials"] > 0 else "ehyb_er_kernel"
-        k_ms, k_alg, k_fmt = er_ms, alg_er, fmt_er
-    else:
-        kname, k_ms, k_alg, k_fmt = "ehyb_ell_kernel", ell_ms, alg_ell, fmt_ell
+    step_ms = r["ms_total"] / min(args.steps, 200)   # the graph-replayed loop between two HIP events on the launch stream
+    kname = dominant_kernel(st, ell_ms, er_ms)
     traffic = pmc_traffic(args.workload, st["sym_pairs"] > 0, kname, st)
     traffic_table, live_detail = traffic, None
     if not args.no_live_pmc and not args.mtx:
         # the counters taken by THIS run (child processes under rocprofv3, after the timed loop: nothing of it is inside `value`)
-        live, live_detail = live_pmc_traffic(args.workload, st["sym_pairs"] > 0, kname, st, log)
+        live, live_detail = side_arm_pair("live PMC traffic", lambda: live_pmc_traffic(args.workload, st["sym_pairs"] > 0, kname, st, log), log)
         if live:
             traffic = live
         else:
             log(f"[bench] no live PMC measurement ({live_detail}): " + ("the table entry of this layout is quoted" if traffic else "format bytes are quoted"))
-    real_bytes = traffic if traffic else k_fmt
-    # Successive multiplies of a plan walk every partition in alternating directions (cfg.ell_alternate), so a launch finds the
-    # tail of the one before it in the 256 MB Infinity Cache: the counters then see FEWER HBM bytes than the kernel consumes.
-    # `achieved` stays the rate at which the kernel consumed its streams (format bytes where the counters are below them),
-    # `traffic` / `hbm_GBps` say how much of it HBM delivered.
-    cache_share = max(0.0, 1.0 - traffic / k_fmt) if (traffic and k_fmt) else 0.0
-    if cache_share > 0.03:
-        real_bytes = k_fmt
-    achieved = real_bytes / (k_ms * 1e-3) / 1e9
-    roofline = {"bound": "hbm", "kernel": kname, "achieved": round(achieved, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                "frac": round(achieved / HBM_PEAK_GBPS, 4), "traffic": traffic,
-                "bytes_basis": ("rocprofv3 PMC bytes per launch measured by this run (tools/pmc_run.py under --pmc FETCH_SIZE and --pmc WRITE_SIZE, "
-                                "separate passes, FETCH_SIZE calibrated on a 1 GiB streaming read in the same process)" if (traffic and traffic is not traffic_table) else
-                                "rocprofv3 PMC bytes per launch of this workload, storage and kernel (profiles/pmc_traffic.json)"
-                                if traffic else "format bytes per launch (what this layout makes the kernel move; no PMC measurement of exactly this layout on file)"),
-                "traffic_table": traffic_table, "traffic_live": live_detail if isinstance(live_detail, dict) else None,
-                "hbm_GBps": round(traffic / (k_ms * 1e-3) / 1e9, 1) if traffic else None,
-                "infinity_cache_share": round(cache_share, 4),
-                "achieved_basis": ("format bytes per launch: the counters show %.0f %% of them coming from the Infinity Cache (alternating walk of successive launches), "
-                                   "not from HBM" % (100 * cache_share)) if cache_share > 0.03 else "the bytes of bytes_basis",
-                "format_bytes_per_launch": k_fmt, "avg_launch_ms": round(k_ms, 5),
-                "alg_bytes_per_launch": k_alg, "alg_GBps": round(k_alg / (k_ms * 1e-3) / 1e9, 1),
-                "alg_frac": round(k_alg / (k_ms * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                "ell_kernel_avg_launch_ms": round(ell_ms, 5),
-                "er_kernel_avg_launch_ms": None if (inline or empty) else round(er_ms, 5),
-                "residual": "empty" if empty else ("inline in the ELL launch" if inline else
-                                                   ("panel form: two launches (x panels, then y blocks in LDS)" if st["er_partials"] > 0 else "own launch (CSR segments)")),
-                "format_bytes_per_spmv": st["bytes_format"],
-                "whole_spmv_real_frac": round(st["bytes_format"] / ((ell_ms + er_ms) * 1e-3) / 1e9 / HBM_PEAK_GBPS, 4),
-                "whole_spmv_alg_GBps": round(st["bytes_alg"] / ((ell_ms + er_ms) * 1e-3) / 1e9, 1)}
+    basis = ("rocprofv3 PMC bytes per launch measured by this run (tools/pmc_run.py under --pmc FETCH_SIZE and --pmc WRITE_SIZE, "
+             "separate passes, FETCH_SIZE calibrated on a 1 GiB streaming read in the same process)" if (traffic and traffic is not traffic_table) else
+             "rocprofv3 PMC bytes per launch of this workload, storage and kernel (profiles/pmc_traffic.json)"
+             if traffic else "format bytes per launch (what this layout makes the kernel move; no PMC measurement of exactly this layout on file)")
+    roofline = roofline_block(st, ell_ms, er_ms, step_ms, traffic, basis)
+    roofline["traffic_table"] = traffic_table
+    roofline["traffic_live"] = live_detail if isinstance(live_detail, dict) else None
+    achieved = roofline["achieved"]
     # the second ceiling SURVEY 8d asks for: a streaming read of 4 GiB measured on this box in this run
     try:
         import ctypes as C
@@ -850,6 +943,8 @@ def main():
             return {"first_to_last_GFLOPs": round(2.0 * nnz / t2 / 1e6, 2), "first_to_last_ms_per_step": round(t2, 5),
                     "alternating_is_the_default": "cfg.ell_alternate = 0: successive multiplies of a plan walk streams of 256 MB - 8 GB in alternating directions"}
         walk = side_arm("first-to-last arm", walk_case, log)
+        if walk and walk.get("first_to_last_ms_per_step"):
+            add_first_to_last(roofline, walk["first_to_last_ms_per_step"], step_ms)
         log(f"[bench] every launch first to last (ell_alternate = 2): {walk}")
     plan.destroy()
     del x_d, y_d

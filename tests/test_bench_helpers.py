@@ -114,3 +114,50 @@ def test_rmat_row_blocks_are_the_rows_of_the_full_matrix(E):
         # balanced on COST: a row counts for its edge samples plus two (per-row bytes of x, y and the partial sums)
         cost = np.diff(np.asarray(full.row_idx)[cuts0]) + 2 * np.diff(cuts0)
         assert cost.max() <= 1.25 * cost.mean() + 5000                    # (hub rows are lumpy, duplicates merged)
+
+
+# ---------------------------------------------------------------- the roofline block's three formulas (round-3 verdict)
+RMAT24 = {"n_rows": 16777216, "n_cols": 16777216, "nnz": 132718859, "nnz_ell": 0, "nnz_er": 132718859, "er_inline": 0, "er_partials": 46100000,
+          "n_items": 0, "rows_er": 9000000, "bytes_format": 2905087512, "bytes_format_ell": 0, "bytes_alg": 1928170632, "sym_pairs": 0}
+AUDIKW = {"n_rows": 943695, "n_cols": 943695, "nnz": 77728167, "nnz_ell": 77723000, "nnz_er": 5167, "er_inline": 12000, "er_partials": 0,
+          "n_items": 256, "rows_er": 3000, "bytes_format": 439100000, "bytes_format_ell": 439100000, "bytes_alg": 951611908, "sym_pairs": 31300000}
+
+
+def test_alg_bytes_are_survey_8d_for_every_kernel():
+    # a plan without an ELL launch: the two panel passes ARE the multiply -> 12 B per entry + row pointer + x + y, not 20 B per entry
+    ell, er = B.alg_bytes_split(RMAT24)
+    assert ell == 0 and er == 12 * 132718859 + 4 * (16777216 + 1) + 8 * 16777216 + 8 * 16777216 == RMAT24["bytes_alg"]
+    # one launch (inline residual): everything on the ELL launch
+    ell, er = B.alg_bytes_split(AUDIKW)
+    assert er == 0 and ell == 12 * 77728167 + 4 * 943696 + 16 * 943695 == 951611908
+    # ELL launch + residual launch: the shares add up to B_alg
+    two = dict(AUDIKW, er_inline=0, nnz_ell=70000000, nnz_er=7728167)
+    ell, er = B.alg_bytes_split(two)
+    assert ell + er == 951611908 and er == 12 * 7728167
+
+
+def test_frac_is_on_the_counters_whenever_they_exist():
+    # rmat-24 as the round-3 driver ran it: 583.5 us per multiply, PMC 2474 MB (below the 2905 MB of the format: L2 hits)
+    r = B.roofline_block(RMAT24, ell_ms=0.005, er_ms=0.565, step_ms=0.5835, traffic=2474e6, bytes_basis="pmc")
+    k_ms = 0.5835 * 0.565 / 0.570
+    assert r["kernel"] == "ehyb_pb_scale_kernel+ehyb_pb_reduce_kernel"
+    assert r["frac"] == pytest.approx(2474e6 / (k_ms * 1e-3) / 8e12, abs=2e-4) and 0.52 < r["frac"] < 0.55
+    assert r["alg_frac"] == pytest.approx(1928170632 / (k_ms * 1e-3) / 8e12, abs=2e-4) and 0.40 < r["alg_frac"] < 0.43
+    assert r["l2_share"] == pytest.approx(1 - 2474e6 / 2905087512, abs=1e-4)
+    assert r["fabric_GBps"] == r["achieved"] and "hbm_GBps" not in r and "infinity_cache_share" not in r
+    assert r["gather_model_bytes_per_launch"] == 20 * 132718859 + 16 * 9000000     # round 3's figure, under its own key
+    # no counters: format bytes, and it says nothing about the fabric
+    r = B.roofline_block(RMAT24, 0.005, 0.565, 0.5835, None, "format")
+    assert r["traffic"] is None and r["fabric_GBps"] is None and r["l2_share"] is None
+    assert r["frac"] == pytest.approx(2905087512 / (k_ms * 1e-3) / 8e12, abs=2e-4)
+
+
+def test_frac_follows_from_the_loop_and_carries_the_cold_cache_figure():
+    # the headline of round 3: 76.16 us per multiply in the loop, 77.97 us between per-launch event pairs, 454.66 MB counted
+    r = B.roofline_block(AUDIKW, ell_ms=0.07797, er_ms=0.004, step_ms=0.07616, traffic=454.66e6, bytes_basis="pmc", first_to_last_step_ms=0.08315)
+    assert r["kernel"] == "ehyb_ell_kernel" and r["avg_launch_ms"] == pytest.approx(0.07616, abs=1e-5)   # inline residual: one launch = one step
+    assert r["event_bracketed_launch_ms"] == pytest.approx(0.07797)
+    assert r["frac"] == pytest.approx(454.66e6 / 76.16e-6 / 8e12, abs=2e-4)                               # 0.746, not the 0.729 of the event pairs
+    assert r["frac_first_to_last"] == pytest.approx(454.66e6 / 83.15e-6 / 8e12, abs=2e-4)                 # 0.683
+    assert r["alg_frac"] > 1.5                                                                              # pairs are read once: SURVEY 8d cannot price them
+    assert r["l2_share"] == 0.0
