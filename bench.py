@@ -261,6 +261,34 @@ def partitioner_for(E, gen):  # ("file": a real matrix -- EHYB_PART_AUTO finds o
     return E.EHYB_PART_DEGREE if gen == "rmat" else E.EHYB_PART_AUTO
 
 
+def step_comm(args, D, dist, stage_on_cpu, log):
+    """The communicator of the C-side step (--step): libehyb.so's own RCCL communicator, made from a ncclUniqueId that
+    torch.distributed broadcasts.  -> (Comm or None, what the JSON line says).  `--step auto` falls back to the Python-issued
+    collectives when the communicator cannot be made on EVERY rank (an all-reduced verdict: no rank goes on alone), and says so;
+    `--step c` fails instead."""
+    import torch
+
+    if args.step == "python" or (args.step == "auto" and stage_on_cpu):
+        return None, "python: torch.distributed collectives, one C call per part" + (" (gloo functional mode)" if stage_on_cpu else "")
+    if stage_on_cpu:
+        raise SystemExit("bench.py: --step c needs the nccl backend (RCCL refuses ranks that share a device)")
+    comm, err = None, ""
+    try:
+        comm = D.make_comm()
+    except Exception as e:  # noqa: BLE001
+        err = f"{type(e).__name__}: {e}"
+    ok = torch.tensor([1.0 if comm is not None else 0.0], dtype=torch.float64, device=torch.device("cuda", torch.cuda.current_device()))
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if ok.item() < 1.0:
+        if comm is not None:
+            comm.destroy()
+        if args.step == "c":
+            raise SystemExit(f"bench.py: --step c: the RCCL communicator could not be made on every rank ({err or 'another rank failed'})")
+        log(f"[bench] C-side step unavailable ({err or 'another rank failed'}): torch.distributed collectives issued from Python instead")
+        return None, f"python (fallback: {err or 'another rank could not join the communicator'})"
+    return comm, "c: libehyb.so's RCCL communicator, ONE host call per multiply (ehyb_halo_spmv / ehyb_gather_spmv)"
+
+
 def run_weak(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     """N > 1, weak scaling: the N = 1 matrix once per GPU -- N audikw_1-like grids stacked along z,
     rank r owning (and generating) block r only -- and a halo exchange of the x entries of the two
@@ -285,7 +313,8 @@ def run_weak(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     t0 = time.time()
     L = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, symmetric=True)  # partition + permute the diagonal block, ghost slots
     del I, J
-    sh = D.HaloSpmv(L, dev, overlap=not args.no_overlap, stage_on_cpu=stage_on_cpu)
+    comm, step_impl = step_comm(args, D, dist, stage_on_cpu, log)
+    sh = D.HaloSpmv(L, dev, overlap=not args.no_overlap, stage_on_cpu=stage_on_cpu, comm=comm)
     sh.set_x_local(x[r0:r1])
     st = sh.plan.stats
     log(f"[bench] rank 0: reorder + plan in {time.time() - t0:.1f}s: ell {st['nnz_ell']} residual {st['nnz_er']} "
@@ -313,12 +342,16 @@ def run_weak(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
                        "window_mode": "halo" if cfg.window_mode != 1 else "reference",
                        "sym_pairs_rank0": st["sym_pairs"], "stored_values_rank0": st["size_block_ell"],
                        "ghost_slots_per_gpu_max": int(mx[0].item()), "ghost_slots_total": int(tot[1].item()),
+                       "step_issued_by": step_impl,
                        "exchange": "halo: gather of the requested x entries + RCCL all_to_all_single into the ghost slots, "
                                    "overlapped with the ELL phase" if not stage_on_cpu else "halo via gloo point-to-point (functional mode)"},
             "alg_GBps": round((12 * nnz + 4 * (n_glob + 1) + 16 * n_glob) / (elapsed / args.steps) / 1e9, 1),
             "roofline": None, "cpu_baseline": None, "parity": {"rows_over_1e-12": bad, "worst_rel": worst},
         }
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.destroy()
 
 
 def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
@@ -377,10 +410,11 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     shares = [float(v) for v in args.chunk_shares.split(",")] if args.chunk_shares else ([0.25, 0.75] if args.chunks == 2 else None)
     L = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, symmetric=symmetric, exchange=args.exchange, chunks=args.chunks, chunk_shares=shares)
     del I, J
+    comm, step_impl = step_comm(args, D, dist, stage_on_cpu, log)
     if args.exchange == "halo":
-        sh = D.HaloSpmv(L, dev, overlap=not args.no_overlap, stage_on_cpu=stage_on_cpu, mode=args.exchange_mode)
+        sh = D.HaloSpmv(L, dev, overlap=not args.no_overlap, stage_on_cpu=stage_on_cpu, mode=args.exchange_mode, comm=comm)
     else:
-        sh = D.GatherSpmv(L, dev, overlap=not args.no_overlap, stage_on_cpu=stage_on_cpu)
+        sh = D.GatherSpmv(L, dev, overlap=not args.no_overlap, stage_on_cpu=stage_on_cpu, comm=comm)
     sh.set_x_local(x[r0:r1])
     st = sh.plan.stats
     log(f"[bench] rank 0: rows [{r0},{r1}) reorder + plan in {time.time() - t0:.1f}s: ell {st['nnz_ell']} residual {st['nnz_er']} "
@@ -426,10 +460,13 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
                        "lds_doubles": int(cfg.lds_doubles), "part_rows": int(cfg.part_rows), "threads": int(cfg.threads),
                        "exchange": ("RCCL all_gather_into_tensor of the x segments (padded to %d doubles each), overlapped with the ELL phase" % sh.seg_len)
                        if args.exchange == "allgather" else
-                       "halo: gather of the requested x entries + one RCCL all_to_all_single per exchange step straight into the ghost "
+                       ("halo: gather of the requested x entries + one group of ncclSend / ncclRecv pairs per exchange step (all_to_all pattern, issued "
+                        "from C on the communicator's own stream) straight into the ghost " if comm is not None else
+                        "halo: gather of the requested x entries + one RCCL all_to_all_single per exchange step straight into the ghost ") +
                        "columns; own-column panels and the panels of the chunks already delivered multiply while the next chunk travels",
                        "exchange_doubles_received_all_gpus": words,
-                       "exchange_steps": L.chunks, "exchange_mode": args.exchange_mode if args.exchange == "halo" else "all_gather_into_tensor",
+                       "step_issued_by": step_impl,
+                       "exchange_steps": L.chunks, "exchange_mode": ("grouped ncclSend/ncclRecv pairs" if comm is not None else args.exchange_mode) if args.exchange == "halo" else ("ncclAllGather" if comm is not None else "all_gather_into_tensor"),
                        "pipelined": bool(args.exchange == "halo" and not args.no_overlap),
                        "recv_doubles_by_rank_step_peer": [[[int(v) for v in row.reshape(L.chunks, world)[k].tolist()] for k in range(L.chunks)]
                                                           for row in vol.cpu().numpy()] if world <= 8 else None,
@@ -452,6 +489,9 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
             "roofline": None, "cpu_baseline": None, "parity": {"rows_over_1e-12": bad, "worst_rel": worst},
         }
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        torch.cuda.synchronize()
+        comm.destroy()
 
 
 def one_gpu_case(E, O, np, workload, sym, kw, steps, warmup, log, want_parity=True, y_cpu=None, scale=None, x=None):
@@ -691,6 +731,10 @@ def main():
     ap.add_argument("--chunk-shares", default="", help="N>1 halo: share of every owner's ghost columns per chunk, e.g. 0.3,0.7 (default: 0.25,0.75 for two chunks, else equal)")
     ap.add_argument("--exchange-mode", default="a2a", choices=["a2a", "p2p"],
                     help="N>1 halo: a2a = one all_to_all_single per exchange step; p2p = grouped isend/irecv pairs (explicit, never a fallback)")
+    ap.add_argument("--step", default="auto", choices=["auto", "c", "python"],
+                    help="N>1: who issues the exchange -- c = libehyb.so's own RCCL communicator, ONE C call per multiply (ehyb_halo_spmv / "
+                         "ehyb_gather_spmv); python = torch.distributed collectives issued from Python, one C call per part (the A/B arm, and "
+                         "the only way over gloo); auto = c on the nccl backend")
     ap.add_argument("--no-single-gpu-anchor", action="store_true",
                     help="N>1 strong: skip the run of the same matrix on rank 0's GPU alone (the N = 1 point inside the N > 1 line)")
     ap.add_argument("--no-tune", action="store_true", help="N=1: skip ehyb_plan_tune (the item -> workgroup map stays the built-in one)")

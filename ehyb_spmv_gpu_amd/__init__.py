@@ -18,6 +18,8 @@ from .host import (  # noqa: F401
     EhybError,
     Matrix,
     Plan,
+    SpmvGraph,
+    Stream,
     device_count,
     entry_order,
     host_threads,

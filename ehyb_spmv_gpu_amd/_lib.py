@@ -135,6 +135,10 @@ SIGNATURES = {
     "ehyb_plan_host_array": (C.c_int, [_vp, C.c_int, _P(_vp), _i64p]),
     "ehyb_spmv": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ehyb_spmv_phase": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
+    "ehyb_spmv_walk": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int]),
+    "ehyb_spmv_graph_create": (C.c_int, [_vp, _vp, _vp, C.c_int, _P(_vp)]),
+    "ehyb_graph_launch": (C.c_int, [_vp, _vp]),
+    "ehyb_graph_destroy": (None, [_vp]),
     "ehyb_plan_tune": (C.c_int, [_vp, _vp, _vp, C.c_int, _dp, _dp]),
     "ehyb_spmv_part": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "ehyb_plan_col_segs": (C.c_int, [_vp, _ip]),
@@ -142,6 +146,18 @@ SIGNATURES = {
     "ehyb_step_pack": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp]),
     "ehyb_step_part": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ehyb_halo_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp]),
+    "ehyb_rccl_version": (C.c_int, [_ip, C.c_char_p, C.c_int]),
+    "ehyb_comm_unique_id": (C.c_int, [_vp]),
+    "ehyb_comm_create": (C.c_int, [_vp, C.c_int, C.c_int, _P(_vp)]),
+    "ehyb_comm_destroy": (None, [_vp]),
+    "ehyb_comm_info": (C.c_int, [_vp, _ip, _ip, _P(_vp)]),
+    "ehyb_comm_allreduce_sum": (C.c_int, [_vp, _vp, C.c_int64, _vp]),
+    "ehyb_comm_allgather": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
+    "ehyb_halo_create": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_int32), C.c_int64, _i64p, _i64p, _P(_vp)]),
+    "ehyb_halo_destroy": (None, [_vp]),
+    "ehyb_halo_spmv": (C.c_int, [_vp, _vp, _vp, _vp]),
+    "ehyb_halo_graph": (C.c_int, [_vp, C.c_int, _ip]),
+    "ehyb_gather_spmv": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "ehyb_spmv_bench": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _dp, _dp, _dp]),
     "ehyb_spmv_host": (C.c_int, [_vp, _dp, _dp, C.c_int]),
     "ehyb_plan_set_values": (C.c_int, [_vp, _vp, C.c_int64, _vp, C.c_int, _vp]),
@@ -154,6 +170,9 @@ SIGNATURES = {
     "ehyb_h2d": (C.c_int, [_vp, _vp, C.c_size_t]),
     "ehyb_d2h": (C.c_int, [_vp, _vp, C.c_size_t]),
     "ehyb_dev_sync": (C.c_int, []),
+    "ehyb_stream_create": (C.c_int, [_P(_vp)]),
+    "ehyb_stream_destroy": (C.c_int, [_vp]),
+    "ehyb_stream_sync": (C.c_int, [_vp]),
     "ehyb_dev_mem_info": (C.c_int, [_P(C.c_size_t), _P(C.c_size_t)]),
     "ehyb_measure_read_bw": (C.c_int, [C.c_size_t, C.c_int, _dp]),
     "ehyb_cg": (C.c_int, [_vp, _vp, _vp, C.c_int, C.c_double, C.c_int, _vp, _ip, _dp]),

@@ -787,6 +787,16 @@ static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long 
 
 // ell_variant: 0/1 = LDS slab counter (default), 3 = static round-robin (A/B arm, tools/sweep.py --variants)
 
+// The walk direction a caller asked for (ehyb_spmv_walk) while its call is on the stack: -1 = the plan's own alternation.
+static thread_local int t_walk = -1;
+namespace {
+struct WalkScope {
+    int saved;
+    explicit WalkScope(int w) : saved(t_walk) { t_walk = w; }
+    ~WalkScope() { t_walk = saved; }
+};
+}  // namespace
+
 template <bool STAMP>
 static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t st, bool inl, unsigned long long* stamps, double* xy_out = nullptr)
 {
@@ -800,11 +810,13 @@ static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t
     // (automatic: where the stream does not fit the cache but the cache is still a fair share of it -- the walk from the short slabs
     // up costs the tail of a workgroup a few per cent: audikw_1-like, 439 MB, 83.5 -> 76.0 us; every entry stored, 729 MB, 143.3 ->
     // 136.8; 120 k rows, 65 MB, 15.4 -> 16.2; kkt3d-200, 2.56 GB, 501.9 -> 473.7 once the items are taken from the far end too)
-    if (!STAMP && (P->cfg.ell_alternate == 1 || (P->cfg.ell_alternate == 0 && H.stats.bytes_format_ell > (256ll << 20) && H.stats.bytes_format_ell <= (8192ll << 20)))) {
-        A.reverse = P->launch_parity;
+    const bool alternates = P->cfg.ell_alternate == 1 || (P->cfg.ell_alternate == 0 && H.stats.bytes_format_ell > (256ll << 20) && H.stats.bytes_format_ell <= (8192ll << 20));
+    if (!STAMP && (t_walk >= 0 || alternates)) {
+        // the caller's explicit direction (ehyb_spmv_walk), else the plan's own alternation: an atomic flip, so that every one of
+        // several threads launching the same plan draws a direction (plain storage: the result does not depend on it)
+        A.reverse = t_walk >= 0 ? (t_walk & 1) : (P->launch_parity.fetch_xor(1, std::memory_order_relaxed) & 1);
         // more than one round of workgroups: what ran in the last round is what the cache holds, so it runs first now
         A.reverse_items = (A.reverse && n_items > kNumCU * (lds > 80 * 1024 ? 1 : 2)) ? 1 : 0;
-        P->launch_parity ^= 1;
     }
     const bool sym = H.sym;
 #define ELL_GO(T, M, I, S)                                                                                  \
@@ -879,11 +891,12 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
         const int grid = queue ? resident : u1;
         // successive launches walk the entry stream in alternating directions (cfg.ell_alternate) where it does not fit the cache
         int rev = 0;
-        if (!queue && !probe && (P->cfg.ell_alternate == 1 || (P->cfg.ell_alternate == 0 && H.pb_bytes > (256ll << 20)))) {
+        if (!queue && !probe && (t_walk >= 0 || P->cfg.ell_alternate == 1 || (P->cfg.ell_alternate == 0 && H.pb_bytes > (256ll << 20)))) {
             // one direction per MULTIPLY: a multiply in parts (ehyb_spmv_part: one pass-1 launch per column segment) turns around
             // with its first part
-            if (unit_begin == 0) P->panel_parity ^= 1;
-            rev = P->panel_parity;
+            if (t_walk >= 0) rev = t_walk & 1;
+            else if (unit_begin == 0) rev = (P->panel_parity.fetch_xor(1, std::memory_order_relaxed) ^ 1) & 1;
+            else rev = P->panel_parity.load(std::memory_order_relaxed) & 1;
         }
 #define PB_SCALE_P(T, D, PR)                                                                                                    \
     hipLaunchKernelGGL((ehyb_pb_scale_kernel<T, D, PR>), dim3(grid), dim3(T), (size_t)(H.pb_panel_cols + ((D) ? 0 : (T)) + 1) * 8, st, (const int2*)P->d_pb_items1 + unit_begin, (const int4*)P->d_pb_units1, \
@@ -1013,6 +1026,24 @@ int ehyb_h2d(void* dst, const void* src, size_t bytes)
 int ehyb_d2h(void* dst, const void* src, size_t bytes)
 {
     HIP_TRY(hipMemcpy(dst, src, bytes, hipMemcpyDeviceToHost));
+    return EHYB_OK;
+}
+int ehyb_stream_create(void** stream)
+{
+    if (!stream) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_stream_create: null");
+    hipStream_t s = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    *stream = (void*)s;
+    return EHYB_OK;
+}
+int ehyb_stream_destroy(void* stream)
+{
+    if (stream) HIP_TRY(hipStreamDestroy((hipStream_t)stream));
+    return EHYB_OK;
+}
+int ehyb_stream_sync(void* stream)
+{
+    HIP_TRY(hipStreamSynchronize((hipStream_t)stream));
     return EHYB_OK;
 }
 int ehyb_dev_mem_info(size_t* free_bytes, size_t* total_bytes)
@@ -1334,6 +1365,68 @@ int ehyb_spmv(ehyb_plan* P, const double* x, double* y, void* stream)
     return ehyb_spmv_phase(P, x, y, stream, 0);
 }
 
+int ehyb_spmv_walk(ehyb_plan* P, const double* x, double* y, void* stream, int walk)
+{
+    if (walk < -1 || walk > 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_spmv_walk: walk %d (EHYB_WALK_AUTO, _FIRST_TO_LAST, _LAST_TO_FIRST)", walk);
+    WalkScope w(walk);
+    return ehyb_spmv_phase(P, x, y, stream, 0);
+}
+
+// ---- a captured multiply (or run of multiplies) that keeps the alternation: see ehyb.h
+struct ehyb_graph {
+    hipGraphExec_t exec[2] = {nullptr, nullptr};   // [d]: the run starting with direction d; equal runs (even count, or a plan that does not alternate) share exec[0]
+    int next = 0;
+    bool two = false;
+};
+
+int ehyb_spmv_graph_create(ehyb_plan* P, const double* x, double* y, int multiplies, ehyb_graph** out)
+{
+    clear_error();
+    if (!P || !x || !y || !out || multiplies < 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_spmv_graph_create: bad arguments");
+    *out = nullptr;
+    if (!P->uploaded) EHYB_FAIL(EHYB_ERR_STATE, "ehyb_spmv_graph_create: plan not uploaded");
+    hipStream_t own = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&own, hipStreamNonBlocking));
+    ehyb_graph* G = new ehyb_graph;
+    G->two = (multiplies & 1) != 0;   // an odd run ends on the direction it began with: the next launch must begin with the other
+    int rc = EHYB_OK;
+    for (int d = 0; d < (G->two ? 2 : 1) && rc == EHYB_OK; ++d) {
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(own, hipStreamCaptureModeThreadLocal) != hipSuccess) {
+            rc = EHYB_ERR_HIP;
+            break;
+        }
+        for (int i = 0; i < multiplies && rc == EHYB_OK; ++i) rc = ehyb_spmv_walk(P, x, y, (void*)own, (d + i) & 1);
+        const hipError_t e = hipStreamEndCapture(own, &g);
+        if (rc == EHYB_OK && (e != hipSuccess || hipGraphInstantiate(&G->exec[d], g, nullptr, nullptr, 0) != hipSuccess)) rc = EHYB_ERR_HIP;
+        if (g) (void)hipGraphDestroy(g);
+    }
+    (void)hipStreamDestroy(own);
+    if (rc != EHYB_OK) {
+        if (rc == EHYB_ERR_HIP) set_error("ehyb_spmv_graph_create: capture failed: %s", hipGetErrorString(hipGetLastError()));
+        ehyb_graph_destroy(G);
+        return rc;
+    }
+    *out = G;
+    return EHYB_OK;
+}
+
+int ehyb_graph_launch(ehyb_graph* G, void* stream)
+{
+    if (!G || !G->exec[0]) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_graph_launch: null");
+    HIP_TRY(hipGraphLaunch(G->exec[G->two ? G->next : 0], (hipStream_t)stream));
+    if (G->two) G->next ^= 1;
+    return EHYB_OK;
+}
+
+void ehyb_graph_destroy(ehyb_graph* G)
+{
+    if (!G) return;
+    for (auto e : G->exec)
+        if (e) (void)hipGraphExecDestroy(e);
+    delete G;
+}
+
 int ehyb_plan_col_segs(const ehyb_plan* P, int* n_col_segs)
 {
     if (!P || !n_col_segs) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_plan_col_segs: null argument");
@@ -1375,15 +1468,30 @@ int ehyb_gather(const double* src, const int32_t* idx, double* dst, int64_t n, v
 }
 
 // "`waiter` waits for everything enqueued on `on` so far": an event record + a stream wait.  The events are a small
-// per-thread ring, made once and reused (recording an event again while an earlier wait on it is pending is well defined:
-// a wait refers to the record that preceded it).
+// per-thread, per-DEVICE ring, made once and reused (recording an event again while an earlier wait on it is pending is
+// well defined: a wait refers to the record that preceded it); a thread that drives plans on several devices gets one ring
+// for each, and the rings are destroyed when the thread ends.
+namespace {
+struct EventRings {
+    static constexpr int kRing = 16, kDevices = 16;
+    hipEvent_t ring[kDevices][kRing] = {};
+    int next[kDevices] = {};
+    ~EventRings()
+    {
+        for (auto& dev : ring)
+            for (hipEvent_t e : dev)
+                if (e) (void)hipEventDestroy(e);
+    }
+};
+}  // namespace
 static int stream_wait_stream(hipStream_t waiter, hipStream_t on)
 {
-    constexpr int kRing = 16;
-    static thread_local hipEvent_t ring[kRing] = {};
-    static thread_local int next = 0;
-    hipEvent_t& e = ring[next];
-    next = (next + 1) % kRing;
+    static thread_local EventRings R;
+    int dev = 0;
+    HIP_TRY(hipGetDevice(&dev));
+    if (dev < 0 || dev >= EventRings::kDevices) EHYB_FAIL(EHYB_ERR_ARG, "stream_wait_stream: device %d", dev);
+    hipEvent_t& e = R.ring[dev][R.next[dev]];
+    R.next[dev] = (R.next[dev] + 1) % EventRings::kRing;
     if (!e) HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     HIP_TRY(hipEventRecord(e, on));
     HIP_TRY(hipStreamWaitEvent(waiter, e, 0));

@@ -1,6 +1,7 @@
 // Internal declarations shared by the host builder, the partitioner and the HIP side.
 // Nothing here is part of the C-ABI (see include/ehyb.h).
 #pragma once
+#include <atomic>
 #include <cstdint>
 #include <cstdarg>
 #include <cstdio>
@@ -296,6 +297,8 @@ struct ehyb_plan {
     int32_t* d_er_src = nullptr;
     int32_t* d_pb_src = nullptr;
     bool host_values_stale = false;  // the device values were refilled: the host copy no longer matches
-    int launch_parity = 0;           // direction of the next ELL launch's walk (cfg.ell_alternate)
-    int panel_parity = 0;            // the same for pass 1 of the panel residual
+    // direction of the next ELL launch's walk (cfg.ell_alternate), and of pass 1 of the panel residual: atomics, so that host
+    // threads that multiply with one plan on their own streams (ELL-only plans: include/ehyb.h) each draw a direction
+    std::atomic<int> launch_parity{0};
+    std::atomic<int> panel_parity{0};
 };

@@ -4,12 +4,18 @@
 // size-line grammar is the subset of mmio.c:96-217 the reference uses.
 #include "ehyb_internal.h"
 
+#include <fcntl.h>
 #include <omp.h>
+#include <sys/mman.h>
+#include <sys/stat.h>
+#include <unistd.h>
 #include <zlib.h>
 
 #include <algorithm>
 #include <cctype>
 #include <cmath>
+#include <memory>
+#include <new>
 #include <numeric>
 
 namespace ehyb {
@@ -60,6 +66,115 @@ int finish_matrix(matrixCOO* m, const ehyb_config* cfg)
     return EHYB_OK;
 }
 
+// ---- number parsing of the Matrix Market body.  glibc's strtod costs 300-500 ns on a 17-digit value; tens of millions of
+// lines are the common case (audikw_1: 39 M).  parse_double below is EXACT -- the value fscanf("%lg") would give
+// (solver_test.c:97,197) -- or it declines: up to 19 significant digits m and a decimal exponent |e| <= 27 are both exact in
+// the x87 extended format (64-bit mantissa; 5^27 < 2^63), so m * 10^e or m / 10^e is ONE correctly rounded extended operation,
+// and rounding that to double is the correctly rounded double unless the extended result sits exactly on a midpoint between two
+// doubles (low 11 bits = 0x400: one case in 2048) -- then, and for anything else out of the fast path's range (more digits, huge
+// exponents, inf / nan, hex floats), strtod decides.
+const long double kPow10L[28] = {1e0L,  1e1L,  1e2L,  1e3L,  1e4L,  1e5L,  1e6L,  1e7L,  1e8L,  1e9L,  1e10L, 1e11L, 1e12L, 1e13L,
+                                 1e14L, 1e15L, 1e16L, 1e17L, 1e18L, 1e19L, 1e20L, 1e21L, 1e22L, 1e23L, 1e24L, 1e25L, 1e26L, 1e27L};
+const double kPow10D[23] = {1e0,  1e1,  1e2,  1e3,  1e4,  1e5,  1e6,  1e7,  1e8,  1e9,  1e10, 1e11,
+                            1e12, 1e13, 1e14, 1e15, 1e16, 1e17, 1e18, 1e19, 1e20, 1e21, 1e22};
+
+inline const char* skip_blanks(const char* p)
+{
+    while (*p == ' ' || *p == '\t') ++p;
+    return p;
+}
+
+// decimal integer at p (after blanks); -> end of the digits, or nullptr if there is no digit / it overflows
+inline const char* parse_index(const char* p, long* out)
+{
+    p = skip_blanks(p);
+    bool neg = false;
+    if (*p == '+' || *p == '-') neg = *p++ == '-';
+    if ((unsigned)(*p - '0') > 9u) return nullptr;
+    unsigned long v = 0;
+    int nd = 0;
+    for (; (unsigned)(*p - '0') <= 9u; ++p, ++nd) v = v * 10 + (unsigned)(*p - '0');
+    if (nd > 18) return nullptr;
+    *out = neg ? -(long)v : (long)v;
+    return p;
+}
+
+// -> end of the number, value in *out; nullptr: no number here
+inline const char* parse_double(const char* p, double* out)
+{
+    const char* const start = skip_blanks(p);
+    p = start;
+    bool neg = false;
+    if (*p == '+' || *p == '-') neg = *p++ == '-';
+    uint64_t m = 0;
+    int nd = 0, dropped = 0, e10 = 0;
+    bool any = false, fast = true;
+    for (; (unsigned)(*p - '0') <= 9u; ++p) {
+        any = true;
+        if (nd < 19) {
+            m = m * 10 + (unsigned)(*p - '0');
+            nd += (m != 0);
+        } else {
+            fast = false;   // more significant digits than the mantissa holds
+            ++dropped;
+        }
+    }
+    if (*p == '.') {
+        ++p;
+        for (; (unsigned)(*p - '0') <= 9u; ++p) {
+            any = true;
+            if (nd < 19) {
+                m = m * 10 + (unsigned)(*p - '0');
+                nd += (m != 0);
+                --e10;
+            } else {
+                fast = fast && *p == '0';   // trailing zeros beyond 19 digits change nothing
+            }
+        }
+    }
+    if (!any) fast = false;
+    if (any && (*p == 'e' || *p == 'E' || *p == 'd' || *p == 'D')) {
+        const char* q = p + 1;
+        bool eneg = false;
+        if (*q == '+' || *q == '-') eneg = *q++ == '-';
+        if ((unsigned)(*q - '0') <= 9u) {
+            int ex = 0;
+            for (; (unsigned)(*q - '0') <= 9u; ++q) ex = ex < 100000 ? ex * 10 + (*q - '0') : ex;
+            e10 += eneg ? -ex : ex;
+            if (*p == 'd' || *p == 'D') fast = false;   // Fortran exponent letter: not what strtod reads -- let it decide
+            p = q;
+        }
+    }
+    (void)dropped;
+    if (*p == 'x' || *p == 'X') fast = false;   // a hexadecimal float ("0x1p3"): strtod reads those
+    if (fast) {
+        if (m == 0) {
+            *out = neg ? -0.0 : 0.0;
+            return p;
+        }
+        if (m < (1ull << 53) && e10 >= -22 && e10 <= 22) {   // both factors exact doubles: one rounding
+            const double d = e10 < 0 ? (double)m / kPow10D[-e10] : (double)m * kPow10D[e10];
+            *out = neg ? -d : d;
+            return p;
+        }
+        if (e10 >= -27 && e10 <= 27 && sizeof(long double) >= 10) {
+            const long double r = e10 < 0 ? (long double)m / kPow10L[-e10] : (long double)m * kPow10L[e10];
+            uint64_t mant;
+            memcpy(&mant, &r, 8);   // x87 extended: the 64-bit mantissa comes first
+            if ((mant & 0x7FFu) != 0x400u) {
+                const double d = (double)r;
+                *out = neg ? -d : d;
+                return p;
+            }
+        }
+    }
+    char* e = nullptr;
+    const double d = strtod(start, &e);
+    if (e == start) return nullptr;
+    *out = d;
+    return e;
+}
+
 inline double hash_value(uint64_t a, uint64_t b)
 {
     // ((31*i + 17*j) mod 200 - 100)/1000, an exact 0 replaced by 0.001
@@ -89,18 +204,95 @@ int ehyb_mm_read(const char* path, const ehyb_config* cfg, matrixCOO* out, int* 
     // does not exist, so `-m audikw_1` also finds ./read/audikw_1.mtx.gz).  The reference parses
     // with fscanf one entry at a time (solver_test.c:96-103,196-206); here the body is cut into
     // line-aligned pieces parsed in parallel -- tens of millions of lines are the common case.
-    std::vector<char> text;
+    const bool verbose = cfg && cfg->verbose;
+    double t_mark = wall_seconds();
+    auto mark = [&](const char* what) {
+        const double t = wall_seconds();
+        if (verbose) fprintf(stderr, "[ehyb_mm_read] %-28s %.3f s\n", what, t - t_mark);
+        t_mark = t;
+    };
+    // gzip: inflated into a buffer that grows by realloc (zlib's inflate is one serial stream: ~0.25 GB/s of text, the floor for
+    // .gz input); plain: see below
+    struct Text {
+        const char* data = nullptr;
+        size_t size = 0;      // bytes of text; data[size] is readable and '\0' unless `tail_copy` says otherwise
+        void* map = nullptr;
+        size_t map_len = 0;
+        char* heap = nullptr;
+        ~Text()
+        {
+            if (map) munmap(map, map_len);
+            free(heap);
+        }
+    } text;
     {
-        gzFile g = gzopen(path, "rb");
-        if (!g) g = gzopen((std::string(path) + ".gz").c_str(), "rb");
-        if (!g) EHYB_FAIL(EHYB_ERR_IO, "file read error: %s", path);
-        gzbuffer(g, 1u << 20);
-        size_t used = 0;
-        try {
-            text.resize(size_t(1) << 24);
+        std::string real = path;
+        int fd = open(real.c_str(), O_RDONLY);
+        if (fd < 0) {
+            real += ".gz";
+            fd = open(real.c_str(), O_RDONLY);
+        }
+        if (fd < 0) EHYB_FAIL(EHYB_ERR_IO, "file read error: %s", path);
+        unsigned char magic[2] = {0, 0};
+        const ssize_t got_magic = pread(fd, magic, 2, 0);
+        struct stat sb;
+        const bool gz = got_magic == 2 && magic[0] == 0x1f && magic[1] == 0x8b;
+        if (!gz && fstat(fd, &sb) == 0 && S_ISREG(sb.st_mode) && sb.st_size > 0) {
+            // plain file: every thread reads its slice straight into place (pread), so the copy out of the page cache and the
+            // first touch of the buffer's pages are both parallel.  (Parsing from a read-only mapping of the file was measured
+            // too: 0.7 s instead of 0.1 s for 310 MB -- every page of the mapping faults in the parse, on few threads at a time.)
+            const size_t size = (size_t)sb.st_size;
+            text.heap = (char*)malloc(size + 1);
+            if (!text.heap) {
+                close(fd);
+                EHYB_FAIL(EHYB_ERR_ALLOC, "out of memory reading %s", path);
+            }
+            const size_t slice = size_t(8) << 20;
+            const int64_t n_slices = (int64_t)((size + slice - 1) / slice);
+            bool read_ok = true;
+#pragma omp parallel for schedule(dynamic, 1)
+            for (int64_t i = 0; i < n_slices; ++i) {
+                size_t off = (size_t)i * slice;
+                const size_t stop = std::min(size, off + slice);
+                while (off < stop) {
+                    const ssize_t got = pread(fd, text.heap + off, stop - off, (off_t)off);
+                    if (got <= 0) {
+#pragma omp atomic write
+                        read_ok = false;
+                        break;
+                    }
+                    off += (size_t)got;
+                }
+            }
+            if (!read_ok) {
+                close(fd);
+                EHYB_FAIL(EHYB_ERR_IO, "file read error: %s", path);
+            }
+            text.heap[size] = '\0';
+            text.data = text.heap, text.size = size;
+        }
+        close(fd);
+        if (!text.data) {
+            gzFile g = gzopen(real.c_str(), "rb");   // zlib reads plain files too
+            if (!g) EHYB_FAIL(EHYB_ERR_IO, "file read error: %s", path);
+            gzbuffer(g, 1u << 20);
+            size_t used = 0, cap = size_t(1) << 26;
+            text.heap = (char*)malloc(cap);
             for (;;) {
-                if (text.size() - used < (size_t(1) << 22)) text.resize(text.size() * 2);
-                const int got = gzread(g, text.data() + used, (unsigned)std::min<size_t>(text.size() - used - 1, size_t(1) << 30));
+                if (!text.heap) {
+                    gzclose(g);
+                    EHYB_FAIL(EHYB_ERR_ALLOC, "out of memory reading %s", path);
+                }
+                if (cap - used < (size_t(1) << 22)) {
+                    cap *= 2;
+                    char* bigger = (char*)realloc(text.heap, cap);
+                    if (!bigger) {
+                        gzclose(g);
+                        EHYB_FAIL(EHYB_ERR_ALLOC, "out of memory reading %s", path);
+                    }
+                    text.heap = bigger;
+                }
+                const int got = gzread(g, text.heap + used, (unsigned)std::min<size_t>(cap - used - 1, size_t(1) << 30));
                 if (got < 0) {
                     gzclose(g);
                     EHYB_FAIL(EHYB_ERR_IO, "file read error: %s (damaged gzip stream?)", path);
@@ -108,16 +300,14 @@ int ehyb_mm_read(const char* path, const ehyb_config* cfg, matrixCOO* out, int* 
                 if (got == 0) break;
                 used += (size_t)got;
             }
-        } catch (const std::bad_alloc&) {
             gzclose(g);
-            EHYB_FAIL(EHYB_ERR_ALLOC, "out of memory reading %s", path);
+            text.heap[used] = '\0';  // number parsing never runs off the end
+            text.data = text.heap, text.size = used;
         }
-        gzclose(g);
-        text.resize(used + 1);
-        text[used] = '\0';  // strtod never runs off the end
     }
-    const char* const end = text.data() + text.size() - 1;
-    const char* cur = text.data();
+    mark("file into memory");
+    const char* const end = text.data + text.size;
+    const char* cur = text.data;
     auto next_line = [&](const char* p) {
         const char* q = (const char*)memchr(p, '\n', (size_t)(end - p));
         return q ? q + 1 : end;
@@ -161,8 +351,13 @@ int ehyb_mm_read(const char* path, const ehyb_config* cfg, matrixCOO* out, int* 
     if (M <= 0 || M != N || stored < 0 || M > 0x7FFFFFF0l)
         EHYB_FAIL(EHYB_ERR_FORMAT, "size line %ld x %ld with %ld entries: a square matrix is required", M, N, stored);
     const int n = (int)M;
-    std::vector<int> fi((size_t)stored), fj((size_t)stored);
-    std::vector<double> fv((size_t)stored);
+    // (uninitialised: a value-initialised vector would touch 16 bytes per entry on one thread before the parse starts)
+    std::unique_ptr<int[]> fi_own(new (std::nothrow) int[(size_t)stored + 1]), fj_own(new (std::nothrow) int[(size_t)stored + 1]);
+    std::unique_ptr<double[]> fv_own(new (std::nothrow) double[(size_t)stored + 1]);
+    if (!fi_own || !fj_own || !fv_own) EHYB_FAIL(EHYB_ERR_ALLOC, "out of memory for %ld entries of %s", stored, path);
+    int* const fi = fi_own.get();
+    int* const fj = fj_own.get();
+    double* const fv = fv_own.get();
     {
         // pieces of the body that start at line starts; entry lines per piece; then parse
         const int pieces = (int)std::max<int64_t>(1, std::min<int64_t>(omp_get_max_threads(), (end - cur) / (1 << 16)));
@@ -177,83 +372,130 @@ int ehyb_mm_read(const char* path, const ehyb_config* cfg, matrixCOO* out, int* 
             return false;
         };
         std::vector<int64_t> first(pieces + 1, 0);
+        // lines per piece.  First try: every line of the body is an entry (no comment or blank line behind the size line --
+        // the usual file), so counting newlines is enough; a piece that meets anything else while parsing says so and the
+        // exact count (every line looked at twice) is taken instead.
+        for (int attempt = 0; attempt < 2; ++attempt) {
+            const bool exact = attempt == 1;
 #pragma omp parallel for schedule(static, 1)
-        for (int t = 0; t < pieces; ++t) {
-            int64_t c = 0;
-            for (const char* p = start[t]; p < start[t + 1];) {
-                const char* q = next_line(p);
-                c += is_entry(p, q);
-                p = q;
-            }
-            first[t + 1] = c;
-        }
-        for (int t = 0; t < pieces; ++t) first[t + 1] += first[t];
-        if (first[pieces] < stored)
-            EHYB_FAIL(EHYB_ERR_FORMAT, "bad entry %lld of %ld in %s", (long long)first[pieces] + 1, stored, path);
-        int64_t bad = -1;
-#pragma omp parallel for schedule(static, 1)
-        for (int t = 0; t < pieces; ++t) {
-            int64_t k = first[t];
-            for (const char* p = start[t]; p < start[t + 1] && k < stored;) {
-                const char* q = next_line(p);
-                if (is_entry(p, q)) {
-                    char* e1 = nullptr;
-                    const long a = strtol(p, &e1, 10);
-                    char* e2 = nullptr;
-                    const long b = strtol(e1, &e2, 10);
-                    double v = 1.0;
-                    char* e3 = e2;
-                    if (!pattern) v = strtod(e2, &e3);
-                    if (e1 == p || e2 == e1 || (!pattern && e3 == e2) || e3 > q || a < 1 || b < 1 || a > n || b > n) {
-#pragma omp critical
-                        if (bad < 0 || k < bad) bad = k;
-                    } else {
-                        fi[k] = (int)a - 1;  // 1-based -> 0-based (solver_test.c:98-99, 198-199)
-                        fj[k] = (int)b - 1;
-                        fv[k] = v;
+            for (int t = 0; t < pieces; ++t) {
+                int64_t c = 0;
+                if (exact) {
+                    for (const char* p = start[t]; p < start[t + 1];) {
+                        const char* q = next_line(p);
+                        c += is_entry(p, q);
+                        p = q;
                     }
-                    ++k;
+                } else {
+                    const char* p = start[t];
+                    while (p < start[t + 1]) {
+                        const char* q = (const char*)memchr(p, '\n', (size_t)(start[t + 1] - p));
+                        if (!q) {
+                            c += is_entry(p, start[t + 1]);   // a last line without a newline
+                            break;
+                        }
+                        ++c;
+                        p = q + 1;
+                    }
                 }
-                p = q;
+                first[t + 1] = c;
             }
+            first[0] = 0;
+            for (int t = 0; t < pieces; ++t) first[t + 1] += first[t];
+            if (first[pieces] < stored)
+                EHYB_FAIL(EHYB_ERR_FORMAT, "bad entry %lld of %ld in %s", (long long)first[pieces] + 1, stored, path);
+            int64_t bad = -1;
+            bool other_lines = false;
+#pragma omp parallel for schedule(static, 1)
+            for (int t = 0; t < pieces; ++t) {
+                int64_t k = first[t];
+                for (const char* p = start[t]; p < start[t + 1] && k < stored;) {
+                    const char* q = next_line(p);
+                    if (is_entry(p, q)) {
+                        long a = 0, b = 0;
+                        double v = 1.0;
+                        const char* e1 = parse_index(p, &a);
+                        const char* e2 = e1 ? parse_index(e1, &b) : nullptr;
+                        const char* e3 = e2;
+                        if (e2 && !pattern) e3 = parse_double(e2, &v);
+                        if (!e1 || !e2 || !e3 || e3 > q || a < 1 || b < 1 || a > n || b > n) {
+#pragma omp critical
+                            if (bad < 0 || k < bad) bad = k;
+                        } else {
+                            fi[k] = (int)a - 1;  // 1-based -> 0-based (solver_test.c:98-99, 198-199)
+                            fj[k] = (int)b - 1;
+                            fv[k] = v;
+                        }
+                        ++k;
+                    } else if (!exact) {
+#pragma omp atomic write
+                        other_lines = true;
+                    }
+                    p = q;
+                }
+            }
+            if (other_lines && !exact) continue;   // comments or blank lines inside the body: count them properly and parse again
+            if (bad >= 0) EHYB_FAIL(EHYB_ERR_FORMAT, "bad entry %lld of %ld in %s", (long long)bad + 1, stored, path);
+            break;
         }
-        if (bad >= 0) EHYB_FAIL(EHYB_ERR_FORMAT, "bad entry %lld of %ld in %s", (long long)bad + 1, stored, path);
     }
-    std::vector<char>().swap(text);
+    if (text.map) munmap(text.map, text.map_len), text.map = nullptr;
+    free(text.heap), text.heap = nullptr;
+    mark("parse");
 
     const bool mirror = sym || skew;
     int64_t total = stored;
-    if (mirror)
-        for (long k = 0; k < stored; ++k) total += fi[k] != fj[k];
+    if (mirror) {
+        int64_t off = 0;
+#pragma omp parallel for schedule(static) reduction(+ : off)
+        for (long k = 0; k < stored; ++k) off += fi[k] != fj[k];
+        total += off;
+    }
     int rc = alloc_matrix(n, total, out);
     if (rc != EHYB_OK) return rc;
-    for (long k = 0; k < stored; ++k) {
-        out->numInRow[fi[k]]++;
-        if (mirror && fi[k] != fj[k]) out->numInRow[fj[k]]++;
+    // Row-grouped placement in file order, the mirrored entry right after its original (solver_test.c:235-255); for general
+    // files this groups rows stably, which leaves the per-row accumulation order of solver_test.c:102 unchanged.  In parallel by
+    // ROW RANGE: every thread walks the whole entry list in file order and places the entries whose (target) row is its own --
+    // the order inside a row is the serial one, the writes of a thread stay inside its rows.
+    const int nt = std::max(1, omp_get_max_threads());
+#pragma omp parallel num_threads(nt)
+    {
+        const int t = omp_get_thread_num(), T = omp_get_num_threads();
+        const int r0 = (int)((int64_t)n * t / T), r1 = (int)((int64_t)n * (t + 1) / T);
+        for (long k = 0; k < stored; ++k) {
+            const int a = fi[k], b = fj[k];
+            if (a >= r0 && a < r1) out->numInRow[a]++;
+            if (mirror && a != b && b >= r0 && b < r1) out->numInRow[b]++;
+        }
     }
     rc = finish_matrix(out, cfg);
     if (rc != EHYB_OK) {
         ehyb_matrix_free(out);
         return rc;
     }
-    // placement in file order, the mirrored entry right after its original
-    // (solver_test.c:235-255); for general files this groups rows stably, which leaves the
-    // per-row accumulation order of solver_test.c:102 unchanged.
     std::vector<int> fill((size_t)n, 0);
-    for (long k = 0; k < stored; ++k) {
-        int a = fi[k], b = fj[k];
-        int64_t at = (int64_t)out->rowIdx[a] + fill[a]++;
-        out->I[at] = a;
-        out->J[at] = b;
-        out->V[at] = fv[k];
-        if (a == b) out->diag[a] = fv[k];
-        if (mirror && a != b) {
-            int64_t at2 = (int64_t)out->rowIdx[b] + fill[b]++;
-            out->I[at2] = b;
-            out->J[at2] = a;
-            out->V[at2] = skew ? -fv[k] : fv[k];
+#pragma omp parallel num_threads(nt)
+    {
+        const int t = omp_get_thread_num(), T = omp_get_num_threads();
+        const int r0 = (int)((int64_t)n * t / T), r1 = (int)((int64_t)n * (t + 1) / T);
+        for (long k = 0; k < stored; ++k) {
+            const int a = fi[k], b = fj[k];
+            if (a >= r0 && a < r1) {
+                const int64_t at = (int64_t)out->rowIdx[a] + fill[a]++;
+                out->I[at] = a;
+                out->J[at] = b;
+                out->V[at] = fv[k];
+                if (a == b) out->diag[a] = fv[k];
+            }
+            if (mirror && a != b && b >= r0 && b < r1) {
+                const int64_t at2 = (int64_t)out->rowIdx[b] + fill[b]++;
+                out->I[at2] = b;
+                out->J[at2] = a;
+                out->V[at2] = skew ? -fv[k] : fv[k];
+            }
         }
     }
+    mark("row-grouped placement");
     if (is_symmetric) *is_symmetric = mirror ? 1 : 0;
     return EHYB_OK;
 }
@@ -264,12 +506,28 @@ int ehyb_mm_write(const char* path, const matrixCOO* m, int symmetric_lower_only
     FILE* f = fopen(path, "w");
     if (!f) EHYB_FAIL(EHYB_ERR_IO, "cannot write %s", path);
     int64_t cnt = 0;
+#pragma omp parallel for schedule(static) reduction(+ : cnt)
     for (int k = 0; k < m->totalNum; ++k) cnt += !symmetric_lower_only || m->I[k] >= m->J[k];
     fprintf(f, "%%%%MatrixMarket matrix coordinate real %s\n", symmetric_lower_only ? "symmetric" : "general");
     fprintf(f, "%d %d %lld\n", m->dimension, m->dimension, (long long)cnt);
-    for (int k = 0; k < m->totalNum; ++k)
-        if (!symmetric_lower_only || m->I[k] >= m->J[k]) fprintf(f, "%d %d %.17g\n", m->I[k] + 1, m->J[k] + 1, m->V[k]);
-    fclose(f);
+    // blocks of entries formatted by all threads (17 significant digits: the value reads back bit for bit), written in order
+    const int T = std::max(1, omp_get_max_threads());
+    constexpr int64_t kBlock = 1 << 18;
+    std::vector<std::string> buf((size_t)T);
+    bool ok = true;
+    for (int64_t base = 0; base < m->totalNum && ok; base += kBlock * T) {
+#pragma omp parallel for schedule(static, 1) num_threads(T)
+        for (int t = 0; t < T; ++t) {
+            std::string& b = buf[(size_t)t];
+            b.clear();
+            const int64_t k0 = std::min<int64_t>(m->totalNum, base + kBlock * t), k1 = std::min<int64_t>(m->totalNum, k0 + kBlock);
+            char line[96];
+            for (int64_t k = k0; k < k1; ++k)
+                if (!symmetric_lower_only || m->I[k] >= m->J[k]) b.append(line, (size_t)snprintf(line, sizeof line, "%d %d %.17g\n", m->I[k] + 1, m->J[k] + 1, m->V[k]));
+        }
+        for (int t = 0; t < T && ok; ++t) ok = buf[(size_t)t].empty() || fwrite(buf[(size_t)t].data(), 1, buf[(size_t)t].size(), f) == buf[(size_t)t].size();
+    }
+    if (fclose(f) != 0 || !ok) EHYB_FAIL(EHYB_ERR_IO, "cannot write %s (disk full?)", path);
     return EHYB_OK;
 }
 

@@ -151,6 +151,8 @@ def _setup_device(group=None):
 def alltoallv(send, send_counts, group=None):
     """Uneven all-to-all of a 1-D numpy array with TENSOR collectives (the counts first, then the payload in one
     all_to_all_single): what the ranks tell each other while the send lists are built.  -> (received, recv_counts)"""
+    if len(send_counts) == 1:      # one rank (the loop-back test of the RCCL step): what I send is what I receive
+        return np.ascontiguousarray(send).copy(), np.asarray([int(send_counts[0])], dtype=np.int64)
     import torch
     import torch.distributed as dist
 
@@ -171,7 +173,7 @@ def _even(v):
 
 
 class RankLocalMatrix:
-    def __init__(self, I, J, V, cuts, rank, cfg=None, symmetric=False, group=None, exchange="halo", chunks=1, chunk_shares=None):
+    def __init__(self, I, J, V, cuts, rank, cfg=None, symmetric=False, group=None, exchange="halo", chunks=1, chunk_shares=None, loopback=0.0):
         """I, J, V: this rank's rows in global labels, row-grouped (I ascending).  cuts: first row of
         every rank, world+1 entries.  Collective: every rank of `group` must call it.
         exchange = "halo": one ghost slot per distinct remote column, filled by all_to_all steps of exactly
@@ -183,7 +185,11 @@ class RankLocalMatrix:
         exchange = "allgather": the ghost columns are the places of the remote entries inside the buffer an
         all-gather of the (padded) x segments fills (GatherSpmv):
         x = [own segment, padded to seg_len | segment of rank 0 | ... | segment of rank world-1], every
-        segment in its owner's plan order, so nothing has to be unpacked after the collective."""
+        segment in its owner's plan order, so nothing has to be unpacked after the collective.
+        loopback (test device, halo exchange only): the columns of the last `loopback` share of this rank's OWN rows are treated
+        as remote columns -- owned by this very rank, which then sends them to itself -- so that a communicator with ONE rank
+        exercises pack -> ncclSend / ncclRecv -> ghost columns -> the multiply in parts (RCCL refuses two ranks on one device,
+        and the GPU box has one)."""
         world = len(cuts) - 1
         self.rank, self.world, self.cuts, self.group = rank, world, [int(c) for c in cuts], group
         r0, r1 = self.cuts[rank], self.cuts[rank + 1]
@@ -195,14 +201,15 @@ class RankLocalMatrix:
             raise ValueError("RankLocalMatrix: rows must lie in [r0, r1) and be grouped in ascending order")
         if exchange not in ("halo", "allgather"):
             raise ValueError(f"RankLocalMatrix: unknown exchange {exchange!r}")
-        if exchange == "allgather" or world == 1:
+        loop = float(loopback) > 0 and exchange == "halo"
+        if exchange == "allgather" or (world == 1 and not loop):
             chunks, chunk_shares = 1, None
         chunks = max(1, int(chunks))
         shares = np.asarray(chunk_shares if chunk_shares is not None else [1.0 / chunks] * chunks, dtype=np.float64)
         if len(shares) != chunks or np.any(shares <= 0):
             raise ValueError("RankLocalMatrix: chunk_shares must hold one positive share per chunk")
         edges = np.cumsum(shares / shares.sum())[:-1]
-        own = (J >= r0) & (J < r1)
+        own = (J >= r0) & (J < (r1 - int(self.n_loc * float(loopback)) if loop else r1))
         # diagonal block: a masked row-grouped sequence is still row-grouped
         indptr = np.zeros(self.n_loc + 1, dtype=np.int64)
         np.cumsum(np.bincount(I[own] - r0, minlength=self.n_loc), out=indptr[1:])
@@ -218,7 +225,8 @@ class RankLocalMatrix:
         self.n_ghost = len(gcols)
         by_owner = np.lexsort((gcols, -refs, owner))                       # owner, then hot columns first
         per_owner = np.bincount(owner, minlength=world).astype(np.int64)
-        assert per_owner[rank] == 0
+        assert loop or per_owner[rank] == 0
+        self.exchanges = world > 1 or loop       # there is something to send and receive
         first_of = np.concatenate(([0], np.cumsum(per_owner)))[:-1]
         pos = np.arange(self.n_ghost) - np.repeat(first_of, per_owner)       # rank inside the owner's list
         frac = (pos + 0.5) / np.maximum(1, np.repeat(per_owner, per_owner))
@@ -245,7 +253,7 @@ class RankLocalMatrix:
         # ---- what the peers want from me, chunk by chunk, in their slot order: tensor collectives
         self.send_counts = np.zeros((chunks, world), dtype=np.int64)
         send_idx = []
-        if world > 1:
+        if self.exchanges:
             for k in range(chunks):
                 sel = chunk_of == k
                 asked, cnt = alltoallv(self.ghost_cols[sel].astype(np.int64), self.recv_counts[k], group)
@@ -272,11 +280,11 @@ class RankLocalMatrix:
             self.m.append_ghosts(self.n_ext, self.perm[I[off] - r0], (col_of_slot - self.n_loc)[slot_of_entry[inv]], V[off])
         self.nnz = len(V)
         self.nnz_own_cols = int(own.sum())
-        self.cfg_plan = _copy_cfg(cfg, n_top=2 if world > 1 else 1)
+        self.cfg_plan = _copy_cfg(cfg, n_top=2 if self.exchanges else 1)
 
     def plan(self, upload=True):
         return H.Plan(self.m, self.cfg_plan, rows=(0, self.n_loc), upload=upload,
-                      col_segs=self.col_segs if (self.col_segs is not None and self.world > 1) else None)
+                      col_segs=self.col_segs if (self.col_segs is not None and self.exchanges) else None)
 
     def x_to_plan(self, x_local):
         """Local x segment (global label order) -> plan order."""
@@ -284,6 +292,69 @@ class RankLocalMatrix:
 
     def y_from_plan(self, y_plan):
         return H.vector_recover(y_plan, self.perm)
+
+
+class Comm:
+    """RCCL communicator of libehyb.so (include/ehyb.h: ehyb_comm_*): what the C-side step sends and receives through.
+    torch.distributed only carries the 128-byte ncclUniqueId from rank 0 to the others (make_comm)."""
+
+    def __init__(self, unique_id, rank, world):
+        self.lib = H._lib.load()
+        self.rank, self.world = int(rank), int(world)
+        h = C.c_void_p()
+        H._check(self.lib.ehyb_comm_create(unique_id, self.rank, self.world, C.byref(h)), "ehyb_comm_create")
+        self.h = h
+        self._halos = []
+        st = C.c_void_p()
+        H._check(self.lib.ehyb_comm_info(self.h, None, None, C.byref(st)), "ehyb_comm_info")
+        self.stream = st.value or 0
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(128)
+        H._check(H._lib.load().ehyb_comm_unique_id(buf), "ehyb_comm_unique_id")
+        return buf
+
+    def halo(self, plan, local):
+        """ehyb_halo_create for a RankLocalMatrix's plan: the send list and the per-chunk, per-peer counts go to the C side once."""
+        idx = np.ascontiguousarray(local.send_idx, dtype=np.int32)
+        sc = np.ascontiguousarray(local.send_counts, dtype=np.int64).reshape(-1)
+        rc = np.ascontiguousarray(local.recv_counts, dtype=np.int64).reshape(-1)
+        h = C.c_void_p()
+        H._check(self.lib.ehyb_halo_create(self.h, plan.h, int(local.chunks), idx.ctypes.data_as(C.POINTER(C.c_int32)), len(idx),
+                                           sc.ctypes.data_as(C.POINTER(C.c_int64)), rc.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(h)), "ehyb_halo_create")
+        self._halos.append(h)
+        return h
+
+    def allreduce_sum(self, ptr, count, stream=0):
+        rc = self.lib.ehyb_comm_allreduce_sum(self.h, ptr, int(count), stream)
+        if rc:
+            H._check(rc, "ehyb_comm_allreduce_sum")
+
+    def destroy(self):
+        for h in self._halos:
+            self.lib.ehyb_halo_destroy(h)
+        self._halos = []
+        if self.h:
+            self.lib.ehyb_comm_destroy(self.h)
+            self.h = None
+
+
+def make_comm(group=None):
+    """One Comm per rank of `group` (torch.distributed; None with no process group = a single rank): rank 0 draws the
+    ncclUniqueId, a broadcast of its 128 bytes hands it to the others, every rank joins (ncclCommInitRank)."""
+    import torch
+    import torch.distributed as dist
+
+    if not (dist.is_available() and dist.is_initialized()):
+        return Comm(Comm.unique_id(), 0, 1)
+    rank, world = dist.get_rank(group), dist.get_world_size(group)
+    dev = _setup_device(group)
+    t = torch.zeros(128, dtype=torch.uint8, device=dev)
+    if rank == 0:
+        t.copy_(torch.frombuffer(bytearray(Comm.unique_id().raw), dtype=torch.uint8))
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group else 0, group=group)
+    return Comm(C.create_string_buffer(bytes(t.cpu().numpy().tobytes()), 128), rank, world)
 
 
 class HaloExchange:
@@ -309,8 +380,8 @@ class HaloExchange:
         self.mode = mode
         self.stage = stage_on_cpu and dev.type != "cpu"  # gloo cannot move GPU tensors: through the host (functional mode)
         segs = local.col_segs
-        self.ghost_views = [x_ext[int(segs[k + 1]):int(segs[k + 1]) + sum(self.recv_counts[k])] for k in range(local.chunks)] if local.world > 1 else []
-        self.send_views = [self.send_buf[int(local.send_first[k]):int(local.send_first[k + 1])] for k in range(local.chunks)] if local.world > 1 else []
+        self.ghost_views = [x_ext[int(segs[k + 1]):int(segs[k + 1]) + sum(self.recv_counts[k])] for k in range(local.chunks)] if local.exchanges else []
+        self.send_views = [self.send_buf[int(local.send_first[k]):int(local.send_first[k + 1])] for k in range(local.chunks)] if local.exchanges else []
         self.lib = H._lib.load()
         self._pack_args = (C.c_void_p(self.x_ext.data_ptr()), C.c_void_p(self.send_idx.data_ptr()), C.c_void_p(self.send_buf.data_ptr()), len(local.send_idx))
 
@@ -322,9 +393,12 @@ class HaloExchange:
 
     def transfer(self, k):
         L, dist, torch = self.L, self.dist, self.torch
-        if L.world == 1:
+        if not L.exchanges:
             return
         send, recv = self.send_views[k], self.ghost_views[k]
+        if L.world == 1:            # loop-back: the rank is its own peer -- a device copy stands in for the collective
+            recv.copy_(send)
+            return
         sc, rc = self.send_counts[k], self.recv_counts[k]
         if self.stage:
             send, recv_dev, recv = send.cpu(), recv, torch.empty(sum(rc), dtype=torch.float64)
@@ -359,10 +433,13 @@ class HaloSpmv:
     collectives on a side stream.  pipelined=False: pack, every chunk, then the whole multiply in one call (the plain step
     the pipelined one is checked against)."""
 
-    def __init__(self, local, device, overlap=True, stage_on_cpu=False, mode="a2a", c_step=False):
-        """c_step: the pipelined step through ONE C call (ehyb_halo_step) that calls back for every collective -- what a
-        C caller with its own RCCL communicator would use; here the callback is Python, so it saves nothing and serves as
-        the test of that entry point."""
+    def __init__(self, local, device, overlap=True, stage_on_cpu=False, mode="a2a", c_step=False, comm=None, graph=False):
+        """comm: a Comm (RCCL communicator of libehyb.so, make_comm) -- the step is then ONE C call, ehyb_halo_spmv: pack, the
+        chunks as grouped ncclSend / ncclRecv pairs on the communicator's stream, the parts of the multiply behind them; torch
+        takes no part in it.  Without one the collectives are torch.distributed's, issued from Python (the A/B arm, and the
+        only way over gloo).
+        c_step: the pipelined step through ONE C call (ehyb_halo_step) that calls back for every collective -- here the
+        callback is Python, so it saves nothing and serves as the test of that entry point."""
         import torch
 
         self.torch = torch
@@ -372,13 +449,29 @@ class HaloSpmv:
         self.x = torch.zeros(local.n_loc + local.n_ext, dtype=torch.float64, device=device)
         self.y = torch.zeros(local.n_loc, dtype=torch.float64, device=device)
         self.halo = HaloExchange(local, self.x, local.group, stage_on_cpu=stage_on_cpu, mode=mode)
-        self.overlap = overlap and local.world > 1
+        self.comm, self.c_halo = comm, None
+        if comm is not None and local.exchanges:
+            if comm.world != local.world or comm.rank != local.rank:
+                raise ValueError("HaloSpmv: the communicator and the matrix disagree about rank / world size")
+            self.c_halo = comm.halo(self.plan, local)
+            if graph:   # the whole step replayed from a hipGraph from its third call on (ehyb_halo_graph); eager if RCCL refuses the capture
+                H._check(H._lib.load().ehyb_halo_graph(self.c_halo, 1, None), "ehyb_halo_graph")
+        self.overlap = overlap and local.exchanges
         self.comm_stream = torch.cuda.Stream(device=device) if self.overlap else None
         st = self.plan.stats
         # a plan that multiplies in one launch (inline residual / direct shape) has no parts: plain steps only
         self.has_parts = not (st["er_inline"] > 0)
         self.lib = H._lib.load()
         self._xp, self._yp = C.c_void_p(self.x.data_ptr()), C.c_void_p(self.y.data_ptr())
+
+    def graph_state(self):
+        """0 off, 1 wanted, 2 replaying, -1 capture refused (steps run eagerly)."""
+        if self.c_halo is None:
+            return 0
+        st = C.c_int(0)
+        H._check(self.lib.ehyb_halo_graph(self.c_halo, -1, C.byref(st)), "ehyb_halo_graph")
+        self.graph_note = self.lib.ehyb_last_error().decode(errors="replace") if st.value < 0 else ""
+        return st.value
 
     def set_x_local(self, x_local):
         """x_local: this rank's x segment in global label order."""
@@ -396,7 +489,12 @@ class HaloSpmv:
         cur = cur_s.cuda_stream
         xp, yp = self.x.data_ptr(), self.y.data_ptr()
         L = self.L
-        if L.world == 1:
+        if self.c_halo is not None:
+            rc = self.lib.ehyb_halo_spmv(self.c_halo, self._xp, self._yp, cur)
+            if rc:
+                H._check(rc, "ehyb_halo_spmv")
+            return
+        if not L.exchanges:
             self.plan.spmv(xp, yp, cur)
             return
         if not (self.overlap and self.has_parts):
@@ -441,7 +539,7 @@ class HaloSpmv:
         work can run while the first chunk is on the wire."""
         torch = self.torch
         cur = torch.cuda.current_stream()
-        if not self.has_parts or self.L.world == 1:
+        if not self.has_parts or not self.L.exchanges:
             return 0.0, _time_local(self, iters)
         a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         for _ in range(3):
@@ -476,10 +574,14 @@ class GatherSpmv:
     equal counts) straight into the part of x the residual phase reads, overlapped with the ELL phase,
     which needs local columns only.  No pack or unpack kernel on either side."""
 
-    def __init__(self, local, device, overlap=True, stage_on_cpu=False):
+    def __init__(self, local, device, overlap=True, stage_on_cpu=False, comm=None):
+        """comm: a Comm -- the step is then ONE C call (ehyb_gather_spmv: ncclAllGather on the communicator's stream beside the ELL
+        phase, then the residual phase)."""
         import torch
         import torch.distributed as dist
 
+        self.comm = comm if (comm is not None and local.world > 1) else None
+        self.lib = H._lib.load()
         assert local.exchange == "allgather" or local.world == 1
         self.torch, self.dist = torch, dist
         self.L = local
@@ -513,6 +615,11 @@ class GatherSpmv:
         xp, yp = self.x.data_ptr(), self.y.data_ptr()
         if self.L.world == 1:
             self.plan.spmv(xp, yp, cur.cuda_stream)
+            return
+        if self.comm is not None:
+            rc = self.lib.ehyb_gather_spmv(self.comm.h, self.plan.h, xp, yp, self.seg_len, cur.cuda_stream)
+            if rc:
+                H._check(rc, "ehyb_gather_spmv")
             return
         if not self.overlap:
             self.exchange()
@@ -571,6 +678,10 @@ class HaloCG:
 
     def _allreduce(self, view):
         if self.L.world == 1:
+            return
+        if getattr(self.sh, "comm", None) is not None:
+            # RCCL from C, on the stream the vector kernels run on: in order with them, no host round trip
+            self.sh.comm.allreduce_sum(view.data_ptr(), view.numel(), self.torch.cuda.current_stream().cuda_stream)
             return
         if self.stage:
             h = view.cpu()

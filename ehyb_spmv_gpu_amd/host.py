@@ -378,10 +378,18 @@ class Plan:
         buf = (C.c_char * (cnt.value * np.dtype(dtype).itemsize)).from_address(p.value)
         return np.frombuffer(buf, dtype=dtype, count=cnt.value).copy()
 
-    def spmv(self, x_dev, y_dev, stream=0, phase=0):
-        """Asynchronous y = A x on device pointers (ints)."""
+    def spmv(self, x_dev, y_dev, stream=0, phase=0, walk=None):
+        """Asynchronous y = A x on device pointers (ints).  walk: None = the plan's own alternation (ehyb_spmv), 0 / 1 = this
+        launch walks its streams first to last / last to first (ehyb_spmv_walk)."""
+        if walk is not None:
+            _check(self.lib.ehyb_spmv_walk(self.h, C.c_void_p(x_dev), C.c_void_p(y_dev), C.c_void_p(stream), int(walk)), "ehyb_spmv_walk")
+            return
         _check(self.lib.ehyb_spmv_phase(self.h, C.c_void_p(x_dev), C.c_void_p(y_dev), C.c_void_p(stream), phase),
                "ehyb_spmv")
+
+    def graph(self, x_dev, y_dev, multiplies=1):
+        """ehyb_spmv_graph_create: `multiplies` multiplies captured into a hipGraph that keeps the alternating walk -> SpmvGraph"""
+        return SpmvGraph(self, x_dev, y_dev, multiplies)
 
     def tune(self, x_dev, y_dev, reps=5):
         """ehyb_plan_tune: the heaviest work items on the XCDs measured fastest -> (launch span before, after) in us."""
@@ -476,6 +484,44 @@ def device_count():
     c = C.c_int(0)
     _lib.load().ehyb_device_count(C.byref(c))
     return c.value
+
+
+class SpmvGraph:
+    """A captured run of multiplies of one plan (include/ehyb.h: ehyb_spmv_graph_create / ehyb_graph_launch)."""
+
+    def __init__(self, plan, x_dev, y_dev, multiplies=1):
+        self.lib = plan.lib
+        self.h = C.c_void_p()
+        _check(self.lib.ehyb_spmv_graph_create(plan.h, C.c_void_p(x_dev), C.c_void_p(y_dev), int(multiplies), C.byref(self.h)), "ehyb_spmv_graph_create")
+
+    def launch(self, stream=0):
+        _check(self.lib.ehyb_graph_launch(self.h, C.c_void_p(stream)), "ehyb_graph_launch")
+
+    def destroy(self):
+        if self.h:
+            self.lib.ehyb_graph_destroy(self.h)
+            self.h = None
+
+
+class Stream:
+    """ehyb_stream_create: a non-blocking HIP stream for callers without a HIP binding (tests)."""
+
+    def __init__(self):
+        self.lib = _lib.load()
+        self.p = C.c_void_p()
+        _check(self.lib.ehyb_stream_create(C.byref(self.p)), "ehyb_stream_create")
+
+    @property
+    def ptr(self):
+        return self.p.value
+
+    def sync(self):
+        _check(self.lib.ehyb_stream_sync(self.p), "ehyb_stream_sync")
+
+    def destroy(self):
+        if self.p:
+            self.lib.ehyb_stream_destroy(self.p)
+            self.p = None
 
 
 class DeviceBuffer:

@@ -420,6 +420,31 @@ int ehyb_plan_host_array(const ehyb_plan* plan, int which, const void** ptr, int
  * overlap on different streams (the reference is not re-entrant either: global device counters).
  */
 int ehyb_spmv(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream);
+/*
+ * THE WALK.  Successive multiplies of a plan whose streams do not fit the 256 MB Infinity Cache walk them in ALTERNATING
+ * directions (cfg.ell_alternate), so that a launch starts with what the one before it left in that cache: a loop of multiplies
+ * -- a solver's -- runs about 10 % faster than the same launches all first to last (audikw_1-like: 76 against 83 us).  A single
+ * multiply after other work gets the cold-cache time either way.  The direction is per-plan state, flipped atomically by every
+ * launch: several host threads may multiply with ONE plan on their own streams and vectors at the same time where the plan
+ * multiplies in ELL launches only (no panel-form residual: see above); with plain storage the result does not depend on the
+ * direction bit for bit, with symmetric pair storage it differs by the rounding of the LDS adds' order, as between any two launches.
+ * ehyb_spmv_walk states the direction per call: EHYB_WALK_AUTO = ehyb_spmv, _FIRST_TO_LAST / _LAST_TO_FIRST explicit (honoured
+ * whatever cfg.ell_alternate says) -- what a caller that captures multiplies into its own hipGraph uses, because a captured launch
+ * keeps the direction it was captured with: capture an even number of multiplies with alternating directions, or use
+ * ehyb_spmv_graph_create, which does exactly that.
+ */
+enum { EHYB_WALK_AUTO = -1, EHYB_WALK_FIRST_TO_LAST = 0, EHYB_WALK_LAST_TO_FIRST = 1 };
+int ehyb_spmv_walk(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream, int walk);
+/*
+ * `multiplies` back-to-back multiplies y = A x captured into a hipGraph with the directions alternating explicitly inside the run;
+ * for an odd count (1: the solver that launches one multiply per iteration) TWO executables are captured, beginning first-to-last
+ * and last-to-first, and ehyb_graph_launch replays them in turn -- the alternation survives the capture.  x and y are bound at
+ * capture.  One launch at a time per graph object.
+ */
+typedef struct ehyb_graph ehyb_graph;
+int ehyb_spmv_graph_create(ehyb_plan* plan, const double* x_dev, double* y_dev, int multiplies, ehyb_graph** graph);
+int ehyb_graph_launch(ehyb_graph* graph, void* stream);
+void ehyb_graph_destroy(ehyb_graph* graph);
 
 /* phase 1: ELL part only (needs only window columns);  phase 2: residual only
  * (y += ...);  phase 0: both.  Lets a multi-GPU caller overlap the x exchange.
@@ -482,6 +507,52 @@ int ehyb_halo_step(ehyb_plan* plan, const double* x_dev, double* y_dev, const in
                    int n_chunks, ehyb_exchange_fn exchange, void* user, void* compute_stream, void* comm_stream);
 
 /*
+ * ---- RCCL-native exchange (multi-GPU, one process per GPU; no reference counterpart: kernel.h:12 is a commented-out mpi.h).
+ * librccl is opened at run time (dlopen; inside a process that has loaded torch the soname resolves to torch's copy), so a
+ * single-GPU caller needs no RCCL.  A communicator is made from a ncclUniqueId that rank 0 creates and the caller hands to
+ * every rank (bench.py / dist.py: a torch.distributed broadcast of the 128 bytes); the device current at
+ * ehyb_comm_create is the rank's GPU.  The communicator owns a high-priority stream its exchanges run on.
+ */
+#define EHYB_COMM_ID_BYTES 128
+typedef struct ehyb_comm ehyb_comm;
+int ehyb_rccl_version(int* version, char* where, int where_len);   /* ncclGetVersion + the file name dlopen found; EHYB_ERR_STATE: no librccl */
+int ehyb_comm_unique_id(void* id_out /* EHYB_COMM_ID_BYTES */);     /* ncclGetUniqueId */
+int ehyb_comm_create(const void* id, int rank, int world, ehyb_comm** comm);   /* ncclCommInitRank: collective over all ranks */
+void ehyb_comm_destroy(ehyb_comm* comm);
+int ehyb_comm_info(const ehyb_comm* comm, int* rank, int* world, void** stream);
+/* sum of `count` doubles over the ranks, in place (the dot products of a distributed CG); stream NULL = the communicator's */
+int ehyb_comm_allreduce_sum(ehyb_comm* comm, double* buf_dev, int64_t count, void* stream);
+int ehyb_comm_allgather(ehyb_comm* comm, const double* send_dev, double* recv_dev, int64_t count_per_rank, void* stream);
+/*
+ * One rank's halo exchange + multiply as ONE host call per step (ehyb_halo_spmv), for a plan made by ehyb_plan_create_segs
+ * with 1 + n_chunks column segments: [own columns | ghost columns of chunk 0 | chunk 1 | ...], inside a chunk the entries
+ * of peer 0, peer 1, ... in rank order.
+ *   send_idx_host   n_send own columns (plan order) the peers asked for, chunk by chunk, inside a chunk peer by peer;
+ *   send_counts / recv_counts   [n_chunks * world]: doubles sent to / received from peer p in chunk k (entry k*world + p;
+ *                   what rank a sends to b in chunk k must be what b receives from a -- the caller agrees on that when it
+ *                   builds the lists, dist.py: RankLocalMatrix).  A rank may send to itself (world 1: the loop-back test).
+ * ehyb_halo_spmv(h, x, y, stream): pack (one gather) on `stream`; on the communicator's stream, behind the pack, chunk
+ * after chunk as a group of ncclSend / ncclRecv pairs straight into the ghost columns of x; on `stream` the own-column
+ * part at once, then chunk k's panels as soon as chunk k has landed, the closing pass last -- the panels of chunk k multiply
+ * while chunk k+1 is on the wire.  Plans that multiply in one launch exchange first, then multiply.  Asynchronous.
+ * The plan, x and y must outlive the calls; one step at a time per halo object.
+ */
+typedef struct ehyb_halo ehyb_halo;
+int ehyb_halo_create(ehyb_comm* comm, ehyb_plan* plan, int n_chunks, const int32_t* send_idx_host, int64_t n_send,
+                     const int64_t* send_counts, const int64_t* recv_counts, ehyb_halo** halo);
+void ehyb_halo_destroy(ehyb_halo* halo);
+int ehyb_halo_spmv(ehyb_halo* halo, double* x_dev, double* y_dev, void* compute_stream);
+/* on > 0: from the third step on the whole step (pack, the RCCL exchanges, every part, both streams) is captured into hipGraphs --
+ * one per walk direction of the plan (cfg.ell_alternate), replayed in turn -- and a multiply costs the host ONE hipGraphLaunch;
+ * x, y and the stream must then stay the same from step to step (a change is noticed and captured anew).  on = 0: off (default);
+ * on < 0: query only.  *state (may be NULL): 0 off, 1 wanted, 2 replaying, -1 the capture was refused by HIP or by this RCCL --
+ * the steps then run eagerly as if the call had not been made. */
+int ehyb_halo_graph(ehyb_halo* halo, int on, int* state);
+/* north_star's "all-gatherv of x" as one call per step: x = [own segment padded to seg_len | segment of rank 0 | ... | of rank
+ * world-1]; ncclAllGather on the communicator's stream while the ELL phase runs, then the residual phase (dist.py: GatherSpmv) */
+int ehyb_gather_spmv(ehyb_comm* comm, ehyb_plan* plan, double* x_dev, double* y_dev, int64_t seg_len, void* compute_stream);
+
+/*
  * Timed loop on device-resident vectors: `warmup` untimed multiplies, then `iters`
  * multiplies bracketed by HIP events on `stream` (no copies inside, residual recomputed
  * every time: SURVEY 8d "Timing protocol").  ms_total = whole loop.  If ms_ell / ms_er
@@ -540,6 +611,10 @@ int ehyb_dev_free(void* ptr);
 int ehyb_h2d(void* dst_dev, const void* src_host, size_t bytes);
 int ehyb_d2h(void* dst_host, const void* src_dev, size_t bytes);
 int ehyb_dev_sync(void);
+/* a non-blocking stream of the current device (hipStream_t as void*), for callers without a HIP binding of their own */
+int ehyb_stream_create(void** stream);
+int ehyb_stream_destroy(void* stream);
+int ehyb_stream_sync(void* stream);
 /* free and total device memory in bytes (hipMemGetInfo): what a harness checks a plan's life cycle against */
 int ehyb_dev_mem_info(size_t* free_bytes, size_t* total_bytes);
 /* Streaming-read ceiling of this device: sums `bytes` of doubles `iters` times, returns GB/s. */

@@ -166,3 +166,64 @@ def test_gzip_input_and_parallel_parse(E, tmp_path):
     with pytest.raises(E.EhybError) as e:
         E.Matrix.read_mtx(tmp_path / "short.mtx")
     assert e.value.code == 6 and "bad entry 999 " in str(e.value)
+
+
+def test_number_parsing_is_exactly_strtod(E, tmp_path):
+    """The reader parses the body itself (glibc's strtod costs 300-500 ns per 17-digit value, audikw_1 has 39 M lines): the fast
+    path -- up to 19 digits and |exponent| <= 27 in one x87 extended operation, anything else handed to strtod -- must return what
+    fscanf("%lg") returns (solver_test.c:97,197) for every spelling: checked bit for bit against libc's strtod."""
+    import ctypes
+    import random
+
+    random.seed(11)
+    vals = []
+    for _ in range(60000):
+        nd = random.randint(1, 21)
+        digs = "".join(random.choice("0123456789") for _ in range(nd))
+        pos = random.randint(0, nd)
+        s = digs[:pos] + "." + digs[pos:] if random.random() < 0.8 else digs
+        s = "0." if s == "." else s
+        if random.random() < 0.6:
+            s += random.choice("eE") + random.choice(["", "+", "-"]) + str(random.randint(0, 40 if random.random() < 0.9 else 320))
+        vals.append(("-" if random.random() < 0.3 else "") + s)
+    vals += ["1e23", "8.5e-324", "4.9e-324", "1.7976931348623157e308", "0.1", "123456789012345678", "9007199254740993", "9007199254740992.5",
+             "1.0000000000000002220446049250313080847263336181640625", "2.2250738585072011e-308", "1e-400", "1e400", "5e-324", ".5", "5.",
+             "+3.25", "inf", "-inf", "nan", "0x1p3", "1e", "1e+", "2.5e-", "7.e2", "00012.500e+001", "-0", "-0.0e5"]
+    n = len(vals)
+    path = tmp_path / "numbers.mtx"
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write(f"{n} {n} {n}\n")
+        for i, s in enumerate(vals):
+            f.write(f"{i + 1} {(i * 7) % n + 1} {s}\n")
+    m = E.Matrix.read_mtx(path)
+    libc = ctypes.CDLL(None)
+    libc.strtod.restype, libc.strtod.argtypes = ctypes.c_double, [ctypes.c_char_p, ctypes.c_void_p]
+    want = np.array([libc.strtod(s.encode(), None) for s in vals])
+    got = m.V
+    assert np.array_equal(np.isnan(got), np.isnan(want))
+    ok = ~np.isnan(want)
+    assert np.array_equal(got[ok].view(np.int64), want[ok].view(np.int64))     # bit for bit, the sign of zero included
+
+
+def test_comment_and_blank_lines_inside_the_body(E, tmp_path):
+    """The fast line count takes every line of the body for an entry; a body with comments or blank lines is noticed while parsing
+    and counted exactly."""
+    path = tmp_path / "gaps.mtx"
+    rows = 30000
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real symmetric\n% a comment\n")
+        f.write(f"{rows} {rows} {2 * rows - 1}\n")
+        for i in range(rows):
+            f.write(f"{i + 1} {i + 1} {2.0 + i}\n")
+            if i % 1000 == 500:
+                f.write("% comment inside the body\n\n   \n")
+            if i:
+                f.write(f"{i + 1} {i} -1.5\n")
+    m = E.Matrix.read_mtx(path)
+    assert m.symmetric and m.n == rows and m.nnz == 3 * rows - 2
+    assert np.array_equal(m.I[:3], [0, 0, 1]) and np.array_equal(m.J[:4], [0, 1, 1, 0])     # row 0: (0,0), the mirror of (1,0); row 1: (1,1), (1,0)
+    d = np.zeros(rows)
+    np.add.at(d, m.I[m.I == m.J], m.V[m.I == m.J])
+    assert np.array_equal(d, 2.0 + np.arange(rows))
+    assert np.all(m.V[m.I != m.J] == -1.5) and (m.I != m.J).sum() == 2 * (rows - 1)

@@ -40,17 +40,24 @@ def main():
     cur = torch.cuda.current_stream()
     out = {}
 
-    def timed(name, fn):
+    def timed(name, fn, batch=8):
+        """Host time to ISSUE one call: batches of `batch` calls on an idle device (a queue that runs full -- HIP's, or RCCL's work
+        FIFO -- would make the host wait for the device and the figure the device's), and the time per call incl. the device."""
         for _ in range(10):
             fn()
         torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        for _ in range(args.reps):
-            fn()
-        t_issue = time.perf_counter() - t0
-        torch.cuda.synchronize()
-        t_all = time.perf_counter() - t0
-        out[name] = {"host_us_per_call": round(t_issue / args.reps * 1e6, 1), "us_per_call_incl_device": round(t_all / args.reps * 1e6, 1)}
+        t_issue = 0.0
+        t0_all = time.perf_counter()
+        done = 0
+        while done < args.reps:
+            t0 = time.perf_counter()
+            for _ in range(batch):
+                fn()
+            t_issue += time.perf_counter() - t0
+            torch.cuda.synchronize()
+            done += batch
+        t_all = time.perf_counter() - t0_all
+        out[name] = {"host_us_per_call": round(t_issue / done * 1e6, 1), "us_per_call_incl_device_and_sync": round(t_all / done * 1e6, 1)}
 
     def a2a():
         with torch.cuda.stream(comm):
@@ -76,9 +83,34 @@ def main():
         lib.ehyb_step_part(plan.h, C.c_void_p(x.data_ptr()), C.c_void_p(y.data_ptr()), C.c_void_p(cur.cuda_stream), C.c_void_p(comm.cuda_stream), 1, 2, 3, 2)
 
     timed("three ehyb_step_part calls (own columns, chunk 0, chunk 1 + closing pass; R-MAT 2^18)", parts)
+    # ---- the whole step as ONE C call over libehyb.so's own RCCL communicator (csrc/ehyb_comm.hip): a rank-local R-MAT whose
+    # ghost columns are 60 % of its own columns, sent to itself in two chunks (0.25 / 0.75, bench.py's default) -- the ncclGroup +
+    # launch path of a real step without the wire
+    from ehyb_spmv_gpu_amd import dist as D
+
+    cfg_g = E.make_config(partitioner=E.EHYB_PART_DEGREE)
+    cfg_p = E.make_config(partitioner=E.EHYB_PART_DEGREE, er_mode=2)
+    mm = E.Matrix.generate("rmat", 18, 1 << 21, 1, cfg=cfg_g)
+    I, J, V, n_r = mm.I.copy(), mm.J.copy(), mm.V.copy(), mm.n
+    mm.free()
+    L = D.RankLocalMatrix(I, J, V, [0, n_r], 0, cfg_p, chunks=2, chunk_shares=[0.25, 0.75], loopback=0.6)
+    c = D.Comm(D.Comm.unique_id(), 0, 1)
+    sh_c = D.HaloSpmv(L, dev, comm=c)
+    sh_py = D.HaloSpmv(L, dev)                      # the same step issued part by part from Python (device copies as the collective)
+    for sh in (sh_c, sh_py):
+        sh.set_x_local(np.ones(n_r))
+    timed("WHOLE STEP, one C call: ehyb_halo_spmv over RCCL (pack + 2 grouped send/recv exchanges + 3 parts + closing pass; R-MAT 2^18, %d ghost columns)" % L.n_ghost,
+          sh_c.step)
+    sh_g = D.HaloSpmv(L, dev, comm=c, graph=True)
+    sh_g.set_x_local(np.ones(n_r))
+    for _ in range(4):
+        sh_g.step()
+    timed("WHOLE STEP replayed from a hipGraph (ehyb_halo_graph; state %d: 2 = replaying, -1 = capture refused, eager)" % sh_g.graph_state(), sh_g.step)
+    timed("WHOLE STEP issued from Python: ehyb_step_pack + 3 ehyb_step_part + 2 device copies in place of the collectives", sh_py.step)
     import json
 
     print(json.dumps(out, indent=1))
+    c.destroy()
     dist.destroy_process_group()
 
 
