@@ -127,7 +127,7 @@ def pmc_traffic(workload, sym, kernel, st=None):
     return e.get("hbm_bytes_per_launch")
 
 
-def live_pmc_traffic(workload, sym, kname, st, log, timeout_s=300):
+def live_pmc_traffic(workload, sym, kname, st, log, timeout_s=300, mtx=""):
     """HBM bytes per launch of the dominant kernel MEASURED BY THIS RUN, not looked up: two child processes -- tools/pmc_run.py
     (the same generator, reorder and plan, a 1 GiB streaming read for the calibration of FETCH_SIZE, ten multiplies) under
     `rocprofv3 --pmc FETCH_SIZE --kernel-trace` and `--pmc WRITE_SIZE --kernel-trace`, separate passes as MI355X_MICROARCH.md
@@ -141,7 +141,7 @@ def live_pmc_traffic(workload, sym, kname, st, log, timeout_s=300):
     rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
     if not os.path.exists(rocprof):
         return None, "rocprofv3 not found"
-    if workload not in WORKLOADS:
+    if workload not in WORKLOADS and not mtx:
         return None, "not a generator workload"
     tools = os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools")
     tmp = tempfile.mkdtemp(prefix="ehyb_pmc_", dir="/tmp")
@@ -150,7 +150,7 @@ def live_pmc_traffic(workload, sym, kname, st, log, timeout_s=300):
     try:
         for counter, sub in (("FETCH_SIZE", "fetch"), ("WRITE_SIZE", "write")):
             cmd = [rocprof, "--pmc", counter, "--kernel-trace", "--output-format", "csv", "-d", os.path.join(tmp, sub), "--",
-                   sys.executable, os.path.join(tools, "pmc_run.py"), "--workload", workload] + ([] if sym else ["--plain"])
+                   sys.executable, os.path.join(tools, "pmc_run.py")] + (["--mtx", os.path.abspath(mtx)] if mtx else ["--workload", workload]) + ([] if sym else ["--plain"])
             if sub == "fetch":
                 cmd += ["--layout-out", os.path.join(tmp, "layout.json")]
             rc, err = run_in_own_group(cmd, env, "/tmp", timeout_s)
@@ -908,9 +908,9 @@ def main():
     kname = dominant_kernel(st, ell_ms, er_ms)
     traffic = pmc_traffic(args.workload, st["sym_pairs"] > 0, kname, st)
     traffic_table, live_detail = traffic, None
-    if not args.no_live_pmc and not args.mtx:
+    if not args.no_live_pmc:
         # the counters taken by THIS run (child processes under rocprofv3, after the timed loop: nothing of it is inside `value`)
-        live, live_detail = side_arm_pair("live PMC traffic", lambda: live_pmc_traffic(args.workload, st["sym_pairs"] > 0, kname, st, log), log)
+        live, live_detail = side_arm_pair("live PMC traffic", lambda: live_pmc_traffic(args.workload, st["sym_pairs"] > 0, kname, st, log, mtx=args.mtx), log)
         if live:
             traffic = live
         else:

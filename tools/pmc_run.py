@@ -17,6 +17,7 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", default="audikw_1-like")
+    ap.add_argument("--mtx", default="", help="a Matrix Market file instead of a generator workload (bench.py --mtx): storage from its banner as bench.py chooses it")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--plain", action="store_true", help="every entry stored even for a symmetric workload")
     ap.add_argument("--layout-out", default="", help="write the plan's layout fingerprint (bench.layout_fingerprint) here: pmc_parse.py stores it with the entry")
@@ -28,10 +29,18 @@ def main():
     lib = _lib.load()
     bw = C.c_double()
     lib.ehyb_measure_read_bw(1 << 30, 5, C.byref(bw))  # 8 launches of ehyb_read_kernel over 1 GiB
-    gen, gargs, _ = B.WORKLOADS[args.workload]
-    sym = B.symmetric_storage_pays(gen, gargs) and not args.plain  # as bench.py does
-    cfg = E.make_config(sym_pairs=1 if sym else 0, partitioner=B.partitioner_for(E, gen))
-    m = E.Matrix.generate(gen, *gargs, cfg=cfg)
+    if args.mtx:
+        probe = E.Matrix.read_mtx(args.mtx)
+        sym = probe.symmetric and probe.n >= B.SYM_MIN_ROWS and not args.plain   # as bench.py --mtx does
+        probe.free()
+        cfg = E.make_config(sym_pairs=1 if sym else 0, partitioner=B.partitioner_for(E, "file"))
+        m = E.Matrix.read_mtx(args.mtx, cfg)
+        args.workload = os.path.splitext(os.path.basename(args.mtx))[0]
+    else:
+        gen, gargs, _ = B.WORKLOADS[args.workload]
+        sym = B.symmetric_storage_pays(gen, gargs) and not args.plain  # as bench.py does
+        cfg = E.make_config(sym_pairs=1 if sym else 0, partitioner=B.partitioner_for(E, gen))
+        m = E.Matrix.generate(gen, *gargs, cfg=cfg)
     x = E.x_glibc(m.n)
     m.reorder(cfg)
     xp = E.vector_reorder(x, m.reorder_list)

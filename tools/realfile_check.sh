@@ -25,7 +25,7 @@ for rep in range(2):
     r.free()
 PY
 cat $O/${TAG}_realfile_write.txt
-( cd $W/read && /usr/bin/time -f "gzip -1: %e s" gzip -1 -k -f audikw_1_like.mtx && mv audikw_1_like.mtx.gz audikw_1_like_gz.mtx.gz && ls -la ) 2>&1 | tail -4
+( cd $W/read && T0=$(date +%s.%N) && gzip -1 -k -f audikw_1_like.mtx && mv audikw_1_like.mtx.gz audikw_1_like_gz.mtx.gz && echo "gzip -1: $(python3 -c "import sys,time; print(round(time.time() - float(sys.argv[1]), 2))" $T0) s" && ls -la ) 2>&1 | tail -4
 python - "$W" >> $O/${TAG}_realfile_write.txt 2>&1 <<'PY'
 import os, sys, time
 sys.path.insert(0, os.environ["GRAFT_REPO_ROOT"])
@@ -39,7 +39,9 @@ tail -5 $O/${TAG}_realfile_write.txt
 # the reference's way: ./read/<name>.mtx relative to the working directory, -m name -i iters (solver_test.c:284,318-321); -c = the plan cache
 cd $W
 for pass in miss hit; do
-  /usr/bin/time -f "solver_test wall clock (plan cache $pass): %e s" $GRAFT_REPO_ROOT/ehyb_spmv_gpu_amd/solver_test -m audikw_1_like -i 2000 -c $W/plan.cache -v > $O/${TAG}_solver_test_$pass.txt 2>&1
+  T0=$(date +%s.%N)
+  $GRAFT_REPO_ROOT/ehyb_spmv_gpu_amd/solver_test -m audikw_1_like -i 2000 -c $W/plan.cache -v > $O/${TAG}_solver_test_$pass.txt 2>&1
+  echo "solver_test wall clock (plan cache $pass): $(python3 -c "import sys,time; print(round(time.time() - float(sys.argv[1]), 2))" $T0) s" | tee -a $O/${TAG}_solver_test_$pass.txt
   grep -a "filename\|parts is\|reorder time\|plan cache\|iter is\|strict check\|PASSED\|FAILED\|wall clock\|symmetric pair\|CPU reference" $O/${TAG}_solver_test_$pass.txt
 done
 cd $GRAFT_REPO_ROOT
