@@ -1,6 +1,8 @@
 // Error text, configuration defaults, the sizing heuristic and the small vector helpers.
 #include "ehyb_internal.h"
 
+#include <sys/mman.h>
+
 #include <omp.h>
 #include <sched.h>
 
@@ -58,6 +60,29 @@ double wall_seconds()
 {
     using namespace std::chrono;
     return duration<double>(steady_clock::now().time_since_epoch()).count();
+}
+
+// Fresh pages of a large array that is about to be filled: mapped in by the kernel in one sweep (madvise MADV_POPULATE_WRITE,
+// Linux 5.14+) instead of one page-fault trap per 4 KiB on first touch.  Measured on the build container (8 CPUs): filling a fresh
+// 620 MB array 0.33 s -> 0.026 s of populate + 0.014 s of fill; the permuted I / J / V of the bench matrix (1.24 GB) were 0.74 s of
+// the reorder step, nearly all of it these traps.  (Transparent huge pages were tried first -- MADV_HUGEPAGE -- and made it WORSE,
+// 0.74 -> 1.99 s: with defrag = madvise every huge-page fault compacts memory synchronously.)  A hint: an older kernel answers
+// EINVAL and the first touch pays as before.
+void prefault(void* p, size_t bytes)
+{
+#ifndef MADV_POPULATE_WRITE
+#define MADV_POPULATE_WRITE 23
+#endif
+    if (!p || bytes < (size_t(8) << 20)) return;
+    const uintptr_t lo = ((uintptr_t)p + 4095) & ~uintptr_t(4095), hi = ((uintptr_t)p + bytes) & ~uintptr_t(4095);
+    if (hi <= lo) return;
+    const size_t slice = size_t(16) << 20;
+    const int64_t n = (int64_t)((hi - lo + slice - 1) / slice);
+#pragma omp parallel for schedule(dynamic, 1)
+    for (int64_t i = 0; i < n; ++i) {
+        const uintptr_t a = lo + (uintptr_t)i * slice, b = std::min<uintptr_t>(hi, a + slice);
+        (void)madvise((void*)a, (size_t)(b - a), MADV_POPULATE_WRITE);
+    }
 }
 
 OmpScope::OmpScope(int want)

@@ -230,6 +230,13 @@ int mtmetis_partition(int n, const int64_t* xadj, const int* adjncy, int nparts,
 
 // ---------------------------------------------------------------- misc
 double wall_seconds();
+void prefault(void* p, size_t bytes);  // fresh pages of an array about to be filled, mapped in one sweep instead of a trap per page
+template <class T>
+inline void prefault_vector(std::vector<T>& v, size_t n)  // reserve + prefault: the resize / push_backs that follow touch mapped pages
+{
+    v.reserve(n);
+    prefault((void*)v.data(), n * sizeof(T));
+}
 int default_host_threads();  // OpenMP threads when cfg.host_threads is 0: capped by affinity and cgroup quota
 // The library's OpenMP regions run on cfg.host_threads (or the default above) threads; the caller's
 // own OpenMP setting (the calling thread's nthreads-var) is put back when the entry point returns.

@@ -257,7 +257,9 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     std::vector<int32_t> partner;     // per kept entry: the dropped entry it also stands for (value map only)
     const bool vmap = cfg.value_map == 1;
     if (sym) {
+        prefault_vector(state, (size_t)(rp[row_end] - k0));
         state.assign((size_t)(rp[row_end] - k0), 0);
+        if (vmap) prefault_vector(partner, state.size());
         if (vmap) partner.assign(state.size(), -1);
         dropped.assign(nrows, 0);
 #pragma omp parallel for schedule(dynamic, 2)
@@ -620,6 +622,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
 
     lap("inline form + prefix sums");
     // ---- pass 3: fill
+    prefault_vector(L->ell_val, (size_t)size_stream), prefault_vector(L->ell_col, (size_t)col_words);   // (fresh pages in one sweep: common.cpp)
     L->ell_val.assign((size_t)size_stream, 0.0);
     L->ell_col.assign((size_t)col_words, 0);
     L->lane_group.assign((size_t)nslabs * kSlabRows, 0);
@@ -630,6 +633,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     // slot maps (cfg.value_map): the entry every slot of a value stream is filled from, so that the numeric
     // phase can be repeated on the device for new values (ehyb_plan_set_values)
     std::vector<int32_t> tsrc(vmap && !view_m ? (size_t)nnz_er : 0);
+    if (vmap) prefault_vector(L->ell_src, (size_t)size_stream);
+    if (vmap && sym) prefault_vector(L->ell_src2, (size_t)size_stream);
     L->ell_src.assign(vmap ? (size_t)size_stream : 0, -1);
     L->ell_src2.assign(vmap && sym ? (size_t)size_stream : 0, -1);
     L->er_src.clear();
@@ -921,6 +926,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         L->er_seg_ptr[i + 1] = L->er_seg_ptr[i] + segs[i].len;
         L->er_seg_row[i] = segs[i].row;
     }
+    prefault_vector(L->er_col, (size_t)nnz_er), prefault_vector(L->er_val, (size_t)nnz_er);
     L->er_col.resize((size_t)nnz_er);
     L->er_val.resize((size_t)nnz_er);
     if (vmap) L->er_src.resize((size_t)nnz_er);

@@ -42,6 +42,7 @@ int alloc_matrix(int n, int64_t nnz, matrixCOO* m)
         ehyb_matrix_free(m);
         EHYB_FAIL(EHYB_ERR_ALLOC, "out of memory for a %d-row, %lld-entry matrix", n, (long long)nnz);
     }
+    prefault(m->I, e * sizeof(int)), prefault(m->J, e * sizeof(int)), prefault(m->V, e * sizeof(double));
     return EHYB_OK;
 }
 
@@ -247,6 +248,7 @@ int ehyb_mm_read(const char* path, const ehyb_config* cfg, matrixCOO* out, int* 
                 close(fd);
                 EHYB_FAIL(EHYB_ERR_ALLOC, "out of memory reading %s", path);
             }
+            prefault(text.heap, size);
             const size_t slice = size_t(8) << 20;
             const int64_t n_slices = (int64_t)((size + slice - 1) / slice);
             bool read_ok = true;
@@ -355,6 +357,7 @@ int ehyb_mm_read(const char* path, const ehyb_config* cfg, matrixCOO* out, int* 
     std::unique_ptr<int[]> fi_own(new (std::nothrow) int[(size_t)stored + 1]), fj_own(new (std::nothrow) int[(size_t)stored + 1]);
     std::unique_ptr<double[]> fv_own(new (std::nothrow) double[(size_t)stored + 1]);
     if (!fi_own || !fj_own || !fv_own) EHYB_FAIL(EHYB_ERR_ALLOC, "out of memory for %ld entries of %s", stored, path);
+    prefault(fi_own.get(), sizeof(int) * (size_t)stored), prefault(fj_own.get(), sizeof(int) * (size_t)stored), prefault(fv_own.get(), sizeof(double) * (size_t)stored);
     int* const fi = fi_own.get();
     int* const fj = fj_own.get();
     double* const fv = fv_own.get();

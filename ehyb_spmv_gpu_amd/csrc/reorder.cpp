@@ -680,6 +680,9 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
         free(nV);
         EHYB_FAIL(EHYB_ERR_ALLOC, "ehyb_matrix_reorder: out of memory for %lld entries", (long long)nnz);
     }
+    const double tp0 = wall_seconds();
+    prefault(nI, sizeof(int) * (size_t)nnz), prefault(nJ, sizeof(int) * (size_t)nnz), prefault(nV, sizeof(double) * (size_t)nnz);
+    const double tp1 = wall_seconds();
 #pragma omp parallel for schedule(dynamic, 1024)
     for (int ti = 0; ti < n; ++ti) {
         const int oi = rows_of[ti];
@@ -695,9 +698,11 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
         }
         num2[ti] = in_window;
     }
+    const double tp2 = wall_seconds();
     free(m->I);
     free(m->J);
     free(m->V);
+    if (c.verbose > 1) printf("  permute: setup %.3f prefault %.3f gather %.3f free %.3f s\n", tp0 - t_perm, tp1 - tp0, tp2 - tp1, wall_seconds() - tp2);
     m->I = nI;
     m->J = nJ;
     m->V = nV;
