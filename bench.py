@@ -370,6 +370,10 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     from oracle import oracle as O
 
     gen, gargs, desc = WORKLOADS[args.workload]
+    if args.exchange is None:
+        args.exchange = "cover" if gen == "rmat" else "halo"
+    if args.exchange == "cover" and gen != "rmat":
+        raise SystemExit("bench.py: --exchange cover builds every rank's plan in panel form: it is for the R-MAT workloads (a mesh's halo is a few per cent of x anyway)")
     t0 = time.time()
     if gen == "rmat":
         # no locality to find: contiguous row blocks with equal numbers of edge samples in the matrix's own
@@ -411,7 +415,7 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     L = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, symmetric=symmetric, exchange=args.exchange, chunks=args.chunks, chunk_shares=shares)
     del I, J
     comm, step_impl = step_comm(args, D, dist, stage_on_cpu, log)
-    if args.exchange == "halo":
+    if args.exchange in ("halo", "cover"):
         sh = D.HaloSpmv(L, dev, overlap=not args.no_overlap, stage_on_cpu=stage_on_cpu, mode=args.exchange_mode, comm=comm)
     else:
         sh = D.GatherSpmv(L, dev, overlap=not args.no_overlap, stage_on_cpu=stage_on_cpu, comm=comm)
@@ -423,11 +427,13 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     bad, worst = O.check_tolerance(sh.y_local(), y_cpu, scale)
     bad, worst = all_ranks_agree_or_exit(bad, worst, torch, dist, world, dev, "strong scaling")
     # per-rank time of the local multiply alone (no exchange), max over ranks: what is left is the exchange
-    if args.exchange == "halo":
+    if args.exchange in ("halo", "cover"):
         own_ms, sh_local_ms = sh.time_parts(args.steps)   # the part that needs the rank's own columns only, and the whole
     else:
         own_ms, sh_local_ms = 0.0, sh.time_local(args.steps)
-    stats = torch.tensor([float(L.n_ghost), float(sh_local_ms), float(len(V)), float(own_ms), float(L.nnz_own_cols)], dtype=torch.float64, device=dev)
+    n_partials = int(L.yrecv_counts.sum())       # exchange "cover": partial sums this rank receives per step (0 otherwise)
+    stats = torch.tensor([float(L.n_ghost), float(sh_local_ms), float(L.nnz), float(own_ms), float(L.nnz_own_cols), float(n_partials), float(L.nnz_exported)],
+                         dtype=torch.float64, device=dev)
     mx = stats.clone()
     dist.all_reduce(stats)
     dist.all_reduce(mx, op=dist.ReduceOp.MAX)
@@ -449,7 +455,7 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
         dist.barrier()
     if rank == 0:
         ms = elapsed / args.steps * 1e3
-        words = int(stats[0].item()) if args.exchange == "halo" else sh.seg_len * world * (world - 1)
+        words = int(stats[0].item() + stats[5].item()) if args.exchange in ("halo", "cover") else sh.seg_len * world * (world - 1)
         out = {
             "metric": "fp64 SpMV GFLOP/s (2*nnz/t_iter), EHYB on MI355X",
             "value": round(2.0 * nnz * args.steps / elapsed / 1e9, 2), "unit": "GFLOP/s", "n_gpus": world,
@@ -460,14 +466,17 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
                        "lds_doubles": int(cfg.lds_doubles), "part_rows": int(cfg.part_rows), "threads": int(cfg.threads),
                        "exchange": ("RCCL all_gather_into_tensor of the x segments (padded to %d doubles each), overlapped with the ELL phase" % sh.seg_len)
                        if args.exchange == "allgather" else
-                       ("halo: gather of the requested x entries + one group of ncclSend / ncclRecv pairs per exchange step (all_to_all pattern, issued "
+                       (args.exchange + ": gather of the requested x entries + one group of ncclSend / ncclRecv pairs per exchange step (all_to_all pattern, issued "
                         "from C on the communicator's own stream) straight into the ghost " if comm is not None else
-                        "halo: gather of the requested x entries + one RCCL all_to_all_single per exchange step straight into the ghost ") +
+                        args.exchange + ": gather of the requested x entries + one RCCL all_to_all_single per exchange step straight into the ghost ") +
                        "columns; own-column panels and the panels of the chunks already delivered multiply while the next chunk travels",
                        "exchange_doubles_received_all_gpus": words,
+                       "cover": ({"ghost_columns_all_gpus": int(stats[0].item()), "partial_sums_all_gpus": int(stats[5].item()), "entries_handed_to_the_column_owner": int(stats[6].item()),
+                                  "what": "per pair of ranks the hub columns of the block travel as x entries, the rest of the block is multiplied by the columns' owner, who ships "
+                                          "one partial sum per row (ehyb_halo_set_partials; DESIGN.md 5)"} if args.exchange == "cover" else None),
                        "step_issued_by": step_impl,
-                       "exchange_steps": L.chunks, "exchange_mode": ("grouped ncclSend/ncclRecv pairs" if comm is not None else args.exchange_mode) if args.exchange == "halo" else ("ncclAllGather" if comm is not None else "all_gather_into_tensor"),
-                       "pipelined": bool(args.exchange == "halo" and not args.no_overlap),
+                       "exchange_steps": L.chunks, "exchange_mode": ("grouped ncclSend/ncclRecv pairs" if comm is not None else args.exchange_mode) if args.exchange in ("halo", "cover") else ("ncclAllGather" if comm is not None else "all_gather_into_tensor"),
+                       "pipelined": bool(args.exchange in ("halo", "cover") and not args.no_overlap),
                        "recv_doubles_by_rank_step_peer": [[[int(v) for v in row.reshape(L.chunks, world)[k].tolist()] for k in range(L.chunks)]
                                                           for row in vol.cpu().numpy()] if world <= 8 else None,
                        "ghost_columns_per_gpu_max": int(mx[0].item()),
@@ -722,9 +731,11 @@ def main():
     ap.add_argument("--scaling", default="strong", choices=["weak", "strong"],
                     help="N>1: strong = ONE matrix sharded by rows (default workload rmat-24, config 5); "
                          "weak = the N=1 matrix once per GPU, rank-local build, halo exchange (fem3d workloads)")
-    ap.add_argument("--exchange", default="halo", choices=["halo", "allgather"],
-                    help="N>1 strong: halo = only the x entries a rank's rows reference (one all_to_all_single); "
-                         "allgather = every x segment to everyone, padded to equal length (one all_gather_into_tensor)")
+    ap.add_argument("--exchange", default=None, choices=["halo", "cover", "allgather"],
+                    help="N>1 strong: halo = the x entries a rank's rows reference, hottest first, in chunks; cover = per pair of ranks only the "
+                         "hub columns of the block travel as x, the rest of the block is handed to the columns' owner, who ships one partial "
+                         "sum per row (a vertex cover of the block: 2.2-2.7 x fewer doubles on R-MAT 2^24; panel-form plans = the R-MAT workloads); "
+                         "allgather = every x segment to everyone, padded to equal length.  Default: cover for the R-MAT workloads, halo otherwise")
     ap.add_argument("--chunks", type=int, default=2,
                     help="N>1 halo: exchange steps per multiply -- every owner's ghost columns, hottest first, are cut into this many "
                          "chunks; the panels of chunk k are multiplied while chunk k+1 is on the wire")

@@ -77,7 +77,8 @@ class Config(C.Structure):
         ("symbolic", C.c_int32),
         ("cg_fused_dot", C.c_int32),
         ("ell_alternate", C.c_int32),
-        ("reserved", C.c_int32 * 25),
+        ("row_split", C.c_int32),
+        ("reserved", C.c_int32 * 24),
     ]
 
 
@@ -143,6 +144,7 @@ SIGNATURES = {
     "ehyb_spmv_part": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int]),
     "ehyb_plan_col_segs": (C.c_int, [_vp, _ip]),
     "ehyb_gather": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
+    "ehyb_scatter_add": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp]),
     "ehyb_step_pack": (C.c_int, [_vp, _vp, _vp, C.c_int64, _vp, _vp]),
     "ehyb_step_part": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_int, C.c_int]),
     "ehyb_halo_step": (C.c_int, [_vp, _vp, _vp, _vp, _vp, C.c_int64, C.c_int, _vp, _vp, _vp, _vp]),
@@ -157,6 +159,7 @@ SIGNATURES = {
     "ehyb_halo_destroy": (None, [_vp]),
     "ehyb_halo_spmv": (C.c_int, [_vp, _vp, _vp, _vp]),
     "ehyb_halo_graph": (C.c_int, [_vp, C.c_int, _ip]),
+    "ehyb_halo_set_partials": (C.c_int, [_vp, C.c_int, _i64p, _i64p, _P(C.c_int32), C.c_int64]),
     "ehyb_gather_spmv": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "ehyb_spmv_bench": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _dp, _dp, _dp]),
     "ehyb_spmv_host": (C.c_int, [_vp, _dp, _dp, C.c_int]),
@@ -193,6 +196,7 @@ SIGNATURES = {
     "ehyb_gen_fem3d_block": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, C.c_int, C.c_int,
                                        _cfgp, _mp]),
     "ehyb_matrix_append_ghosts": (C.c_int, [_mp, C.c_int, C.c_int64, _ip, _ip, _dp]),
+    "ehyb_matrix_append_rows": (C.c_int, [_mp, C.c_int, C.c_int, C.c_int64, _ip, _ip, _dp, C.c_int]),
     "ehyb_gen_rmat": (C.c_int, [C.c_int, C.c_int64, C.c_uint64, _cfgp, _mp]),
     "ehyb_gen_rmat_block": (C.c_int, [C.c_int, C.c_int64, C.c_uint64, C.c_int, C.c_int, _ip, _cfgp, _mp]),
     "ehyb_gen_stencil2d": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _cfgp, _mp]),

@@ -167,6 +167,7 @@ Config resolve_config(const ehyb_config* in)
     c.symbolic = z.symbolic == 1 ? 1 : 2;
     c.cg_fused_dot = z.cg_fused_dot == 2 ? 2 : 1;
     c.ell_alternate = (z.ell_alternate == 1 || z.ell_alternate == 2) ? z.ell_alternate : 0;  // 0: by the size of the stream (launch_ell)
+    c.row_split = z.row_split > 0 ? z.row_split : 0;
     c.er_queue = z.er_queue == 1 ? 1 : 2;  // measured: no gain, so the default stays one workgroup per item
     // the automatic choice of the direct shape is for callers that left the window sizing alone: a caller
     // that names a window (lds_doubles / part_rows other than the defaults) gets that window
@@ -240,6 +241,7 @@ void ehyb_config_resolve(const ehyb_config* in, ehyb_config* out)
     r.symbolic = c.symbolic;
     r.cg_fused_dot = c.cg_fused_dot;
     r.ell_alternate = c.ell_alternate;
+    r.row_split = c.row_split;
     *out = r;
 }
 

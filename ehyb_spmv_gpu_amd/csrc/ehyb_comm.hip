@@ -137,6 +137,16 @@ struct ehyb_halo {
     hipStream_t gcs = nullptr;
     int gnext = 0;
     std::string graph_note;                    // why a capture was refused
+    // exchange "cover" (ehyb_halo_set_partials): the plan's rows from row_split on are partial sums for OTHER ranks' rows, computed
+    // here from this rank's own x entries; they leave as soon as they are closed, the ones computed elsewhere for this rank's rows
+    // arrive in d_ybuf and are added into y at the end of the step
+    bool cover = false;
+    int row_split = 0;
+    std::vector<int64_t> ysend_cnt, yrecv_cnt;  // [peer]
+    int64_t n_yrecv = 0;
+    double* d_ybuf = nullptr;
+    int32_t* d_yidx = nullptr;
+    hipEvent_t ev_foreign = nullptr, ev_partials = nullptr;
 };
 
 static void drop_graphs(ehyb_halo* h);
@@ -344,6 +354,10 @@ void ehyb_halo_destroy(ehyb_halo* h)
     drop_graphs(h);
     for (auto e : h->ev)
         if (e) (void)hipEventDestroy(e);
+    if (h->ev_foreign) (void)hipEventDestroy(h->ev_foreign);
+    if (h->ev_partials) (void)hipEventDestroy(h->ev_partials);
+    if (h->d_ybuf) (void)hipFree(h->d_ybuf);
+    if (h->d_yidx) (void)hipFree(h->d_yidx);
     if (h->d_send_idx) (void)hipFree(h->d_send_idx);
     if (h->d_send_buf) (void)hipFree(h->d_send_buf);
     delete h;
@@ -370,8 +384,62 @@ static int exchange_chunk(ehyb_halo* h, double* x, int k)
 // y = A [x own | ghosts] with the ghosts fetched on the way.  x_dev: the rank's own x entries in plan order, the ghost
 // columns behind them are WRITTEN by the exchange.  Asynchronous: everything is enqueued on compute_stream and the
 // communicator's stream; the result is complete when compute_stream has drained.
+// the partial sums this rank computed for the others (its plan's rows from row_split on, grouped by destination) against the ones the
+// others computed for it, on the communicator's stream
+static int exchange_partials(ehyb_halo* h, double* y)
+{
+    const ehyb_comm* c = h->comm;
+    NCCL_TRY(g_rccl.GroupStart());
+    ncclResult_t r = ncclSuccess;
+    int64_t so = h->row_split, ro = 0;
+    for (int p = 0; p < c->world && r == ncclSuccess; ++p) {
+        if (h->ysend_cnt[(size_t)p] > 0) r = g_rccl.Send(y + so, (size_t)h->ysend_cnt[(size_t)p], ncclFloat64, p, c->comm, c->stream);
+        if (r == ncclSuccess && h->yrecv_cnt[(size_t)p] > 0) r = g_rccl.Recv(h->d_ybuf + ro, (size_t)h->yrecv_cnt[(size_t)p], ncclFloat64, p, c->comm, c->stream);
+        so += h->ysend_cnt[(size_t)p];
+        ro += h->yrecv_cnt[(size_t)p];
+    }
+    ncclResult_t e = g_rccl.GroupEnd();
+    if (r != ncclSuccess || e != ncclSuccess) EHYB_FAIL(EHYB_ERR_HIP, "RCCL: exchange of the partial sums: %s", g_rccl.GetErrorString(r != ncclSuccess ? r : e));
+    return EHYB_OK;
+}
+
+// Exchange "cover": per pair of ranks the hub columns of the block travel as x entries (as in the plain halo step), the rest of the
+// block was handed to the column's owner, who multiplies it with its OWN x and ships one partial sum per row.  One step:
+//   compute   pack | segment 0 (own columns: own rows AND foreign rows) | close the foreign rows | chunk 0's panels | ... | close own rows | add partials
+//   comm           x chunk 0, x chunk 1, ...                          (after the foreign close:) partial sums out / in
+// The x entries leave at once and are needed only after segment 0 has been multiplied; the partial sums leave as soon as they exist
+// and are needed only at the very end: both directions hide behind the multiply.
+static int halo_step_cover(ehyb_halo* h, double* x_dev, double* y_dev, void* compute_stream)
+{
+    ehyb_comm* c = h->comm;
+    hipStream_t cs = (hipStream_t)compute_stream;
+    const int K = h->n_chunks;
+    int rc = ehyb_gather(x_dev, h->d_send_idx, h->d_send_buf, h->n_send, compute_stream);
+    if (rc != EHYB_OK) return rc;
+    HIP_TRY(hipEventRecord(h->ev[0], cs));
+    HIP_TRY(hipStreamWaitEvent(c->stream, h->ev[0], 0));
+    for (int k = 0; k < K; ++k) {
+        if ((rc = exchange_chunk(h, x_dev, k)) != EHYB_OK) return rc;
+        HIP_TRY(hipEventRecord(h->ev[1 + k], c->stream));
+    }
+    rc = ehyb_spmv_part(h->plan, x_dev, y_dev, compute_stream, 0, 1, EHYB_PART_FIRST | EHYB_PART_LAST_FOREIGN);
+    if (rc != EHYB_OK) return rc;
+    HIP_TRY(hipEventRecord(h->ev_foreign, cs));
+    HIP_TRY(hipStreamWaitEvent(c->stream, h->ev_foreign, 0));
+    if ((rc = exchange_partials(h, y_dev)) != EHYB_OK) return rc;
+    HIP_TRY(hipEventRecord(h->ev_partials, c->stream));
+    for (int k = 0; k < K && rc == EHYB_OK; ++k) {
+        HIP_TRY(hipStreamWaitEvent(cs, h->ev[1 + k], 0));
+        rc = ehyb_spmv_part(h->plan, x_dev, y_dev, compute_stream, 1 + k, 2 + k, k == K - 1 ? EHYB_PART_LAST : 0);
+    }
+    if (rc != EHYB_OK) return rc;
+    HIP_TRY(hipStreamWaitEvent(cs, h->ev_partials, 0));
+    return ehyb_scatter_add(y_dev, h->d_yidx, h->d_ybuf, h->n_yrecv, compute_stream);
+}
+
 static int halo_step_eager(ehyb_halo* h, double* x_dev, double* y_dev, void* compute_stream)
 {
+    if (h->cover) return halo_step_cover(h, x_dev, y_dev, compute_stream);
     ehyb_comm* c = h->comm;
     hipStream_t cs = (hipStream_t)compute_stream;
     const int K = h->n_chunks;
@@ -459,6 +527,44 @@ int ehyb_halo_spmv(ehyb_halo* h, double* x_dev, double* y_dev, void* compute_str
     }
     HIP_TRY(hipGraphLaunch(h->gexec[p], cs));
     h->gnext ^= 1;
+    return EHYB_OK;
+}
+
+// Turns the halo object into the "cover" exchange: the plan was built with cfg.row_split = row_split and its rows from there on are
+// this rank's FOREIGN rows, grouped by destination rank -- ysend_counts[p] of them are rank p's; yrecv_counts[p] partial sums arrive
+// from rank p, and partial i (in arrival order: peer 0's first) belongs to row yrecv_idx_host[i] of this rank (plan order).
+// y_dev of ehyb_halo_spmv then holds the own rows followed by the foreign rows.
+int ehyb_halo_set_partials(ehyb_halo* h, int row_split, const int64_t* ysend_counts, const int64_t* yrecv_counts, const int32_t* yrecv_idx_host, int64_t n_yrecv)
+{
+    clear_error();
+    if (!h || row_split <= 0 || !ysend_counts || !yrecv_counts || n_yrecv < 0 || (n_yrecv > 0 && !yrecv_idx_host))
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_halo_set_partials: bad arguments");
+    if (h->cover) EHYB_FAIL(EHYB_ERR_STATE, "ehyb_halo_set_partials: already set");
+    ehyb_stats st;
+    if (int rc = ehyb_plan_stats(h->plan, &st)) return rc;
+    if (h->plan->cfg.row_split != row_split) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_halo_set_partials: the plan was built with cfg.row_split = %d, not %d", h->plan->cfg.row_split, row_split);
+    if (!(st.er_partials > 0) || st.nnz_ell != 0 || !h->parts)
+        EHYB_FAIL(EHYB_ERR_STATE, "ehyb_halo_set_partials: the cover exchange needs a plan that multiplies in panel form alone (every window given up)");
+    const int W = h->comm->world;
+    int64_t ns = 0, nr = 0;
+    for (int p = 0; p < W; ++p) {
+        if (ysend_counts[p] < 0 || yrecv_counts[p] < 0) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_halo_set_partials: negative count");
+        ns += ysend_counts[p], nr += yrecv_counts[p];
+    }
+    if (nr != n_yrecv) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_halo_set_partials: the receive counts add up to %lld, the index list holds %lld", (long long)nr, (long long)n_yrecv);
+    if (row_split + ns > st.n_rows) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_halo_set_partials: %lld foreign rows behind row %d, the plan has %lld rows", (long long)ns, row_split, (long long)st.n_rows);
+    for (int64_t i = 0; i < n_yrecv; ++i)
+        if (yrecv_idx_host[i] < 0 || yrecv_idx_host[i] >= row_split) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_halo_set_partials: partial %lld goes to row %d, not one of the rank's own %d", (long long)i, yrecv_idx_host[i], row_split);
+    HIP_TRY(hipMalloc((void**)&h->d_ybuf, (size_t)std::max<int64_t>(n_yrecv, 1) * 8));
+    HIP_TRY(hipMalloc((void**)&h->d_yidx, (size_t)std::max<int64_t>(n_yrecv, 1) * 4));
+    if (n_yrecv > 0) HIP_TRY(hipMemcpy(h->d_yidx, yrecv_idx_host, (size_t)n_yrecv * 4, hipMemcpyHostToDevice));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_foreign, hipEventDisableTiming));
+    HIP_TRY(hipEventCreateWithFlags(&h->ev_partials, hipEventDisableTiming));
+    h->ysend_cnt.assign(ysend_counts, ysend_counts + W);
+    h->yrecv_cnt.assign(yrecv_counts, yrecv_counts + W);
+    h->n_yrecv = n_yrecv;
+    h->row_split = row_split;
+    h->cover = true;
     return EHYB_OK;
 }
 

@@ -744,6 +744,21 @@ __global__ __launch_bounds__(256) void ehyb_gather_kernel(const double* __restri
         if (base + j < n) dst[base + j] = v[j];
 }
 
+// y[idx[i]] += src[i]: partial sums computed elsewhere, added into this rank's rows (an index may occur more than once)
+__global__ __launch_bounds__(256) void ehyb_scatter_add_kernel(double* __restrict__ y, const int32_t* __restrict__ idx, const double* __restrict__ src, long long n)
+{
+    const long long base = ((long long)blockIdx.x * 256 + threadIdx.x) * 4;
+    int32_t k[4];
+    double v[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) k[j] = base + j < n ? idx[base + j] : 0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) v[j] = base + j < n ? src[base + j] : 0.0;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (base + j < n) unsafeAtomicAdd(&y[k[j]], v[j]);
+}
+
 // streaming-read probe for the on-box bandwidth ceiling
 __global__ __launch_bounds__(256) void ehyb_read_kernel(const double2* __restrict__ src, size_t n2, double* sink)
 {
@@ -871,10 +886,28 @@ int ehyb::spmv_xy(ehyb_plan* P, const double* x, double* y, void* stream, double
 }
 
 // which: 1 = pass 1 (scale), 2 = pass 2 (reduce), 3 = both; pass 1 over the items [unit_begin, unit_end) (-1: all)
-static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st, int probe, int which, int unit_begin = 0, int unit_end = -1)
+// first pass-2 unit whose rows lie at or behind cfg.row_split (= number of units: no split)
+static int pass2_split(const ehyb_plan* P)
 {
     const HostLayout& H = P->host;
-    const int u_all = (int)(H.pb_items1.size() / 2), u2 = (int)(H.pb_units2.size() / 4);
+    const int u2 = (int)(H.pb_units2.size() / 4);
+    if (P->cfg.row_split <= 0) return u2;
+    int lo = 0, hi = u2;   // units ascend by first row
+    while (lo < hi) {
+        const int mid = (lo + hi) / 2;
+        if (H.pb_units2[(size_t)mid * 4 + 2] < P->cfg.row_split) lo = mid + 1;
+        else hi = mid;
+    }
+    return lo;
+}
+
+// u2_part (pass 2): 0 = every row block, 1 = the blocks in front of cfg.row_split, 2 = the blocks from it on
+static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st, int probe, int which, int unit_begin = 0, int unit_end = -1, int u2_part = 0)
+{
+    const HostLayout& H = P->host;
+    const int u_all = (int)(H.pb_items1.size() / 2), u2_all = (int)(H.pb_units2.size() / 4);
+    const int u2_cut = u2_part ? pass2_split(P) : 0;
+    const int u2_first = u2_part == 2 ? u2_cut : 0, u2 = (u2_part == 1 ? u2_cut : u2_all) - u2_first;
     if (unit_end < 0) unit_end = u_all;
     if (unit_begin < 0 || unit_end > u_all || unit_begin > unit_end) EHYB_FAIL(EHYB_ERR_ARG, "launch_panel: items [%d, %d) of %d", unit_begin, unit_end, u_all);
     const int u1 = unit_end - unit_begin;
@@ -913,7 +946,7 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
 #undef PB_SCALE_P
     }
     if ((which & 2) && u2 > 0)
-        hipLaunchKernelGGL(ehyb_pb_reduce_kernel<512>, dim3(u2), dim3(512), (size_t)H.pb_rows_max * 8, st, (const int4*)P->d_pb_units2,
+        hipLaunchKernelGGL(ehyb_pb_reduce_kernel<512>, dim3(u2), dim3(512), (size_t)H.pb_rows_max * 8, st, (const int4*)P->d_pb_units2 + u2_first,
                            P->d_pb_partial, P->d_pb_row, y, probe);
     HIP_TRY(hipGetLastError());
     return EHYB_OK;
@@ -1454,7 +1487,14 @@ int ehyb_spmv_part(ehyb_plan* P, const double* x, double* y, void* stream, int s
         const int ue = H.pb_seg_item.empty() ? -1 : H.pb_seg_item[(size_t)seg_end];
         rc = launch_panel(P, x, y, st, 0, 1, ub, ue);
     }
-    if (rc == EHYB_OK && (flags & EHYB_PART_LAST)) rc = launch_panel(P, x, y, st, 0, 2);
+    // the closing pass: all row blocks, or -- with cfg.row_split -- the foreign rows first (EHYB_PART_LAST_FOREIGN, as soon as
+    // segment 0's pass 1 is enqueued) and the rows in front of the split at the end
+    const bool split = P->cfg.row_split > 0;
+    if (rc == EHYB_OK && (flags & EHYB_PART_LAST_FOREIGN)) {
+        if (!split) EHYB_FAIL(EHYB_ERR_STATE, "ehyb_spmv_part: EHYB_PART_LAST_FOREIGN needs a plan built with cfg.row_split");
+        rc = launch_panel(P, x, y, st, 0, 2, 0, -1, 2);
+    }
+    if (rc == EHYB_OK && (flags & EHYB_PART_LAST)) rc = launch_panel(P, x, y, st, 0, 2, 0, -1, split ? 1 : 0);
     return rc;
 }
 
@@ -1463,6 +1503,15 @@ int ehyb_gather(const double* src, const int32_t* idx, double* dst, int64_t n, v
     if (n < 0 || (n > 0 && (!src || !idx || !dst))) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gather: bad arguments");
     if (n == 0) return EHYB_OK;
     hipLaunchKernelGGL(ehyb_gather_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, src, idx, dst, (long long)n);
+    HIP_TRY(hipGetLastError());
+    return EHYB_OK;
+}
+
+int ehyb_scatter_add(double* y, const int32_t* idx, const double* src, int64_t n, void* stream)
+{
+    if (n < 0 || (n > 0 && (!y || !idx || !src))) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_scatter_add: bad arguments");
+    if (n == 0) return EHYB_OK;
+    hipLaunchKernelGGL(ehyb_scatter_add_kernel, dim3((unsigned)((n + 1023) / 1024)), dim3(256), 0, (hipStream_t)stream, y, idx, src, (long long)n);
     HIP_TRY(hipGetLastError());
     return EHYB_OK;
 }

@@ -66,6 +66,7 @@ struct Config {
     int symbolic;           // where the panel form is built by ehyb_plan_create[_segs]: 1 host, 2 device (default)
     int cg_fused_dot;       // 1 on (default), 2 off
     int ell_alternate;      // 0 automatic (streams that do not fit the Infinity Cache), 1 on, 2 off
+    int row_split;          // panel form: no row block of pass 2 straddles this row (0 = none)
 };
 Config resolve_config(const ehyb_config* cfg);
 

@@ -133,7 +133,9 @@ int panel_geometry(const Config& cfg, const HostLayout& L, const int32_t* cnt_ro
         rb_first.push_back(row_begin);
         for (int r = 0; r < nrows; ++r) {
             // close the block in front of this row if taking it would overshoot
-            if (r > first && (acc + cnt_row[r] > target || r - first >= rows_max || (L.pb_assign && row_assign[r] != row_assign[r - 1]))) {
+            // (cfg.row_split: the rows from it on are closed by a pass 2 of their own, ehyb_spmv_part / EHYB_PART_LAST_FOREIGN)
+            if (r > first && (acc + cnt_row[r] > target || r - first >= rows_max || (L.pb_assign && row_assign[r] != row_assign[r - 1]) ||
+                              (cfg.row_split > 0 && row_begin + r == cfg.row_split))) {
                 rb_first.push_back(row_begin + r);
                 first = r;
                 acc = 0;

@@ -1241,4 +1241,51 @@ int ehyb_matrix_append_ghosts(matrixCOO* m, int n_ghost, int64_t nnz_g, const in
     return EHYB_OK;
 }
 
+int ehyb_matrix_append_rows(matrixCOO* m, int row0, int n_rows, int64_t nnz, const int* ri, const int* cj, const double* v, int rows_per_part)
+{
+    clear_error();
+    if (!m || !m->rowIdx || !m->partBoundary || row0 < 0 || n_rows < 0 || nnz < 0 || (nnz > 0 && (!ri || !cj || !v)))
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_append_rows: bad arguments");
+    const int n = m->dimension;
+    if ((int64_t)row0 + n_rows > n) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_append_rows: rows [%d, %d) outside the dimension %d", row0, row0 + n_rows, n);
+    if (m->partBoundary[m->nParts] > row0) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_append_rows: row %d lies inside the partitions (they end at %d)", row0, m->partBoundary[m->nParts]);
+    if (m->rowIdx[n] != m->rowIdx[row0]) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_append_rows: rows from %d on are not empty", row0);
+    const int64_t nnz0 = m->totalNum, nnz1 = nnz0 + nnz;
+    if (nnz1 > 0x7FFFFFFFll) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_append_rows: result does not fit int counts");
+    for (int64_t k = 0; k < nnz; ++k)
+        if ((unsigned)ri[k] >= (unsigned)n_rows || (unsigned)cj[k] >= (unsigned)n || (k > 0 && ri[k] < ri[k - 1]))
+            EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_append_rows: entry %lld (%d,%d) out of range or rows not ascending", (long long)k, ri[k], cj[k]);
+    if (n_rows == 0) return EHYB_OK;
+    const size_t e = (size_t)std::max<int64_t>(nnz1, 1);
+    int* I = (int*)realloc(m->I, e * sizeof(int));
+    if (I) m->I = I;
+    int* J = (int*)realloc(m->J, e * sizeof(int));
+    if (J) m->J = J;
+    double* V = (double*)realloc(m->V, e * sizeof(double));
+    if (V) m->V = V;
+    if (!I || !J || !V) EHYB_FAIL(EHYB_ERR_ALLOC, "ehyb_matrix_append_rows: out of memory");
+    std::vector<int> cnt((size_t)n_rows, 0);
+    for (int64_t k = 0; k < nnz; ++k) {
+        m->I[nnz0 + k] = row0 + ri[k];
+        m->J[nnz0 + k] = cj[k];
+        m->V[nnz0 + k] = v[k];
+        ++cnt[(size_t)ri[k]];
+    }
+    for (int r = 0; r < n_rows; ++r) {
+        m->rowIdx[row0 + r + 1] = m->rowIdx[row0 + r] + cnt[(size_t)r];
+        m->numInRow[row0 + r] = cnt[(size_t)r];
+        m->numInRow2[row0 + r] = 0;   // no entry of a foreign row lies in its own partition's window
+        m->maxCol = std::max(m->maxCol, cnt[(size_t)r]);
+    }
+    for (int r = row0 + n_rows; r < n; ++r) m->rowIdx[r + 1] = m->rowIdx[row0 + n_rows];
+    m->totalNum = (int)nnz1;
+    // new partitions behind the existing ones; a gap between the last boundary and row0 (padding rows) becomes a partition of its own
+    const int per = rows_per_part > 0 ? rows_per_part : std::max<int>(kSlabRows, m->vectorCacheSize);
+    int np = m->nParts;
+    if (m->partBoundary[np] < row0) m->partBoundary[++np] = row0;
+    for (int r = row0; r < row0 + n_rows; r += per) m->partBoundary[++np] = std::min(row0 + n_rows, r + per);
+    m->nParts = np;
+    return EHYB_OK;
+}
+
 }  // extern "C"

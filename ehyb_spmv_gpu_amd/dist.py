@@ -199,9 +199,10 @@ class RankLocalMatrix:
         V = np.asarray(V, dtype=np.float64)
         if len(I) and (I.min() < r0 or I.max() >= r1 or np.any(np.diff(I) < 0)):
             raise ValueError("RankLocalMatrix: rows must lie in [r0, r1) and be grouped in ascending order")
-        if exchange not in ("halo", "allgather"):
+        if exchange not in ("halo", "allgather", "cover"):
             raise ValueError(f"RankLocalMatrix: unknown exchange {exchange!r}")
-        loop = float(loopback) > 0 and exchange == "halo"
+        loop = float(loopback) > 0 and exchange in ("halo", "cover")
+        cover = exchange == "cover" and (world > 1 or loop)
         if exchange == "allgather" or (world == 1 and not loop):
             chunks, chunk_shares = 1, None
         chunks = max(1, int(chunks))
@@ -219,9 +220,64 @@ class RankLocalMatrix:
         self.perm = self.m.reorder_list[:self.n_loc].copy()  # local row i (unpermuted) -> its place in the plan
         # ---- ghost slots: the distinct remote columns, ordered by (chunk, owner, references descending, label)
         off = ~own
-        Jg = J[off]
+        Jg, Ioff, Voff = J[off], I[off], V[off]
         gcols, inv, refs = np.unique(Jg, return_inverse=True, return_counts=True)
         owner = np.searchsorted(np.asarray(self.cuts), gcols, side="right") - 1
+        self.n_foreign, self.nnz_exported, self.nnz_imported = 0, 0, 0
+        self.ysend_counts = np.zeros(world, dtype=np.int64)
+        self.yrecv_counts = np.zeros(world, dtype=np.int64)
+        self.yrecv_idx = np.zeros(0, dtype=np.int32)
+        foreign = None
+        if cover:
+            # ---- exchange "cover": per owner p a vertex cover of the block A[my rows, p's columns] -- its columns of degree >= t_p
+            # stay GHOST columns (their x entries travel to me), every other entry of the block is handed to p, who multiplies it with
+            # its own x and ships one partial sum per row: t_p = the threshold with the fewest columns + rows (t = 1: all columns, the
+            # plain halo exchange; t = inf: all rows)
+            n_loc1 = max(1, self.n_loc)
+            own_e, deg_e = owner[inv], refs[inv]
+            key = own_e.astype(np.int64) * n_loc1 + (Ioff - r0)
+            ordk = np.argsort(key, kind="stable")
+            ks = key[ordk]
+            starts = np.flatnonzero(np.concatenate(([True], ks[1:] != ks[:-1]))) if len(ks) else np.zeros(0, dtype=np.int64)
+            gmin = np.minimum.reduceat(deg_e[ordk], starts) if len(ks) else np.zeros(0, dtype=np.int64)
+            gown = ks[starts] // n_loc1
+            best_size, best_t = None, None
+            for t in (1, 2, 3, 4, 6, 8, 12, 16, 32, 64, 1 << 30):
+                size = np.bincount(owner[refs >= t], minlength=world) + np.bincount(gown[gmin < t], minlength=world)
+                if best_size is None:
+                    best_size, best_t = size.copy(), np.full(world, t, dtype=np.int64)
+                else:
+                    better = size < best_size
+                    best_size[better], best_t[better] = size[better], t
+            self.cover_threshold = best_t
+            hot_col = refs >= best_t[owner]
+            keep_e = hot_col[inv]
+            # the entries that leave, grouped by their new owner: (global row, global column, value)
+            out = np.flatnonzero(~keep_e)
+            out = out[np.argsort(own_e[out], kind="stable")]
+            out_counts = np.bincount(own_e[out], minlength=world).astype(np.int64)
+            Ir, cnt_from = alltoallv(Ioff[out].astype(np.int64), out_counts, group)
+            Jr, _ = alltoallv(Jg[out].astype(np.int64), out_counts, group)
+            Vr, _ = alltoallv(Voff[out].astype(np.float64), out_counts, group)
+            self.nnz_exported, self.nnz_imported = int(len(out)), int(len(Ir))
+            if len(Jr) and (Jr.min() < r0 or Jr.max() >= r1):
+                raise ValueError("RankLocalMatrix: a peer handed over an entry of a column this rank does not own")
+            # my FOREIGN rows: one per distinct (origin rank, its row), grouped by origin -- what I ship back every step
+            n_glob = int(self.cuts[-1])
+            origin = np.repeat(np.arange(world, dtype=np.int64), cnt_from)
+            fu, finv = np.unique(origin * n_glob + Ir, return_inverse=True)
+            self.n_foreign = len(fu)
+            self.ysend_counts = np.bincount(fu // n_glob, minlength=world).astype(np.int64)
+            rows_back, self.yrecv_counts = alltoallv(fu % n_glob, self.ysend_counts, group)   # every origin learns which of its rows get a partial sum from me
+            if len(rows_back) and (rows_back.min() < r0 or rows_back.max() >= r1):
+                raise ValueError("RankLocalMatrix: a peer announced partial sums for rows this rank does not own")
+            self.yrecv_idx = self.perm[rows_back - r0].astype(np.int32)
+            fo = np.argsort(finv, kind="stable")
+            foreign = (finv[fo].astype(np.int32), self.perm[Jr[fo] - r0].astype(np.int32), Vr[fo])
+            # what stays here: the entries in the hot columns
+            remap = np.cumsum(hot_col) - 1
+            Jg, Ioff, Voff, inv = Jg[keep_e], Ioff[keep_e], Voff[keep_e], remap[inv[keep_e]]
+            gcols, refs, owner = gcols[hot_col], refs[hot_col], owner[hot_col]
         self.n_ghost = len(gcols)
         by_owner = np.lexsort((gcols, -refs, owner))                       # owner, then hot columns first
         per_owner = np.bincount(owner, minlength=world).astype(np.int64)
@@ -275,15 +331,27 @@ class RankLocalMatrix:
             self.m.append_ghosts(self.n_ext, self.perm[I[off] - r0], (slot_col - self.n_loc)[slot_of_entry[inv]], V[off])
         else:
             # the coupling entries, rows in plan numbering, columns = ghost columns behind the own ones
+            if cover:   # the matrix is square: room for the foreign rows behind the own ones, the last column segment padded to match
+                seg[-1] = max(seg[-1], _even(self.n_loc + self.n_foreign))
             self.n_ext = seg[-1] - self.n_loc
             self.col_segs = np.asarray(seg, dtype=np.int32)
-            self.m.append_ghosts(self.n_ext, self.perm[I[off] - r0], (col_of_slot - self.n_loc)[slot_of_entry[inv]], V[off])
-        self.nnz = len(V)
-        self.nnz_own_cols = int(own.sum())
-        self.cfg_plan = _copy_cfg(cfg, n_top=2 if self.exchanges else 1)
+            self.m.append_ghosts(self.n_ext, self.perm[Ioff - r0], (col_of_slot - self.n_loc)[slot_of_entry[inv]], Voff)
+            if cover and self.n_foreign:
+                cfgr = H.make_config() if cfg is None else cfg
+                lib = H._lib.load()
+                fi, fj, fv = (np.ascontiguousarray(a) for a in foreign)
+                H._check(lib.ehyb_matrix_append_rows(C.byref(self.m.c), self.n_loc, self.n_foreign, len(fi), fi.ctypes.data_as(C.POINTER(C.c_int)),
+                                                     fj.ctypes.data_as(C.POINTER(C.c_int)), fv.ctypes.data_as(C.POINTER(C.c_double)), int(cfgr.part_rows)),
+                         "ehyb_matrix_append_rows")
+        self.nnz = len(V) - self.nnz_exported + self.nnz_imported      # entries this rank multiplies
+        self.nnz_own_cols = int(own.sum()) + self.nnz_imported
+        self.cover = cover
+        # (cover: every window given up -- the foreign rows close in a pass 2 of their own, which only the panel form has)
+        kw = dict(row_split=self.n_loc, er_mode=2, prune_pct=1, fuse_er=2, direct=2) if cover else {}
+        self.cfg_plan = _copy_cfg(cfg, n_top=2 if self.exchanges else 1, **kw)
 
     def plan(self, upload=True):
-        return H.Plan(self.m, self.cfg_plan, rows=(0, self.n_loc), upload=upload,
+        return H.Plan(self.m, self.cfg_plan, rows=(0, self.n_loc + self.n_foreign), upload=upload,
                       col_segs=self.col_segs if (self.col_segs is not None and self.exchanges) else None)
 
     def x_to_plan(self, x_local):
@@ -324,6 +392,12 @@ class Comm:
         H._check(self.lib.ehyb_halo_create(self.h, plan.h, int(local.chunks), idx.ctypes.data_as(C.POINTER(C.c_int32)), len(idx),
                                            sc.ctypes.data_as(C.POINTER(C.c_int64)), rc.ctypes.data_as(C.POINTER(C.c_int64)), C.byref(h)), "ehyb_halo_create")
         self._halos.append(h)
+        if getattr(local, "cover", False):
+            ys = np.ascontiguousarray(local.ysend_counts, dtype=np.int64)
+            yr = np.ascontiguousarray(local.yrecv_counts, dtype=np.int64)
+            yi = np.ascontiguousarray(local.yrecv_idx, dtype=np.int32)
+            H._check(self.lib.ehyb_halo_set_partials(h, int(local.n_loc), ys.ctypes.data_as(C.POINTER(C.c_int64)), yr.ctypes.data_as(C.POINTER(C.c_int64)),
+                                                     yi.ctypes.data_as(C.POINTER(C.c_int32)), len(yi)), "ehyb_halo_set_partials")
         return h
 
     def allreduce_sum(self, ptr, count, stream=0):
@@ -419,6 +493,36 @@ class HaloExchange:
         if self.stage:
             recv_dev.copy_(recv)
 
+    def setup_partials(self, y):
+        """exchange "cover": the buffers of the partial-sum exchange -- y[n_loc:] (this rank's foreign rows, grouped by destination)
+        against ybuf (what the others computed for this rank's rows) + the rows they belong to."""
+        L, torch = self.L, self.torch
+        self.y = y
+        self.ybuf = torch.zeros(max(1, int(L.yrecv_counts.sum())), dtype=torch.float64, device=y.device)
+        self.yidx = torch.from_numpy(L.yrecv_idx.astype(np.int32)).to(y.device)
+        self.ysend_counts = [int(c) for c in L.ysend_counts]
+        self.yrecv_counts = [int(c) for c in L.yrecv_counts]
+
+    def transfer_partials(self):
+        L, dist, torch = self.L, self.dist, self.torch
+        n_send, n_recv = sum(self.ysend_counts), sum(self.yrecv_counts)
+        send, recv = self.y[L.n_loc:L.n_loc + n_send], self.ybuf[:n_recv]
+        if L.world == 1:            # loop-back
+            recv.copy_(send)
+            return
+        if self.stage:
+            send, recv_dev, recv = send.cpu(), recv, torch.empty(n_recv, dtype=torch.float64)
+        dist.all_to_all_single(recv, send.contiguous(), self.yrecv_counts, self.ysend_counts, group=self.group)
+        if self.stage:
+            recv_dev.copy_(recv)
+
+    def add_partials(self, stream=0):
+        """y[row] += partial for everything transfer_partials delivered (ehyb_scatter_add)."""
+        n = sum(self.yrecv_counts)
+        rc = self.lib.ehyb_scatter_add(C.c_void_p(self.y.data_ptr()), C.c_void_p(self.yidx.data_ptr()), C.c_void_p(self.ybuf.data_ptr()), n, stream)
+        if rc:
+            H._check(rc, "ehyb_scatter_add")
+
     def run(self):
         cur = self.torch.cuda.current_stream().cuda_stream if self.x_ext.device.type == "cuda" else 0
         self.pack(cur, cur)
@@ -447,8 +551,13 @@ class HaloSpmv:
         self.c_step = c_step
         self.plan = local.plan()
         self.x = torch.zeros(local.n_loc + local.n_ext, dtype=torch.float64, device=device)
-        self.y = torch.zeros(local.n_loc, dtype=torch.float64, device=device)
+        self.cover = bool(getattr(local, "cover", False))
+        self.y = torch.zeros(local.n_loc + (local.n_foreign if self.cover else 0), dtype=torch.float64, device=device)   # own rows | foreign rows
         self.halo = HaloExchange(local, self.x, local.group, stage_on_cpu=stage_on_cpu, mode=mode)
+        if self.cover:
+            if self.plan.stats["nnz_ell"] != 0 or self.plan.stats["er_partials"] == 0:
+                raise RuntimeError("HaloSpmv: the cover exchange needs a plan in panel form alone")
+            self.halo.setup_partials(self.y)
         self.comm, self.c_halo = comm, None
         if comm is not None and local.exchanges:
             if comm.world != local.world or comm.rank != local.rank:
@@ -502,9 +611,26 @@ class HaloSpmv:
             for k in range(L.chunks):
                 self.halo.transfer(k)
             self.plan.spmv(xp, yp, cur)
+            if self.cover:                     # the plain cover step: everything multiplied, then the partial sums travel and are added
+                self.halo.transfer_partials()
+                self.halo.add_partials(cur)
             return
         comm = self.comm_stream.cuda_stream
         K = L.chunks
+        if self.cover:
+            # own columns (own AND foreign rows) + the close of the foreign rows; their partial sums travel while the chunks multiply
+            self.halo.pack(cur, comm)
+            with torch.cuda.stream(self.comm_stream):
+                for k in range(K):
+                    self.halo.transfer(k)
+            self._part(cur, comm, 0, 0, 1, 1 | 4)                    # EHYB_PART_FIRST | EHYB_PART_LAST_FOREIGN
+            self.comm_stream.wait_stream(cur_s)
+            with torch.cuda.stream(self.comm_stream):
+                self.halo.transfer_partials()
+            for k in range(K):
+                self._part(cur, comm, 1 if k == 0 else 0, 1 + k, 2 + k, 2 if k == K - 1 else 0)   # (one wait for everything the side stream holds)
+            self.halo.add_partials(cur)
+            return
         if self.c_step:
             if not hasattr(self, "_cb"):
                 def exchange(k, _comm, _user):
@@ -529,7 +655,7 @@ class HaloSpmv:
 
     def y_local(self):
         """This rank's y segment in global label order (host array)."""
-        return self.L.y_from_plan(self.y.cpu().numpy())
+        return self.L.y_from_plan(self.y[:self.L.n_loc].cpu().numpy())
 
     def time_local(self, iters):
         return _time_local(self, iters)
@@ -704,7 +830,7 @@ class HaloCG:
             x.copy_(torch.from_numpy(L.x_to_plan(np.asarray(x0_local, dtype=np.float64))))
         r = torch.empty(n, dtype=torch.float64, device=self.dev)
         p = sh.x[:n]                     # the direction vector lives where the multiply reads it
-        q = sh.y
+        q = sh.y[:n]                     # (the exchange "cover" keeps the rank's foreign rows behind its own)
         dinv = self.dinv.data_ptr() if self.dinv is not None else None
         st = lambda: torch.cuda.current_stream().cuda_stream  # noqa: E731
         s_ptr = self.s.data_ptr()

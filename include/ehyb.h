@@ -196,7 +196,11 @@ typedef struct ehyb_config {
                               the walk from the short slabs up), 1 = always, 2 = never (always first to last).  With more work items
                               than resident workgroups the items are taken from the far end as well.  Pass 1 of the panel
                               residual alternates the same way                                                        */
-    int32_t reserved[25];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
+    int32_t row_split;     /* panel form, multi-GPU: a row block of pass 2 never straddles this row (0 = none).  The rows from it on
+                              are the FOREIGN rows of a rank -- partial sums it computes for other ranks from its own x entries
+                              (dist.py: exchange "cover") -- and ehyb_spmv_part can close them early (EHYB_PART_LAST_FOREIGN), so
+                              that they travel while the rank's own rows are still being multiplied                       */
+    int32_t reserved[24];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);
@@ -476,13 +480,20 @@ int ehyb_plan_tune(ehyb_plan* plan, const double* x_dev, double* y_dev, int reps
  *                             or, for a plan whose residual is in CSR form, the residual launch (all of x).
  * ehyb_spmv == one call with every segment and both flags.  Parts of one multiply go to ONE stream, in order.
  */
-enum { EHYB_PART_FIRST = 1, EHYB_PART_LAST = 2 };
+enum { EHYB_PART_FIRST = 1, EHYB_PART_LAST = 2,
+       EHYB_PART_LAST_FOREIGN = 4 /* panel form with cfg.row_split: pass 2 over the row blocks from row_split on only (they have entries in
+                                     column segment 0 alone, so they are complete once segment 0's pass 1 is enqueued); with such a
+                                     plan EHYB_PART_LAST closes the rows IN FRONT of row_split only: ehyb_spmv == one call with every
+                                     segment and all three flags */ };
 int ehyb_spmv_part(ehyb_plan* plan, const double* x_dev, double* y_dev, void* stream, int seg_begin, int seg_end, int flags);
 /* Column segments of the plan (1 unless made by ehyb_plan_create_host_segs). */
 int ehyb_plan_col_segs(const ehyb_plan* plan, int* n_col_segs);
 /* dst[i] = src[idx[i]], i < n, on `stream`: packs the x entries the other ranks asked for (the send list of a halo
  * exchange) -- device pointers. */
 int ehyb_gather(const double* src_dev, const int32_t* idx_dev, double* dst_dev, int64_t n, void* stream);
+/* y[idx[i]] += src[i], i < n, on `stream` (fp64 atomics: an index may occur more than once): the partial sums other ranks
+ * computed for this rank's rows, added in (exchange "cover") -- device pointers. */
+int ehyb_scatter_add(double* y_dev, const int32_t* idx_dev, const double* src_dev, int64_t n, void* stream);
 /*
  * Stream plumbing of one exchange step, so that the host issues ONE call per part instead of an event record, a stream
  * wait and a launch each (the host side of a step costs as much as the device side at 8 GPUs: DESIGN.md 5):
@@ -542,6 +553,19 @@ int ehyb_halo_create(ehyb_comm* comm, ehyb_plan* plan, int n_chunks, const int32
                      const int64_t* send_counts, const int64_t* recv_counts, ehyb_halo** halo);
 void ehyb_halo_destroy(ehyb_halo* halo);
 int ehyb_halo_spmv(ehyb_halo* halo, double* x_dev, double* y_dev, void* compute_stream);
+/*
+ * Exchange "cover" (dist.py: RankLocalMatrix(exchange="cover")): per pair of ranks only the hub columns of the block
+ * A[r, s] travel as x entries; the rest of the block is handed to the columns' owner s at set-up, who multiplies it with its own x
+ * and ships ONE PARTIAL SUM PER ROW -- a vertex cover of the block's bipartite graph instead of all its columns (R-MAT 2^24: 2.2-2.7 x
+ * fewer doubles on the wire at 2 / 4 / 8 ranks, tools/dist_volume_model.py).  The plan of such a rank was built with cfg.row_split
+ * = its number of own rows; the rows behind are its FOREIGN rows (ehyb_matrix_append_rows), grouped by destination rank:
+ * ysend_counts[p] of them belong to rank p, yrecv_counts[p] partial sums arrive from rank p, partial i (arrival order, peer 0's first)
+ * is added to row yrecv_idx_host[i].  ehyb_halo_spmv then: pack; the x chunks on the wire at once; segment 0 (own columns: own AND
+ * foreign rows); the foreign rows closed (EHYB_PART_LAST_FOREIGN) and sent off; the chunks' panels as they land; the own rows closed;
+ * the received partial sums added (ehyb_scatter_add).  y_dev holds own rows followed by the foreign rows.  Panel-form plans only.
+ */
+int ehyb_halo_set_partials(ehyb_halo* halo, int row_split, const int64_t* ysend_counts, const int64_t* yrecv_counts,
+                           const int32_t* yrecv_idx_host, int64_t n_yrecv);
 /* on > 0: from the third step on the whole step (pack, the RCCL exchanges, every part, both streams) is captured into hipGraphs --
  * one per walk direction of the plan (cfg.ell_alternate), replayed in turn -- and a multiply costs the host ONE hipGraphLaunch;
  * x, y and the stream must then stay the same from step to step (a change is noticed and captured anew).  on = 0: off (default);
@@ -694,6 +718,15 @@ void ehyb_matrix_free(matrixCOO* m);
  */
 int ehyb_matrix_append_ghosts(matrixCOO* m, int n_ghost, int64_t nnz_g,
                               const int* gi, const int* gj, const double* gv);
+/*
+ * The other direction (exchange "cover"): rows [row0, row0 + n_rows) of m -- empty so far, at or behind the last partition
+ * boundary, inside the dimension ehyb_matrix_append_ghosts gave the matrix -- receive nnz entries (ri[k] in [0, n_rows) ascending,
+ * cj[k] any column of m, v[k]): the FOREIGN rows of a rank, whose entries another rank handed over because shipping one partial sum
+ * per row is cheaper than shipping the x entries of their columns.  They form new partitions of at most rows_per_part rows behind
+ * the existing ones (nParts and partBoundary grow; rows_per_part <= 0: m->vectorCacheSize).  A plan over rows [0, row0 + n_rows) with
+ * cfg.row_split = row0 then multiplies them with everything else.
+ */
+int ehyb_matrix_append_rows(matrixCOO* m, int row0, int n_rows, int64_t nnz, const int* ri, const int* cj, const double* v, int rows_per_part);
 
 /* x[i]: srand(i); (rand()%200-100)/1000.0  -- solver_test.c:89-92, 228-231 (glibc rand). */
 void ehyb_x_glibc(int n, double* x);

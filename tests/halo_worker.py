@@ -100,6 +100,53 @@ def check_rank(tag, I, J, V, cuts, rank, world, cfg, symmetric, chunks=1, shares
     return int(tot[2])
 
 
+def check_cover(tag, I, J, V, cuts, rank, world, cfg, chunks=1, shares=None, loopback=0.0):
+    """exchange "cover": per pair of ranks the hub columns of the block travel as x entries, the rest of the block is handed to the
+    columns' owner, who ships one partial sum per row.  The rank's plan (own rows + foreign rows, all in panel form) walked by the
+    oracle over x = [own | ghosts], the partial sums exchanged over gloo and added: the oracle's product on the rank's rows."""
+    n_glob = cuts[-1]
+    r0, r1 = cuts[rank], cuts[rank + 1]
+    x = O.x_glibc(n_glob)
+    y_ref = O.spmv_coo(n_glob, I, J, V, x)[r0:r1]
+    scale = O.abs_rowsum(n_glob, I, J, V, x)[r0:r1]
+    R = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, chunks=chunks, chunk_shares=shares, loopback=loopback)                      # the plain halo exchange, for the volumes
+    L = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, exchange="cover", chunks=chunks, chunk_shares=shares, loopback=loopback)
+    assert L.cover and L.n_ghost <= R.n_ghost
+    assert L.n_ghost + int(L.yrecv_counts.sum()) <= R.n_ghost, "a cover never moves more than all the block's columns"
+    assert int(L.ysend_counts.sum()) == L.n_foreign and len(L.yrecv_idx) == int(L.yrecv_counts.sum())
+    assert L.m.n == L.n_loc + L.n_ext and L.col_segs[-1] == L.m.n and L.m.n >= L.n_loc + L.n_foreign
+    plan = L.plan(upload=False)
+    st = plan.stats
+    assert st["nnz_ell"] == 0 and st["n_rows"] == L.n_loc + L.n_foreign and st["nnz"] == L.nnz
+    u2 = plan.array("pb_units2").reshape(-1, 4)
+    assert not np.any((u2[:, 2] < L.n_loc) & (u2[:, 2] + np.abs(u2[:, 3]) > L.n_loc)), "a row block straddles the own / foreign boundary"
+    # the foreign rows have entries in the rank's OWN columns only: they are complete after column segment 0
+    rp = L.m.row_idx.astype(np.int64)
+    assert L.n_foreign == 0 or L.m.J[rp[L.n_loc]:rp[L.n_loc + L.n_foreign]].max() < L.n_loc
+    x_ext = torch.zeros(L.n_loc + L.n_ext, dtype=torch.float64)
+    x_ext[:L.n_loc] = torch.from_numpy(L.x_to_plan(x[r0:r1]))
+    hx = D.HaloExchange(L, x_ext)
+    hx.send_buf.copy_(x_ext[torch.from_numpy(L.send_idx.astype(np.int64))])
+    for k in range(L.chunks):
+        hx.transfer(k)
+    assert np.array_equal(x_ext.numpy()[L.ghost_slot_col], x[L.ghost_cols])
+    y_plan, written = O.walk_plan(plan, x_ext.numpy())
+    assert written[:L.n_loc + L.n_foreign].min() == 1
+    y_t = torch.from_numpy(np.ascontiguousarray(y_plan[:L.n_loc + L.n_foreign]))
+    hx.setup_partials(y_t)
+    hx.transfer_partials()
+    y_own = y_t[:L.n_loc].numpy().copy()
+    np.add.at(y_own, L.yrecv_idx, hx.ybuf.numpy()[:len(L.yrecv_idx)])
+    bad, worst = O.check_tolerance(L.y_from_plan(y_own), y_ref, scale)
+    tot = torch.tensor([float(R.n_ghost), float(L.n_ghost + int(L.yrecv_counts.sum())), float(L.nnz_exported), float(bad)], dtype=torch.float64)
+    if world > 1:
+        dist.all_reduce(tot)
+    if rank == 0:
+        print(f"HALO_CASE {tag} world={world} doubles_received: all columns {int(tot[0])} -> cover {int(tot[1])}; entries handed over {int(tot[2])} bad={int(tot[3])} worst0={worst:.2e}",
+              flush=True)
+    return int(tot[3])
+
+
 def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -130,6 +177,11 @@ def main():
     bad += check_rank("rmat-rows-panel-chunks", g.I[a:b].copy(), g.J[a:b].copy(), g.V[a:b].copy(), base, rank, world, cfgp, symmetric=False,
                       chunks=3, shares=[0.2, 0.3, 0.5])
     bad += check_rank("rmat-rows-chunks-p2p", g.I[a:b].copy(), g.J[a:b].copy(), g.V[a:b].copy(), base, rank, world, cfg, symmetric=False, chunks=2)
+    # 2d. exchange "cover" on the same rows: hub columns as x, the rest as partial sums (world 1: the rank is its own peer)
+    cfgc = E.make_config(lds_doubles=256, er_panel_cols=512, er_block_rows=300)
+    lb = 0.5 if world == 1 else 0.0
+    bad += check_cover("rmat-rows-cover", g.I[a:b].copy(), g.J[a:b].copy(), g.V[a:b].copy(), base, rank, world, cfgc, loopback=lb)
+    bad += check_cover("rmat-rows-cover-chunks", g.I[a:b].copy(), g.J[a:b].copy(), g.V[a:b].copy(), base, rank, world, cfgc, chunks=3, shares=[0.2, 0.3, 0.5], loopback=lb)
     # 3. block diagonal: no ghosts at all, the exchange is empty
     cfg = E.make_config(lds_doubles=1024, window_mode=1, partitioner=1)
     g = E.Matrix.generate("banded", 2048, 16, 1024, cfg=cfg)

@@ -17,13 +17,13 @@ from ehyb_spmv_gpu_amd import dist as D  # noqa: E402
 from oracle import oracle as O  # noqa: E402
 
 
-def case(tag, I, J, V, cuts, rank, world, cfg, chunks, shares, symmetric, dev, mode="a2a", exact=False, c_step=False):
+def case(tag, I, J, V, cuts, rank, world, cfg, chunks, shares, symmetric, dev, mode="a2a", exact=False, c_step=False, exchange="halo"):
     n = cuts[-1]
     r0, r1 = cuts[rank], cuts[rank + 1]
     x = O.x_glibc(n)
     y_ref = O.spmv_coo(n, I, J, V, x)[r0:r1]
     scale = O.abs_rowsum(n, I, J, V, x)[r0:r1]
-    L = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, symmetric=symmetric, chunks=chunks, chunk_shares=shares)
+    L = D.RankLocalMatrix(I, J, V, cuts, rank, cfg, symmetric=symmetric, chunks=chunks, chunk_shares=shares, exchange=exchange)
     sh = D.HaloSpmv(L, dev, overlap=True, stage_on_cpu=True, mode=mode, c_step=c_step)
     sh.set_x_local(x[r0:r1])
     st = sh.plan.stats
@@ -77,6 +77,9 @@ def main():
     bad += case("rmat-18-csr-2chunks", I, J, V, cuts, rank, world, E.make_config(er_mode=1), 2, None, False, dev)
     # the same pipelined step through the one-call C entry point (ehyb_halo_step) with the collectives as callbacks
     bad += case("rmat-18-panel-3chunks-c-step", I, J, V, cuts, rank, world, cfgp, 3, [0.2, 0.3, 0.5], False, dev, c_step=True)
+    # exchange "cover": hub columns travel as x, the rest of every block was handed to the columns' owner and comes back as one partial
+    # sum per row -- the foreign rows close early (EHYB_PART_LAST_FOREIGN) and travel while the chunks multiply
+    bad += case("rmat-18-cover-2chunks", I, J, V, cuts, rank, world, E.make_config(er_panel_cols=4096), 2, [0.25, 0.75], False, dev, exchange="cover")
     # a FEM matrix cut into slabs: windows kept, small CSR residual over the ghost columns -- deterministic kernels: bit for bit
     n = 30000
     cfgf = E.make_config(lds_doubles=4096)

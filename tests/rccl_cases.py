@@ -33,7 +33,7 @@ def comm(gpu):
     c.destroy()
 
 
-def _case(E, O, comm, gen, gargs, cfg_gen, cfg_plan, chunks, shares, loopback, symmetric=False):
+def _case(E, O, comm, gen, gargs, cfg_gen, cfg_plan, chunks, shares, loopback, symmetric=False, exchange="halo"):
     import torch
 
     from ehyb_spmv_gpu_amd import dist as D
@@ -46,7 +46,7 @@ def _case(E, O, comm, gen, gargs, cfg_gen, cfg_plan, chunks, shares, loopback, s
     x = O.x_glibc(n)
     y_ref = O.spmv_coo(n, I, J, V, x)
     scale = O.abs_rowsum(n, I, J, V, x)
-    L = D.RankLocalMatrix(I, J, V, [0, n], 0, cfg_plan, symmetric=symmetric, chunks=chunks, chunk_shares=shares, loopback=loopback)
+    L = D.RankLocalMatrix(I, J, V, [0, n], 0, cfg_plan, symmetric=symmetric, chunks=chunks, chunk_shares=shares, loopback=loopback, exchange=exchange)
     assert L.exchanges and L.n_ghost > 0 and int(L.send_counts.sum()) == int(L.recv_counts.sum()) == L.n_ghost
     plain = D.HaloSpmv(L, dev, overlap=False)                 # the reference step: device copies, then ehyb_spmv
     rccl = D.HaloSpmv(L, dev, comm=comm)                      # ONE C call per step, the exchange through RCCL
@@ -211,3 +211,28 @@ def test_whole_step_replayed_from_a_hipgraph(E, O, comm):
         torch.cuda.synchronize()
         done += 8
     print(f"host_us_per_step (C step from a hipGraph, state {state}): {t_issue / done * 1e6:.1f}")
+
+
+def test_cover_exchange_over_rccl(E, O, comm):
+    """exchange "cover" through the C step (ehyb_halo_set_partials): x chunks out at once, own columns incl. the foreign rows, the
+    foreign rows closed and shipped (to the rank itself here), chunks, own rows closed, received partial sums added -- against the
+    plain step and the oracle, over several steps with x changing."""
+    import torch
+
+    cfg = E.make_config(partitioner=E.EHYB_PART_DEGREE)
+    cfgp = E.make_config(partitioner=E.EHYB_PART_DEGREE, er_panel_cols=4096)
+    L, plain, rccl, x, y_ref, scale = _case(E, O, comm, "rmat", (17, 1 << 20, 1), cfg, cfgp, 2, [0.25, 0.75], 0.6, exchange="cover")
+    assert L.cover and L.n_foreign > 0 and rccl.plan.stats["nnz_ell"] == 0
+    print(f"cover: {L.n_ghost} ghost columns + {int(L.yrecv_counts.sum())} partial sums per step, {L.nnz_exported} entries handed over")
+    y0 = _run(plain, x)
+    assert O.check_tolerance(y0, y_ref, scale)[0] == 0
+    rccl.set_x_local(x)
+    ys = []
+    for k in range(5):
+        rccl.x[L.n_loc:].fill_(float("nan"))
+        rccl.step()
+        ys.append(rccl.y[:L.n_loc].clone())
+        rccl.x[:L.n_loc].mul_(-0.5)
+    torch.cuda.synchronize()
+    for k, y in enumerate(ys):
+        assert O.check_tolerance(L.y_from_plan(y.cpu().numpy()), y_ref * (-0.5) ** k, scale * 0.5 ** k)[0] == 0, k

@@ -36,4 +36,4 @@ def test_halo_path_gloo(world):
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=600, env=env)
     assert p.returncode == 0, p.stdout[-3000:] + p.stderr[-3000:]
     assert "HALO_OK" in p.stdout, p.stdout[-3000:]
-    assert p.stdout.count("HALO_CASE") == 7 + 8    # seven structured cases + eight fuzz seeds
+    assert p.stdout.count("HALO_CASE") == 9 + 8    # nine structured cases (two of them the "cover" exchange) + eight fuzz seeds

@@ -56,6 +56,10 @@ def test_strong_halo_rmat_two_ranks_self_launched(gpu):
     c = out["config"]
     assert "all_to_all" in c["exchange"] and 0 < c["ghost_columns_per_gpu_max"] < c["rows"]
     assert out["local_multiply_ms_max_over_ranks"] > 0
+    # the default exchange of the R-MAT workloads is "cover": hub columns as x entries, the rest of every block as partial sums
+    cov = c["cover"]
+    assert c["exchange"].startswith("cover") and cov["partial_sums_all_gpus"] > 0 and cov["entries_handed_to_the_column_owner"] > 0
+    assert cov["ghost_columns_all_gpus"] + cov["partial_sums_all_gpus"] == c["exchange_doubles_received_all_gpus"]
 
 
 def test_strong_allgather_three_ranks(gpu):
@@ -86,13 +90,13 @@ def test_pipelined_step_equals_plain_step(gpu, world):
            "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.join(ROOT, "tests", "pipeline_worker.py")]
     p = subprocess.run(cmd, capture_output=True, text=True, timeout=900, env=dict(os.environ), cwd=ROOT)
     assert p.returncode == 0, p.stdout[-2000:] + p.stderr[-3000:]
-    assert "PIPE_OK" in p.stdout and p.stdout.count("PIPE_CASE") == 5, p.stdout[-2000:]
+    assert "PIPE_OK" in p.stdout and p.stdout.count("PIPE_CASE") == 6, p.stdout[-2000:]
 
 
 def test_strong_bench_line_carries_the_step_anatomy(gpu):
     """bench.py --gpus 2 (strong, halo, 3 chunks): the JSON line says how much of the local multiply can run before the
     first chunk lands, what the host spends per step, and who receives how much from whom per exchange step."""
-    out = _bench(2, ["--chunks", "3", "--chunk-shares", "0.2,0.3,0.5"], workload="rmat-18")
+    out = _bench(2, ["--exchange", "halo", "--chunks", "3", "--chunk-shares", "0.2,0.3,0.5"], workload="rmat-18")
     assert out["parity"]["rows_over_1e-12"] == 0
     c = out["config"]
     assert c["exchange_steps"] == 3 and c["pipelined"] is True and c["exchange_mode"] == "a2a"
