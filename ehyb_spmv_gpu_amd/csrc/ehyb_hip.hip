@@ -1722,8 +1722,21 @@ int ehyb_plan_create_segs(const matrixCOO* m, int row_begin, int row_end, const 
     int rc = create_host_plan(m, row_begin, row_end, cfg, n_col_segs, col_seg_first, on_device_ok, plan);
     if (rc != EHYB_OK) return rc;
     const double t1 = wall_seconds();
-    const bool on_device = (*plan)->host.deferred.pending;
+    bool on_device = (*plan)->host.deferred.pending;
     if (on_device) rc = build_panel_on_device(*plan);
+    if (on_device && rc != EHYB_OK && (rc == EHYB_ERR_HIP || rc == EHYB_ERR_ALLOC)) {
+        // the device ran out of memory after all (ranks that share a device can each pass the check above before the other
+        // allocates) or a sort failed: the matrix is still with the caller -- build the whole layout again with the panel form on the
+        // host (the same arrays, slower) instead of giving up
+        const std::string why = ehyb_last_error();
+        (void)hipGetLastError();
+        ehyb_plan_destroy(*plan);
+        *plan = nullptr;
+        rc = create_host_plan(m, row_begin, row_end, cfg, n_col_segs, col_seg_first, false, plan);
+        if (rc != EHYB_OK) return rc;
+        if ((*plan)->cfg.verbose) printf("plan: the device builder failed (%s): panel form rebuilt on the host\n", why.c_str());
+        on_device = false;
+    }
     const double t2 = wall_seconds();
     if (rc == EHYB_OK) rc = ehyb_plan_upload(*plan);
     if (rc != EHYB_OK) {

@@ -23,7 +23,7 @@ def test_rccl_native_step_over_a_loopback_communicator(gpu):
     m = re.search(r"host_us_per_step \(C step, 2 chunks, world 1\): ([0-9.]+)", p.stdout)
     assert m, tail
     for line in p.stdout.splitlines():
-        if line.startswith("graph state") or line.startswith("cover:"):
+        if "graph state" in line or "cover:" in line:
             print(line)
     g = re.search(r"host_us_per_step \(C step from a hipGraph, state (-?\d+)\): ([0-9.]+)", p.stdout)
     assert g, tail
