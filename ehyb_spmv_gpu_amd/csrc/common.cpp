@@ -163,7 +163,7 @@ Config resolve_config(const ehyb_config* in)
     c.xcd_map = z.xcd_map == 2 ? 2 : 1;
     c.graphs = z.graphs == 2 ? 2 : 1;
     c.er_sums = z.er_sums == 2 ? 2 : 1;
-    c.er_panel_threads = (z.er_panel_threads == 512 || z.er_panel_threads == 1024) ? z.er_panel_threads : 0;
+    c.er_panel_threads = (z.er_panel_threads == 512 || z.er_panel_threads == 1024 || z.er_panel_threads == 2048) ? z.er_panel_threads : 0;
     c.symbolic = z.symbolic == 1 ? 1 : 2;
     c.cg_fused_dot = z.cg_fused_dot == 2 ? 2 : 1;
     c.ell_alternate = (z.ell_alternate == 1 || z.ell_alternate == 2) ? z.ell_alternate : 0;  // 0: by the size of the stream (launch_ell)

@@ -471,8 +471,10 @@ __device__ __forceinline__ double piece_sums(double prod, unsigned long long hea
 // about the same time and stage their panel from its L2 instead of each from the fabric.
 // PROBE: the timing-diagnostics instantiation (ehyb_debug_panel_times only); the product's own launches run PROBE = false,
 // where every probe test folds away (they cost six vector instructions of ~70 per chunk).
-template <int THREADS, bool SUMS_DPP, bool PROBE>
-__global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __restrict__ items, const int4* __restrict__ units,
+// KCH = chunks per wave and step (8: 24 independent vector loads in flight per lane at 4 waves per SIMD; the two-workgroups-per-CU
+// instantiation takes 6 to stay inside 64 VGPRs)
+template <int THREADS, bool SUMS_DPP, bool PROBE, int KCH>
+__device__ __forceinline__ void pb_scale_body(const int2* __restrict__ items, const int4* __restrict__ units,
                                                                 const double* __restrict__ val,
                                                                 const uint16_t* __restrict__ colf,
                                                                 const uint32_t* __restrict__ chunk,
@@ -503,6 +505,7 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double* scr = win + panel_cols + 64 * wave;  // this wave's 64 piece accumulators, behind the panel (!SUMS_DPP only)
     if (!SUMS_DPP) scr[lane] = 0.0;
+    int staged_x = -1, staged_n = -1;  // the panel in this workgroup's LDS (first column, columns): wave-uniform
     int my_q = 0;
     if (queue != nullptr && threadIdx.x == 0) {
         unsigned xcc;
@@ -546,10 +549,14 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
   for (int ui = it.x; ui < it.y; ++ui) {
     const int un = reverse ? it.y - 1 - (ui - it.x) : ui;
     const int4 u = units[un];
-    if (ui != it.x) __syncthreads();  // every wave is done with the previous panel
+    // the panel this workgroup staged last is still in its LDS: a unit of the same panel (the next stretch of a hub panel's
+    // entries -- with the work queues a workgroup takes neighbouring items) streams straight away
+    const bool staged_already = u.x == staged_x && u.y == staged_n;
+    if (!staged_already && (ui != it.x || staged_n >= 0)) __syncthreads();  // every wave is done with the previous panel
+    staged_x = u.x, staged_n = u.y;
     // stage the panel: all of a thread's loads in flight before the first store (a 64 KiB panel is 16
     // double2 loads per thread; one load per loop trip would pay the memory latency 16 times)
-    if (!(probe & 8)) {
+    if (!(probe & 8) && !staged_already) {
         const double2* __restrict__ xp2 = reinterpret_cast<const double2*>(x + u.x);  // panels start on even columns
         double2* win2 = reinterpret_cast<double2*>(win);
         const int n2 = u.y >> 1;
@@ -568,9 +575,9 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
         }
         if ((u.y & 1) && threadIdx.x == 0) win[u.y - 1] = x[u.x + u.y - 1];
     }
-    __syncthreads();
+    if (!staged_already) __syncthreads();
     const int c0 = u.z >> 6, c1 = u.w >> 6;  // chunks of 64 entries
-    constexpr int K = 8;  // chunks per wave and step: 24 independent vector loads in flight per lane
+    constexpr int K = KCH;  // chunks per wave and step: 24 independent vector loads in flight per lane at K = 8
     // The jump-list range of a chunk is known from the chunk records alone (wave-uniform, scalar loads): they are
     // fetched one step ahead, so that the jump entries travel together with the values and column words instead
     // of behind them (a gather that waits for the flags doubled the latency per step: 345 -> 470 us on R-MAT 2^24).
@@ -661,6 +668,25 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
         for (int k = 0; k < 8; ++k) __hip_atomic_store(&queue[16 * k], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         __hip_atomic_store(&queue[128], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
+}
+
+template <int THREADS, bool SUMS_DPP, bool PROBE>
+__global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __restrict__ items, const int4* __restrict__ units, const double* __restrict__ val,
+                                                                const uint16_t* __restrict__ colf, const uint32_t* __restrict__ chunk,
+                                                                const uint32_t* __restrict__ jump, const double* __restrict__ x, double* __restrict__ partial,
+                                                                int panel_cols, int probe_arg, int xcd_map, int* __restrict__ queue, int n_items, int reverse)
+{
+    pb_scale_body<THREADS, SUMS_DPP, PROBE, 8>(items, units, val, colf, chunk, jump, x, partial, panel_cols, probe_arg, xcd_map, queue, n_items, reverse);
+}
+
+// The same for TWO 1024-thread workgroups per CU (cfg.er_panel_threads = 2048, panels of at most 9,728 columns = 76 KiB each): 8 waves
+// per SIMD instead of 4 -- one workgroup stages its panel while the other streams -- which the register file allows at <= 64 VGPRs.
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void ehyb_pb_scale_kernel_two(
+    const int2* __restrict__ items, const int4* __restrict__ units, const double* __restrict__ val, const uint16_t* __restrict__ colf,
+    const uint32_t* __restrict__ chunk, const uint32_t* __restrict__ jump, const double* __restrict__ x, double* __restrict__ partial, int panel_cols,
+    int probe_arg, int xcd_map, int* __restrict__ queue, int n_items, int reverse)
+{
+    pb_scale_body<1024, true, false, 6>(items, units, val, colf, chunk, jump, x, partial, panel_cols, probe_arg, xcd_map, queue, n_items, reverse);
 }
 
 // Pass 2: one workgroup per unit {first partial, end partial, first row, rows}.  The row block's
@@ -914,12 +940,13 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
     if ((which & 1) && u1 > 0) {
         // panels of up to 9,728 columns: two 512-thread workgroups per CU (one stages while the other streams); wider
         // panels leave room for one workgroup only, which then gets the CU's 16 waves
-        const bool wide = P->cfg.er_panel_threads ? P->cfg.er_panel_threads == 1024 : H.pb_panel_cols > 9728;
+        const bool two = P->cfg.er_panel_threads == 2048 && H.pb_panel_cols <= 9728 && !probe && P->cfg.er_sums != 2;  // two 1024-thread workgroups per CU
+        const bool wide = two || (P->cfg.er_panel_threads ? P->cfg.er_panel_threads == 1024 : H.pb_panel_cols > 9728);
         const bool dpp = P->cfg.er_sums != 2;
         const int xcd = P->cfg.xcd_map != 2 ? 1 : 0;
         // cfg.er_queue: one resident round of workgroups taking items from per-XCD queues (with stealing) instead of one
         // workgroup per item; needs the XCD map's contiguous eighths, and more items than workgroups to be worth it
-        const int resident = kNumCU * (wide ? 1 : 2);
+        const int resident = kNumCU * ((wide && !two) ? 1 : 2);
         int* queue = (P->cfg.er_queue == 1 && xcd && u1 > resident) ? P->d_pb_queue : nullptr;
         const int grid = queue ? resident : u1;
         // successive launches walk the entry stream in alternating directions (cfg.ell_alternate) where it does not fit the cache
@@ -937,7 +964,10 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
 #define PB_SCALE(T, D)                  \
     if (probe) PB_SCALE_P(T, D, true);  \
     else PB_SCALE_P(T, D, false)
-        if (wide) {
+        if (two) {
+            hipLaunchKernelGGL(ehyb_pb_scale_kernel_two, dim3(grid), dim3(1024), (size_t)(H.pb_panel_cols + 1) * 8, st, (const int2*)P->d_pb_items1 + unit_begin,
+                               (const int4*)P->d_pb_units1, P->d_pb_val, P->d_pb_colf, P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, 0, xcd, queue, u1, rev);
+        } else if (wide) {
             if (dpp) { PB_SCALE(1024, true); } else { PB_SCALE(1024, false); }
         } else {
             if (dpp) { PB_SCALE(512, true); } else { PB_SCALE(512, false); }
@@ -1357,6 +1387,7 @@ int ehyb_plan_upload(ehyb_plan* P)
     LDS_ATTR_T(256)
     LDS_ATTR_T(512)
     LDS_ATTR_T(1024)
+    LDS_ATTR(ehyb_pb_scale_kernel_two)
     LDS_ATTR((ehyb_pb_scale_kernel<512, true, false>))
     LDS_ATTR((ehyb_pb_scale_kernel<512, false, false>))
     LDS_ATTR((ehyb_pb_scale_kernel<1024, true, false>))
