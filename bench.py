@@ -622,8 +622,8 @@ def alg_bytes_split(st):
     nnz_er = int(st["nnz_er"])
     if inline or nnz_er == 0:
         return 12 * (int(st["nnz_ell"]) + nnz_er) + vec, 0
-    if int(st["nnz_ell"]) == 0 and int(st["n_items"]) == 0:
-        return 0, 12 * nnz_er + vec          # no ELL launch at all: the residual launches are the whole multiply
+    if int(st["nnz_ell"]) == 0:
+        return 0, 12 * nnz_er + vec          # no entry is multiplied by an ELL launch (every window given up): the residual launches are the whole multiply
     return 12 * int(st["nnz_ell"]) + vec, 12 * nnz_er
 
 

@@ -127,6 +127,7 @@ def test_alg_bytes_are_survey_8d_for_every_kernel():
     # a plan without an ELL launch: the two panel passes ARE the multiply -> 12 B per entry + row pointer + x + y, not 20 B per entry
     ell, er = B.alg_bytes_split(RMAT24)
     assert ell == 0 and er == 12 * 132718859 + 4 * (16777216 + 1) + 8 * 16777216 + 8 * 16777216 == RMAT24["bytes_alg"]
+    assert B.alg_bytes_split(dict(RMAT24, n_items=256)) == (ell, er)      # work items without entries change nothing
     # one launch (inline residual): everything on the ELL launch
     ell, er = B.alg_bytes_split(AUDIKW)
     assert er == 0 and ell == 12 * 77728167 + 4 * 943696 + 16 * 943695 == 951611908
