@@ -163,12 +163,12 @@ Config resolve_config(const ehyb_config* in)
     c.xcd_map = z.xcd_map == 2 ? 2 : 1;
     c.graphs = z.graphs == 2 ? 2 : 1;
     c.er_sums = z.er_sums == 2 ? 2 : 1;
-    c.er_panel_threads = (z.er_panel_threads == 512 || z.er_panel_threads == 1024 || z.er_panel_threads == 2048) ? z.er_panel_threads : 0;
+    c.er_panel_threads = (z.er_panel_threads == 512 || z.er_panel_threads == 1024) ? z.er_panel_threads : 0;
     c.symbolic = z.symbolic == 1 ? 1 : 2;
     c.cg_fused_dot = z.cg_fused_dot == 2 ? 2 : 1;
     c.ell_alternate = (z.ell_alternate == 1 || z.ell_alternate == 2) ? z.ell_alternate : 0;  // 0: by the size of the stream (launch_ell)
     c.row_split = z.row_split > 0 ? z.row_split : 0;
-    c.er_queue = z.er_queue == 1 ? 1 : 2;  // measured: no gain, so the default stays one workgroup per item
+    c.er_queue = (z.er_queue == 1 || z.er_queue == 2) ? z.er_queue : 0;  // 0: by the number of items per resident workgroup (launch_panel)
     // the automatic choice of the direct shape is for callers that left the window sizing alone: a caller
     // that names a window (lds_doubles / part_rows other than the defaults) gets that window
     if (c.direct == 0 && (c.lds_doubles != EHYB_LDS_MAX_DOUBLES || c.part_rows != round_down(EHYB_LDS_MAX_DOUBLES * 11 / 20, kSlabRows) ||

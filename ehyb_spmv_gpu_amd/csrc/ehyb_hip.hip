@@ -471,8 +471,10 @@ __device__ __forceinline__ double piece_sums(double prod, unsigned long long hea
 // about the same time and stage their panel from its L2 instead of each from the fabric.
 // PROBE: the timing-diagnostics instantiation (ehyb_debug_panel_times only); the product's own launches run PROBE = false,
 // where every probe test folds away (they cost six vector instructions of ~70 per chunk).
-// KCH = chunks per wave and step (8: 24 independent vector loads in flight per lane at 4 waves per SIMD; the two-workgroups-per-CU
-// instantiation takes 6 to stay inside 64 VGPRs)
+// KCH = chunks per wave and step (8: 24 independent vector loads in flight per lane at 4 waves per SIMD).
+// (Round 4 measured an instantiation for TWO 1024-thread workgroups per CU -- 9,728-column panels, KCH = 6, 59 VGPRs, 8 waves per SIMD, one
+// workgroup staging while the other streams: R-MAT 2^22 140 against 132 us, 2^24 665 against 574 us, profiles/r04_d_panel_two_ab.jsonl -- the
+// narrower panels' extra partial sums cost more than the occupancy gives; pass 1 alone ran level.  Removed again.)
 template <int THREADS, bool SUMS_DPP, bool PROBE, int KCH>
 __device__ __forceinline__ void pb_scale_body(const int2* __restrict__ items, const int4* __restrict__ units,
                                                                 const double* __restrict__ val,
@@ -522,7 +524,7 @@ __device__ __forceinline__ void pb_scale_body(const int2* __restrict__ items, co
                 const int first = (int)((long long)n_items * my_q / 8), len = (int)((long long)n_items * (my_q + 1) / 8) - first;
                 const int idx = len > 0 ? atomicAdd(&queue[16 * my_q], 1) : len;
                 if (idx < len) {
-                    item = first + idx;
+                    item = reverse ? first + len - 1 - idx : first + idx;   // (alternating walk: every eighth from its far end)
                     break;
                 }
                 int best = -1, most = 0;  // own eighth used up: the one with the most items left
@@ -677,16 +679,6 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
                                                                 int panel_cols, int probe_arg, int xcd_map, int* __restrict__ queue, int n_items, int reverse)
 {
     pb_scale_body<THREADS, SUMS_DPP, PROBE, 8>(items, units, val, colf, chunk, jump, x, partial, panel_cols, probe_arg, xcd_map, queue, n_items, reverse);
-}
-
-// The same for TWO 1024-thread workgroups per CU (cfg.er_panel_threads = 2048, panels of at most 9,728 columns = 76 KiB each): 8 waves
-// per SIMD instead of 4 -- one workgroup stages its panel while the other streams -- which the register file allows at <= 64 VGPRs.
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(8, 8))) void ehyb_pb_scale_kernel_two(
-    const int2* __restrict__ items, const int4* __restrict__ units, const double* __restrict__ val, const uint16_t* __restrict__ colf,
-    const uint32_t* __restrict__ chunk, const uint32_t* __restrict__ jump, const double* __restrict__ x, double* __restrict__ partial, int panel_cols,
-    int probe_arg, int xcd_map, int* __restrict__ queue, int n_items, int reverse)
-{
-    pb_scale_body<1024, true, false, 6>(items, units, val, colf, chunk, jump, x, partial, panel_cols, probe_arg, xcd_map, queue, n_items, reverse);
 }
 
 // Pass 2: one workgroup per unit {first partial, end partial, first row, rows}.  The row block's
@@ -940,18 +932,21 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
     if ((which & 1) && u1 > 0) {
         // panels of up to 9,728 columns: two 512-thread workgroups per CU (one stages while the other streams); wider
         // panels leave room for one workgroup only, which then gets the CU's 16 waves
-        const bool two = P->cfg.er_panel_threads == 2048 && H.pb_panel_cols <= 9728 && !probe && P->cfg.er_sums != 2;  // two 1024-thread workgroups per CU
-        const bool wide = two || (P->cfg.er_panel_threads ? P->cfg.er_panel_threads == 1024 : H.pb_panel_cols > 9728);
+        const bool wide = P->cfg.er_panel_threads ? P->cfg.er_panel_threads == 1024 : H.pb_panel_cols > 9728;
         const bool dpp = P->cfg.er_sums != 2;
         const int xcd = P->cfg.xcd_map != 2 ? 1 : 0;
         // cfg.er_queue: one resident round of workgroups taking items from per-XCD queues (with stealing) instead of one
         // workgroup per item; needs the XCD map's contiguous eighths, and more items than workgroups to be worth it
-        const int resident = kNumCU * ((wide && !two) ? 1 : 2);
-        int* queue = (P->cfg.er_queue == 1 && xcd && u1 > resident) ? P->d_pb_queue : nullptr;
+        const int resident = kNumCU * (wide ? 1 : 2);
+        // (automatic, cfg.er_queue = 0: from six items per resident workgroup up -- a workgroup that takes neighbouring items finds the panel
+        // of the previous one still staged, and the XCDs even out: R-MAT 2^24 574 -> 544 us; with three or four items per workgroup the two
+        // barriers and the atomic round trip per item cost more than that: 2^22 132 -> 138 us.  profiles/r04_d_panel_two_ab.jsonl)
+        const bool want_queue = P->cfg.er_queue == 1 || (P->cfg.er_queue == 0 && u1 >= 6 * resident);
+        int* queue = (want_queue && xcd && u1 > resident) ? P->d_pb_queue : nullptr;
         const int grid = queue ? resident : u1;
         // successive launches walk the entry stream in alternating directions (cfg.ell_alternate) where it does not fit the cache
         int rev = 0;
-        if (!queue && !probe && (t_walk >= 0 || P->cfg.ell_alternate == 1 || (P->cfg.ell_alternate == 0 && H.pb_bytes > (256ll << 20)))) {
+        if (!probe && (t_walk >= 0 || P->cfg.ell_alternate == 1 || (P->cfg.ell_alternate == 0 && H.pb_bytes > (256ll << 20)))) {
             // one direction per MULTIPLY: a multiply in parts (ehyb_spmv_part: one pass-1 launch per column segment) turns around
             // with its first part
             if (t_walk >= 0) rev = t_walk & 1;
@@ -964,10 +959,7 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
 #define PB_SCALE(T, D)                  \
     if (probe) PB_SCALE_P(T, D, true);  \
     else PB_SCALE_P(T, D, false)
-        if (two) {
-            hipLaunchKernelGGL(ehyb_pb_scale_kernel_two, dim3(grid), dim3(1024), (size_t)(H.pb_panel_cols + 1) * 8, st, (const int2*)P->d_pb_items1 + unit_begin,
-                               (const int4*)P->d_pb_units1, P->d_pb_val, P->d_pb_colf, P->d_pb_chunk, P->d_pb_jump, x, P->d_pb_partial, H.pb_panel_cols, 0, xcd, queue, u1, rev);
-        } else if (wide) {
+        if (wide) {
             if (dpp) { PB_SCALE(1024, true); } else { PB_SCALE(1024, false); }
         } else {
             if (dpp) { PB_SCALE(512, true); } else { PB_SCALE(512, false); }
@@ -1387,7 +1379,6 @@ int ehyb_plan_upload(ehyb_plan* P)
     LDS_ATTR_T(256)
     LDS_ATTR_T(512)
     LDS_ATTR_T(1024)
-    LDS_ATTR(ehyb_pb_scale_kernel_two)
     LDS_ATTR((ehyb_pb_scale_kernel<512, true, false>))
     LDS_ATTR((ehyb_pb_scale_kernel<512, false, false>))
     LDS_ATTR((ehyb_pb_scale_kernel<1024, true, false>))

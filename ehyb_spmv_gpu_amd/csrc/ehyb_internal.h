@@ -62,7 +62,7 @@ struct Config {
     int graphs;             // 1 on, 2 off
     int er_sums;            // 1 DPP scan, 2 LDS words
     int er_panel_threads;   // 0 automatic, 512, 1024
-    int er_queue;           // 1 per-XCD work queues with stealing (A/B arm), 2 one workgroup per item (default)
+    int er_queue;           // 0 automatic (queues from six items per resident workgroup up), 1 per-XCD work queues with stealing, 2 one workgroup per item
     int symbolic;           // where the panel form is built by ehyb_plan_create[_segs]: 1 host, 2 device (default)
     int cg_fused_dot;       // 1 on (default), 2 off
     int ell_alternate;      // 0 automatic (streams that do not fit the Infinity Cache), 1 on, 2 off

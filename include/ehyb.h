@@ -176,12 +176,12 @@ typedef struct ehyb_config {
                               from hipGraphs, 2 = plain launches (A/B, debugging)                                */
     int32_t er_sums;       /* panel form, pass 1: how the products of one row inside a 64-entry chunk are added up: 0/1 =
                               segmented DPP scan in registers, 2 = ds_add_f64 into per-wave LDS words (round 2's way) */
-    int32_t er_panel_threads; /* panel form, pass 1: workgroup size, 512 or 1024 (0 = automatic); 2048 = TWO 1024-thread workgroups per CU
-                              (panels of at most 9,728 columns, a build of the kernel inside 64 VGPRs): an A/B arm */
-    int32_t er_queue;      /* panel form, pass 1: 0/2 = one workgroup per item (default); 1 = one resident round of workgroups
-                              takes the items from per-XCD queues, an XCD whose own eighth is used up helping the one with
-                              the most left (the 8 XCDs do not stream equally fast) -- measured + 1.6 % on R-MAT 2^24 and
-                              - 6 % on 2^22, kept as an A/B arm                                                   */
+    int32_t er_panel_threads; /* panel form, pass 1: workgroup size, 512 or 1024 (0 = automatic)                 */
+    int32_t er_queue;      /* panel form, pass 1: 2 = one workgroup per item; 1 = one resident round of workgroups takes the items from
+                              per-XCD queues, an XCD whose own eighth is used up helping the one with the most left (the 8 XCDs do not
+                              stream equally fast), and a workgroup that takes the next item of the SAME panel does not stage it again;
+                              0 = automatic: the queues from six items per resident workgroup up (R-MAT 2^24, 2,700 items: 574 -> 544 us;
+                              2^22, 770 items: 132 -> 138 us, so not there)                                                    */
     int32_t symbolic;      /* ehyb_plan_create / ehyb_plan_create_segs (the calls that build AND upload): where the panel form
                               of a residual is built when it is certain to be used (R-MAT: every partition given up, or
                               er_mode = 2).  0/2 = on the DEVICE, from the entries in row order (radix sort by panel, row,

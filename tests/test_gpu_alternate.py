@@ -22,6 +22,10 @@ def _case(E, O, kind, args, cfg):
     ("banded-relative-columns", "banded", (1024 * 64, 32, 1024), dict(), True),
     ("rmat-panel", "rmat", (17, 1 << 20, 3), dict(er_mode=2, fuse_er=2, direct=2, er_panel_cols=4096), False),
     ("rmat-panel-units", "rmat", (16, 1 << 19, 5), dict(er_mode=2, fuse_er=2, direct=2, er_units1=7, er_panel_cols=1024), False),
+    # the per-XCD work queues (automatic from six items per resident workgroup up): every eighth taken from its far end on the way back,
+    # and a workgroup that draws the next item of the panel it has staged streams straight away
+    ("rmat-panel-queues", "rmat", (17, 1 << 20, 3), dict(er_mode=2, fuse_er=2, direct=2, er_units1=3000, er_panel_cols=2048, er_queue=1), False),
+    ("rmat-panel-queues-wide", "rmat", (17, 1 << 20, 3), dict(er_mode=2, fuse_er=2, direct=2, er_units1=1200, er_queue=1), False),
 ], ids=lambda v: v if isinstance(v, str) else None)
 def test_both_directions_give_the_product(E, O, gpu, name, kind, args, kw, deterministic):
     cfg = E.make_config(ell_alternate=1, **kw)          # (1 = always: these matrices are far smaller than the cache)
