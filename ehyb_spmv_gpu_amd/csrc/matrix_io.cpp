@@ -767,15 +767,12 @@ static inline void rmat_sample(int scale, uint64_t seed, int64_t e, int* pi, int
 // ranges holding about equally many edge samples (cuts[0..n_blocks], the same on every process: they
 // come from a histogram pass over all samples), and only the samples of the own block are kept, sorted
 // and merged.  Dimension 2^scale, rows outside the block empty.
-int ehyb_gen_rmat_block(int scale, int64_t edges, uint64_t seed, int block, int n_blocks, int* cuts, const ehyb_config* cfg,
-                        matrixCOO* out)
+// rows [r0, r1) of the R-MAT: block < 0 -- the caller names the rows (ehyb_gen_rmat_rows); else block `block` of n_blocks blocks of equal cost,
+// cuts filled (ehyb_gen_rmat_block)
+static int gen_rmat_rows_impl(int scale, int64_t edges, uint64_t seed, int block, int n_blocks, int* cuts, int r0_in, int r1_in, const ehyb_config* cfg,
+                              matrixCOO* out)
 {
-    clear_error();
-    OmpScope omp_scope(cfg);
-    if (!out || !cuts || scale < 1 || scale > 30 || edges < 1 || n_blocks < 1 || block < 0 || block >= n_blocks)
-        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_rmat_block: bad arguments");
     const int n = 1 << scale;
-    if (n_blocks > n) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_rmat_block: more blocks than rows");
     // pass 1: samples per row (every process, nothing stored)
     std::vector<int64_t> hist((size_t)n + 1, 0);
     {
@@ -803,8 +800,8 @@ int ehyb_gen_rmat_block(int scale, int64_t edges, uint64_t seed, int block, int 
     // equal samples gave the rank with the 7.3 M low-degree rows 552 MB to move and the rank with the 70 k hub rows 295 MB.
     // A row counts for two samples more.
     auto cost_before = [&](int i) { return hist[(size_t)i] + 2 * (int64_t)i; };
-    cuts[0] = 0;
-    for (int b = 1; b < n_blocks; ++b) {
+    if (block >= 0) cuts[0] = 0;
+    for (int b = 1; block >= 0 && b < n_blocks; ++b) {
         const int64_t goal = cost_before(n) * b / n_blocks;
         int lo = 0, hi = n;  // first row index whose cost_before reaches the goal
         while (lo < hi) {
@@ -817,8 +814,8 @@ int ehyb_gen_rmat_block(int scale, int64_t edges, uint64_t seed, int block, int 
         int c = std::min(std::max(lo, cuts[b - 1] + 1), n - (n_blocks - b));
         cuts[b] = c;
     }
-    cuts[n_blocks] = n;
-    const int r0 = cuts[block], r1 = cuts[block + 1];
+    if (block >= 0) cuts[n_blocks] = n;
+    const int r0 = block >= 0 ? cuts[block] : r0_in, r1 = block >= 0 ? cuts[block + 1] : r1_in;
     // pass 2: the own block's samples, grouped by row
     const int64_t mine = hist[r1] - hist[r0];
     std::vector<int> cols((size_t)mine);
@@ -864,6 +861,26 @@ int ehyb_gen_rmat_block(int scale, int64_t edges, uint64_t seed, int block, int 
         }
     }
     return EHYB_OK;
+}
+
+int ehyb_gen_rmat_block(int scale, int64_t edges, uint64_t seed, int block, int n_blocks, int* cuts, const ehyb_config* cfg,
+                        matrixCOO* out)
+{
+    clear_error();
+    OmpScope omp_scope(cfg);
+    if (!out || !cuts || scale < 1 || scale > 30 || edges < 1 || n_blocks < 1 || block < 0 || block >= n_blocks)
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_rmat_block: bad arguments");
+    if (n_blocks > (1 << scale)) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_rmat_block: more blocks than rows");
+    return gen_rmat_rows_impl(scale, edges, seed, block, n_blocks, cuts, 0, 0, cfg, out);
+}
+
+int ehyb_gen_rmat_rows(int scale, int64_t edges, uint64_t seed, int row0, int row1, const ehyb_config* cfg, matrixCOO* out)
+{
+    clear_error();
+    OmpScope omp_scope(cfg);
+    if (!out || scale < 1 || scale > 30 || edges < 1 || row0 < 0 || row1 > (1 << scale) || row0 >= row1)
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_rmat_rows: bad arguments");
+    return gen_rmat_rows_impl(scale, edges, seed, -1, 1, nullptr, row0, row1, cfg, out);
 }
 
 int ehyb_gen_rmat(int scale, int64_t edges, uint64_t seed, const ehyb_config* cfg, matrixCOO* out)

@@ -143,6 +143,9 @@ class Matrix:
             cuts = (C.c_int * (n_blocks + 1))()
             rc = m.lib.ehyb_gen_rmat_block(scale, edges, seed, block, n_blocks, cuts, cp, C.byref(m.c))
             m.block_cuts = [int(c) for c in cuts]
+        elif kind == "rmat_rows":
+            scale, edges, seed, row0, row1 = args
+            rc = m.lib.ehyb_gen_rmat_rows(scale, edges, seed, row0, row1, cp, C.byref(m.c))
         elif kind == "stencil2d":
             nx, ny, points, extra, seed = args
             rc = m.lib.ehyb_gen_stencil2d(nx, ny, points, extra, seed, cp, C.byref(m.c))

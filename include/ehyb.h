@@ -763,6 +763,9 @@ int ehyb_gen_rmat(int scale, int64_t edges, uint64_t seed, const ehyb_config* cf
  * (n_blocks+1 ints, out) are the same on every process.  Dimension 2^scale, rows outside the block empty. */
 int ehyb_gen_rmat_block(int scale, int64_t edges, uint64_t seed, int block, int n_blocks, int* cuts, const ehyb_config* cfg,
                         matrixCOO* out);
+/* The rows [row0, row1) of that same matrix, for a process whose row range was decided elsewhere (bench.py re-cuts the ranks' rows once
+ * the cost of the "cover" exchange is known).  Dimension 2^scale, rows outside the range empty. */
+int ehyb_gen_rmat_rows(int scale, int64_t edges, uint64_t seed, int row0, int row1, const ehyb_config* cfg, matrixCOO* out);
 /* 2-D 5/9-point stencil plus `extra` random symmetric couplings (small test inputs) */
 int ehyb_gen_stencil2d(int nx, int ny, int points, int extra, uint64_t seed,
                        const ehyb_config* cfg, matrixCOO* out);

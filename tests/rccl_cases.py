@@ -191,11 +191,14 @@ def test_whole_step_replayed_from_a_hipgraph(E, O, comm):
     L, plain, eager, x, y_ref, scale = _case(E, O, comm, "rmat", (17, 1 << 20, 1), cfg, cfgp, 2, [0.25, 0.75], 0.6)
     g = D.HaloSpmv(L, torch.device("cuda", 0), comm=comm, graph=True)
     g.set_x_local(x)
+    torch.cuda.synchronize()
+    side = torch.cuda.Stream()                 # (the legacy default stream cannot be captured: the step needs a stream of its own)
     ys = []
-    for k in range(8):
-        g.step()
-        ys.append(g.y.clone())
-        g.x[:L.n_loc].mul_(-0.5)
+    with torch.cuda.stream(side):
+        for k in range(8):
+            g.step()
+            ys.append(g.y.clone())
+            g.x[:L.n_loc].mul_(-0.5)
     torch.cuda.synchronize()
     state = g.graph_state()
     print(f"graph state after 8 steps: {state} {getattr(g, 'graph_note', '')}")
@@ -203,13 +206,14 @@ def test_whole_step_replayed_from_a_hipgraph(E, O, comm):
     for k, y in enumerate(ys):
         assert O.check_tolerance(L.y_from_plan(y.cpu().numpy()), y_ref * (-0.5) ** k, scale * 0.5 ** k)[0] == 0, k
     t_issue, done = 0.0, 0
-    while done < 240:
-        t0 = time.perf_counter()
-        for _ in range(8):
-            g.step()
-        t_issue += time.perf_counter() - t0
-        torch.cuda.synchronize()
-        done += 8
+    with torch.cuda.stream(side):
+        while done < 240:
+            t0 = time.perf_counter()
+            for _ in range(8):
+                g.step()
+            t_issue += time.perf_counter() - t0
+            torch.cuda.synchronize()
+            done += 8
     print(f"host_us_per_step (C step from a hipGraph, state {state}): {t_issue / done * 1e6:.1f}")
 
 

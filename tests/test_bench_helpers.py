@@ -114,6 +114,11 @@ def test_rmat_row_blocks_are_the_rows_of_the_full_matrix(E):
         # balanced on COST: a row counts for its edge samples plus two (per-row bytes of x, y and the partial sums)
         cost = np.diff(np.asarray(full.row_idx)[cuts0]) + 2 * np.diff(cuts0)
         assert cost.max() <= 1.25 * cost.mean() + 5000                    # (hub rows are lumpy, duplicates merged)
+    # ehyb_gen_rmat_rows: a row range named by the caller
+    for r0, r1 in ((0, 1), (1000, 9000), (32000, 32768)):
+        m = E.Matrix.generate("rmat_rows", 15, 1 << 18, 5, r0, r1)
+        a, b = int(full.row_idx[r0]), int(full.row_idx[r1])
+        assert m.n == full.n and m.nnz == b - a and np.array_equal(m.I, full.I[a:b]) and np.array_equal(m.J, full.J[a:b]) and np.array_equal(m.V, full.V[a:b])
 
 
 # ---------------------------------------------------------------- the roofline block's three formulas (round-3 verdict)
