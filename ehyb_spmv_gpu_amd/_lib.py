@@ -158,7 +158,6 @@ SIGNATURES = {
     "ehyb_halo_create": (C.c_int, [_vp, _vp, C.c_int, _P(C.c_int32), C.c_int64, _i64p, _i64p, _P(_vp)]),
     "ehyb_halo_destroy": (None, [_vp]),
     "ehyb_halo_spmv": (C.c_int, [_vp, _vp, _vp, _vp]),
-    "ehyb_halo_graph": (C.c_int, [_vp, C.c_int, _ip]),
     "ehyb_halo_set_partials": (C.c_int, [_vp, C.c_int, _i64p, _i64p, _P(C.c_int32), C.c_int64]),
     "ehyb_gather_spmv": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int64, _vp]),
     "ehyb_spmv_bench": (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, _dp, _dp, _dp]),

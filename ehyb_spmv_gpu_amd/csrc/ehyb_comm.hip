@@ -130,13 +130,6 @@ struct ehyb_halo {
     std::vector<int64_t> recv_col;             // [chunk * world + peer] column of x the peer's entries of that chunk land at
     std::vector<hipEvent_t> ev;                // [0] packed; [1 + k] chunk k delivered; [n_chunks + 1] step done (comm stream may be reused)
     int64_t steps = 0;
-    // hipGraph replay of the whole step (ehyb_halo_graph): two executables, one per walk direction of the plan's streams
-    int graph_state = 0;                       // 0 off, 1 wanted (eager until warm, then captured), 2 replaying, -1 capture refused: eager for good
-    hipGraphExec_t gexec[2] = {nullptr, nullptr};
-    double *gx = nullptr, *gy = nullptr;
-    hipStream_t gcs = nullptr;
-    int gnext = 0;
-    std::string graph_note;                    // why a capture was refused
     // exchange "cover" (ehyb_halo_set_partials): the plan's rows from row_split on are partial sums for OTHER ranks' rows, computed
     // here from this rank's own x entries; they leave as soon as they are closed, the ones computed elsewhere for this rank's rows
     // arrive in d_ybuf and are added into y at the end of the step
@@ -148,8 +141,6 @@ struct ehyb_halo {
     int32_t* d_yidx = nullptr;
     hipEvent_t ev_foreign = nullptr, ev_partials = nullptr;
 };
-
-static void drop_graphs(ehyb_halo* h);
 
 extern "C" {
 
@@ -351,7 +342,6 @@ void ehyb_halo_destroy(ehyb_halo* h)
 {
     if (!h) return;
     if (h->comm && h->comm->stream) (void)hipStreamSynchronize(h->comm->stream);
-    drop_graphs(h);
     for (auto e : h->ev)
         if (e) (void)hipEventDestroy(e);
     if (h->ev_foreign) (void)hipEventDestroy(h->ev_foreign);
@@ -470,64 +460,14 @@ static int halo_step_eager(ehyb_halo* h, double* x_dev, double* y_dev, void* com
     return rc;
 }
 
-static void drop_graphs(ehyb_halo* h)
-{
-    for (auto& g : h->gexec) {
-        if (g) (void)hipGraphExecDestroy(g);
-        g = nullptr;
-    }
-    h->gnext = 0;
-}
-
 int ehyb_halo_spmv(ehyb_halo* h, double* x_dev, double* y_dev, void* compute_stream)
 {
     if (!h || !x_dev || !y_dev) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_halo_spmv: null argument");
-    hipStream_t cs = (hipStream_t)compute_stream;
     ++h->steps;
-    // eager: always, until two steps have run (RCCL sets up its connections on first use: not capturable), and for good once a
-    // capture has been refused
-    if (h->graph_state <= 0 || h->steps <= 2) return halo_step_eager(h, x_dev, y_dev, compute_stream);
-    if (h->gx != x_dev || h->gy != y_dev || h->gcs != cs) {   // a captured step is bound to its vectors and its stream
-        drop_graphs(h);
-        h->gx = x_dev, h->gy = y_dev, h->gcs = cs;
-    }
-    const int p = h->gnext;
-    if (!h->gexec[p]) {
-        // capture: the communicator's stream joins through its wait on the pack event and is joined back by the wait on the last
-        // chunk's event, RCCL records its grouped send / recv kernels into the graph; successive captures see the plan's walk
-        // direction alternate (cfg.ell_alternate), so the two executables replay the two directions in turn
-        hipGraph_t g = nullptr;
-        hipError_t e = hipStreamBeginCapture(cs, hipStreamCaptureModeRelaxed);
-        int rc = e == hipSuccess ? halo_step_eager(h, x_dev, y_dev, compute_stream) : EHYB_ERR_HIP;
-        if (e != hipSuccess) h->graph_note = std::string("hipStreamBeginCapture: ") + hipGetErrorString(e);
-        else if (rc != EHYB_OK) h->graph_note = std::string("while capturing: ") + ehyb_last_error();
-        if (e == hipSuccess) {
-            const hipError_t e2 = hipStreamEndCapture(cs, &g);
-            if (rc == EHYB_OK && e2 != hipSuccess) {
-                rc = EHYB_ERR_HIP;
-                h->graph_note = std::string("hipStreamEndCapture: ") + hipGetErrorString(e2);
-            }
-        }
-        if (rc == EHYB_OK) {
-            const hipError_t e3 = hipGraphInstantiate(&h->gexec[p], g, nullptr, nullptr, 0);
-            if (e3 != hipSuccess) {
-                rc = EHYB_ERR_HIP;
-                h->graph_note = std::string("hipGraphInstantiate: ") + hipGetErrorString(e3);
-            }
-        }
-        if (g) (void)hipGraphDestroy(g);
-        if (rc != EHYB_OK) {
-            // nothing of the refused capture has run: drop the idea, run this step (and all later ones) eagerly
-            (void)hipGetLastError();
-            drop_graphs(h);
-            h->graph_state = -1;
-            return halo_step_eager(h, x_dev, y_dev, compute_stream);
-        }
-        h->graph_state = 2;
-    }
-    HIP_TRY(hipGraphLaunch(h->gexec[p], cs));
-    h->gnext ^= 1;
-    return EHYB_OK;
+    // (Replaying the whole step from a hipGraph was built and taken out again in round 4: capturing RCCL's grouped send / recv
+    // on a non-default stream crashes inside this RCCL 2.26.6 / HIP 7.0 -- a segmentation fault under hipStreamBeginCapture,
+    // gpurun_out r04_g -- and the eager call costs the host 30-50 us against ~115 us of device time per step.)
+    return halo_step_eager(h, x_dev, y_dev, compute_stream);
 }
 
 // Turns the halo object into the "cover" exchange: the plan was built with cfg.row_split = row_split and its rows from there on are
@@ -565,22 +505,6 @@ int ehyb_halo_set_partials(ehyb_halo* h, int row_split, const int64_t* ysend_cou
     h->n_yrecv = n_yrecv;
     h->row_split = row_split;
     h->cover = true;
-    return EHYB_OK;
-}
-
-// on != 0: from the third step on the whole step -- pack, RCCL exchanges, every part of the multiply, both streams -- is replayed
-// from a hipGraph, ONE hipGraphLaunch per multiply; x, y and the stream must then stay the same from step to step (a change is
-// noticed and captured anew).  *state (may be NULL): 0 off, 1 wanted, 2 replaying, -1 the capture was refused (by HIP or by
-// this RCCL): steps run eagerly, as without the call.
-int ehyb_halo_graph(ehyb_halo* h, int on, int* state)
-{
-    if (!h) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_halo_graph: null");
-    if (on >= 0) {
-        if (!on) drop_graphs(h);
-        h->graph_state = on ? (h->graph_state == 2 ? 2 : 1) : 0;
-    }
-    if (state) *state = h->graph_state;
-    if (h->graph_state < 0) set_error("ehyb_halo_graph: capture refused: %s", h->graph_note.c_str());   // (readable through ehyb_last_error; the call itself succeeds)
     return EHYB_OK;
 }
 

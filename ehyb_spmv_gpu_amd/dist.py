@@ -537,7 +537,7 @@ class HaloSpmv:
     collectives on a side stream.  pipelined=False: pack, every chunk, then the whole multiply in one call (the plain step
     the pipelined one is checked against)."""
 
-    def __init__(self, local, device, overlap=True, stage_on_cpu=False, mode="a2a", c_step=False, comm=None, graph=False):
+    def __init__(self, local, device, overlap=True, stage_on_cpu=False, mode="a2a", c_step=False, comm=None):
         """comm: a Comm (RCCL communicator of libehyb.so, make_comm) -- the step is then ONE C call, ehyb_halo_spmv: pack, the
         chunks as grouped ncclSend / ncclRecv pairs on the communicator's stream, the parts of the multiply behind them; torch
         takes no part in it.  Without one the collectives are torch.distributed's, issued from Python (the A/B arm, and the
@@ -563,8 +563,6 @@ class HaloSpmv:
             if comm.world != local.world or comm.rank != local.rank:
                 raise ValueError("HaloSpmv: the communicator and the matrix disagree about rank / world size")
             self.c_halo = comm.halo(self.plan, local)
-            if graph:   # the whole step replayed from a hipGraph from its third call on (ehyb_halo_graph); eager if RCCL refuses the capture
-                H._check(H._lib.load().ehyb_halo_graph(self.c_halo, 1, None), "ehyb_halo_graph")
         self.overlap = overlap and local.exchanges
         self.comm_stream = torch.cuda.Stream(device=device) if self.overlap else None
         st = self.plan.stats
@@ -572,15 +570,6 @@ class HaloSpmv:
         self.has_parts = not (st["er_inline"] > 0)
         self.lib = H._lib.load()
         self._xp, self._yp = C.c_void_p(self.x.data_ptr()), C.c_void_p(self.y.data_ptr())
-
-    def graph_state(self):
-        """0 off, 1 wanted, 2 replaying, -1 capture refused (steps run eagerly)."""
-        if self.c_halo is None:
-            return 0
-        st = C.c_int(0)
-        H._check(self.lib.ehyb_halo_graph(self.c_halo, -1, C.byref(st)), "ehyb_halo_graph")
-        self.graph_note = self.lib.ehyb_last_error().decode(errors="replace") if st.value < 0 else ""
-        return st.value
 
     def set_x_local(self, x_local):
         """x_local: this rank's x segment in global label order."""

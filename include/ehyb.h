@@ -567,12 +567,6 @@ int ehyb_halo_spmv(ehyb_halo* halo, double* x_dev, double* y_dev, void* compute_
  */
 int ehyb_halo_set_partials(ehyb_halo* halo, int row_split, const int64_t* ysend_counts, const int64_t* yrecv_counts,
                            const int32_t* yrecv_idx_host, int64_t n_yrecv);
-/* on > 0: from the third step on the whole step (pack, the RCCL exchanges, every part, both streams) is captured into hipGraphs --
- * one per walk direction of the plan (cfg.ell_alternate), replayed in turn -- and a multiply costs the host ONE hipGraphLaunch;
- * x, y and the stream must then stay the same from step to step (a change is noticed and captured anew).  on = 0: off (default);
- * on < 0: query only.  *state (may be NULL): 0 off, 1 wanted, 2 replaying, -1 the capture was refused by HIP or by this RCCL --
- * the steps then run eagerly as if the call had not been made. */
-int ehyb_halo_graph(ehyb_halo* halo, int on, int* state);
 /* north_star's "all-gatherv of x" as one call per step: x = [own segment padded to seg_len | segment of rank 0 | ... | of rank
  * world-1]; ncclAllGather on the communicator's stream while the ELL phase runs, then the residual phase (dist.py: GatherSpmv) */
 int ehyb_gather_spmv(ehyb_comm* comm, ehyb_plan* plan, double* x_dev, double* y_dev, int64_t seg_len, void* compute_stream);

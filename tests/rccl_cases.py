@@ -178,45 +178,6 @@ def test_host_cost_of_the_c_step(E, O, comm):
     assert host_us < 100
 
 
-def test_whole_step_replayed_from_a_hipgraph(E, O, comm):
-    """ehyb_halo_graph: pack, the RCCL exchanges and every part of the multiply captured into two hipGraphs (one per walk
-    direction) and replayed in turn -- same results as the eager step while x changes under it; if this RCCL / HIP refuses the
-    capture the steps stay eager (state -1) and the results must still be right."""
-    import torch
-
-    from ehyb_spmv_gpu_amd import dist as D
-
-    cfg = E.make_config(partitioner=E.EHYB_PART_DEGREE)
-    cfgp = E.make_config(partitioner=E.EHYB_PART_DEGREE, er_mode=2, er_panel_cols=4096, ell_alternate=1)
-    L, plain, eager, x, y_ref, scale = _case(E, O, comm, "rmat", (17, 1 << 20, 1), cfg, cfgp, 2, [0.25, 0.75], 0.6)
-    g = D.HaloSpmv(L, torch.device("cuda", 0), comm=comm, graph=True)
-    g.set_x_local(x)
-    torch.cuda.synchronize()
-    side = torch.cuda.Stream()                 # (the legacy default stream cannot be captured: the step needs a stream of its own)
-    ys = []
-    with torch.cuda.stream(side):
-        for k in range(8):
-            g.step()
-            ys.append(g.y.clone())
-            g.x[:L.n_loc].mul_(-0.5)
-    torch.cuda.synchronize()
-    state = g.graph_state()
-    print(f"graph state after 8 steps: {state} {getattr(g, 'graph_note', '')}")
-    assert state in (2, -1)
-    for k, y in enumerate(ys):
-        assert O.check_tolerance(L.y_from_plan(y.cpu().numpy()), y_ref * (-0.5) ** k, scale * 0.5 ** k)[0] == 0, k
-    t_issue, done = 0.0, 0
-    with torch.cuda.stream(side):
-        while done < 240:
-            t0 = time.perf_counter()
-            for _ in range(8):
-                g.step()
-            t_issue += time.perf_counter() - t0
-            torch.cuda.synchronize()
-            done += 8
-    print(f"host_us_per_step (C step from a hipGraph, state {state}): {t_issue / done * 1e6:.1f}")
-
-
 def test_cover_exchange_over_rccl(E, O, comm):
     """exchange "cover" through the C step (ehyb_halo_set_partials): x chunks out at once, own columns incl. the foreign rows, the
     foreign rows closed and shipped (to the rank itself here), chunks, own rows closed, received partial sums added -- against the

@@ -19,12 +19,10 @@ def test_rccl_native_step_over_a_loopback_communicator(gpu):
     tail = p.stdout[-4000:] + p.stderr[-2000:]
     assert p.returncode == 0, tail
     m = re.search(r"(\d+) passed", p.stdout)
-    assert m and int(m.group(1)) >= 10, tail
+    assert m and int(m.group(1)) >= 9, tail
     m = re.search(r"host_us_per_step \(C step, 2 chunks, world 1\): ([0-9.]+)", p.stdout)
     assert m, tail
     for line in p.stdout.splitlines():
-        if "graph state" in line or "cover:" in line:
+        if "cover:" in line:
             print(line)
-    g = re.search(r"host_us_per_step \(C step from a hipGraph, state (-?\d+)\): ([0-9.]+)", p.stdout)
-    assert g, tail
-    print(f"host_us_per_step of the C step: {m.group(1)} eager, {g.group(2)} from a hipGraph (state {g.group(1)})")
+    print(f"host_us_per_step of the C step: {m.group(1)}")

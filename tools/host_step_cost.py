@@ -101,20 +101,6 @@ def main():
         sh.set_x_local(np.ones(n_r))
     timed("WHOLE STEP, one C call: ehyb_halo_spmv over RCCL (pack + 2 grouped send/recv exchanges + 3 parts + closing pass; R-MAT 2^18, %d ghost columns)" % L.n_ghost,
           sh_c.step)
-    sh_g = D.HaloSpmv(L, dev, comm=c, graph=True)
-    sh_g.set_x_local(np.ones(n_r))
-    torch.cuda.synchronize()
-    side = torch.cuda.Stream(device=dev)            # (the legacy default stream cannot be captured)
-
-    def graph_step():
-        with torch.cuda.stream(side):
-            sh_g.step()
-
-    for _ in range(4):
-        graph_step()
-    torch.cuda.synchronize()
-    timed("WHOLE STEP replayed from a hipGraph on a stream of its own (ehyb_halo_graph; state %d: 2 = replaying, -1 = capture refused, eager; %s)" % (sh_g.graph_state(), getattr(sh_g, "graph_note", "")),
-          graph_step)
     timed("WHOLE STEP issued from Python: ehyb_step_pack + 3 ehyb_step_part + 2 device copies in place of the collectives", sh_py.step)
     import json
 
