@@ -378,7 +378,8 @@ def run_strong(args, E, torch, dist, rank, world, dev, cfg, log, stage_on_cpu):
     if gen == "rmat":
         # no locality to find: contiguous row blocks with equal numbers of edge samples in the matrix's own
         # numbering; every rank draws all samples twice (histogram, then its own block) and keeps only its rows
-        m = E.Matrix.generate("rmat_block", *gargs, rank, world, cfg=cfg)
+        # (the cuts balance what a rank will multiply: under the cover exchange the entries of the hub rows mostly go to the columns' owners)
+        m = E.Matrix.generate("rmat_block", *gargs, rank, world, 1 if args.exchange == "cover" else 0, cfg=cfg)
         n, cuts = m.n, m.block_cuts
         t = torch.tensor([float(m.nnz)], dtype=torch.float64, device=dev)
         dist.all_reduce(t)

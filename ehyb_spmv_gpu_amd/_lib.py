@@ -199,6 +199,7 @@ SIGNATURES = {
     "ehyb_gen_rmat": (C.c_int, [C.c_int, C.c_int64, C.c_uint64, _cfgp, _mp]),
     "ehyb_gen_rmat_block": (C.c_int, [C.c_int, C.c_int64, C.c_uint64, C.c_int, C.c_int, _ip, _cfgp, _mp]),
     "ehyb_gen_rmat_rows": (C.c_int, [C.c_int, C.c_int64, C.c_uint64, C.c_int, C.c_int, _cfgp, _mp]),
+    "ehyb_gen_rmat_block_cost": (C.c_int, [C.c_int, C.c_int64, C.c_uint64, C.c_int, C.c_int, C.c_int, _ip, _cfgp, _mp]),
     "ehyb_gen_stencil2d": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _cfgp, _mp]),
     "ehyb_gen_kkt3d": (C.c_int, [C.c_int, _cfgp, _mp]),
     "ehyb_gen_mesh3d": (C.c_int, [C.c_int, C.c_int, C.c_int, C.c_int, C.c_uint64, _cfgp, _mp]),

@@ -769,29 +769,64 @@ static inline void rmat_sample(int scale, uint64_t seed, int64_t e, int* pi, int
 // and merged.  Dimension 2^scale, rows outside the block empty.
 // rows [r0, r1) of the R-MAT: block < 0 -- the caller names the rows (ehyb_gen_rmat_rows); else block `block` of n_blocks blocks of equal cost,
 // cuts filled (ehyb_gen_rmat_block)
+// cost_model (blocks only): 0 = a row costs its samples + 2; 1 = the cost under the "cover" exchange of the multi-GPU step, where an entry is
+// multiplied by the owner of its ROW if its column is the hub of the two (column degree >= row degree: the column's x entry travels) and by the
+// owner of its COLUMN otherwise (a partial sum travels back): index k costs the samples it ends up multiplying + 2
 static int gen_rmat_rows_impl(int scale, int64_t edges, uint64_t seed, int block, int n_blocks, int* cuts, int r0_in, int r1_in, const ehyb_config* cfg,
-                              matrixCOO* out)
+                              matrixCOO* out, int cost_model = 0)
 {
     const int n = 1 << scale;
     // pass 1: samples per row (every process, nothing stored)
     std::vector<int64_t> hist((size_t)n + 1, 0);
+    std::vector<int64_t> work;   // cost_model 1: prefix of the samples every index multiplies
     {
         const int nt = omp_get_max_threads();
-        std::vector<std::vector<int32_t>> part((size_t)nt);
+        const bool cover = cost_model == 1 && block >= 0;
+        std::vector<std::vector<int32_t>> part((size_t)nt), cpart((size_t)(cover ? nt : 0));
 #pragma omp parallel
         {
             std::vector<int32_t>& h = part[omp_get_thread_num()];
             h.assign((size_t)n, 0);
+            int32_t* hc = nullptr;
+            if (cover) {
+                cpart[omp_get_thread_num()].assign((size_t)n, 0);
+                hc = cpart[omp_get_thread_num()].data();
+            }
 #pragma omp for schedule(static, 65536)
             for (int64_t e = 0; e < edges; ++e) {
                 int i, j;
                 rmat_sample(scale, seed, e, &i, &j);
                 ++h[i];
+                if (hc) ++hc[j];
             }
         }
         for (const auto& h : part)
             if (!h.empty())
                 for (int i = 0; i < n; ++i) hist[i + 1] += h[i];
+        if (cover) {
+            std::vector<int32_t> rdeg((size_t)n), cdeg((size_t)n, 0);
+            for (int i = 0; i < n; ++i) rdeg[(size_t)i] = (int32_t)hist[(size_t)i + 1];
+            for (const auto& h : cpart)
+                if (!h.empty())
+                    for (int i = 0; i < n; ++i) cdeg[(size_t)i] += h[(size_t)i];
+            // second sweep over the samples: who multiplies each (the per-thread row histograms are reused as counters)
+#pragma omp parallel
+            {
+                std::vector<int32_t>& w = part[omp_get_thread_num()];
+                std::fill(w.begin(), w.end(), 0);
+#pragma omp for schedule(static, 65536)
+                for (int64_t e = 0; e < edges; ++e) {
+                    int i, j;
+                    rmat_sample(scale, seed, e, &i, &j);
+                    ++w[(size_t)(cdeg[(size_t)j] >= rdeg[(size_t)i] ? i : j)];
+                }
+            }
+            work.assign((size_t)n + 1, 0);
+            for (const auto& w : part)
+                if (!w.empty())
+                    for (int i = 0; i < n; ++i) work[(size_t)i + 1] += w[(size_t)i];
+            for (int i = 0; i < n; ++i) work[(size_t)i + 1] += work[(size_t)i];
+        }
     }
     for (int i = 0; i < n; ++i) hist[i + 1] += hist[i];
     // Blocks of equal COST, not of equal samples: besides its entries a row costs its x and y entries and -- in the panel
@@ -799,7 +834,9 @@ static int gen_rmat_rows_impl(int scale, int64_t edges, uint64_t seed, int block
     // on the plans of R-MAT 2^24 at 8 ranks (tools/dist_stats.py): format bytes = 18 B per entry + 34 B per row, so that
     // equal samples gave the rank with the 7.3 M low-degree rows 552 MB to move and the rank with the 70 k hub rows 295 MB.
     // A row counts for two samples more.
-    auto cost_before = [&](int i) { return hist[(size_t)i] + 2 * (int64_t)i; };
+    // (cost_model 1, the "cover" exchange: model rows [0.13 .. 5.7 M] -> work max / mean 1.24 with the row cost, 1.05 with this one at 8 ranks;
+    // 1.23 -> 1.08 at 4, 1.14 -> 1.01 at 2: R-MAT 2^22, the cover really chosen per block afterwards)
+    auto cost_before = [&](int i) { return (work.empty() ? hist[(size_t)i] : work[(size_t)i]) + 2 * (int64_t)i; };
     if (block >= 0) cuts[0] = 0;
     for (int b = 1; block >= 0 && b < n_blocks; ++b) {
         const int64_t goal = cost_before(n) * b / n_blocks;
@@ -872,6 +909,17 @@ int ehyb_gen_rmat_block(int scale, int64_t edges, uint64_t seed, int block, int 
         EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_rmat_block: bad arguments");
     if (n_blocks > (1 << scale)) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_rmat_block: more blocks than rows");
     return gen_rmat_rows_impl(scale, edges, seed, block, n_blocks, cuts, 0, 0, cfg, out);
+}
+
+int ehyb_gen_rmat_block_cost(int scale, int64_t edges, uint64_t seed, int block, int n_blocks, int cost_model, int* cuts, const ehyb_config* cfg,
+                             matrixCOO* out)
+{
+    clear_error();
+    OmpScope omp_scope(cfg);
+    if (!out || !cuts || scale < 1 || scale > 30 || edges < 1 || n_blocks < 1 || block < 0 || block >= n_blocks || cost_model < 0 || cost_model > 1)
+        EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_rmat_block_cost: bad arguments");
+    if (n_blocks > (1 << scale)) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gen_rmat_block_cost: more blocks than rows");
+    return gen_rmat_rows_impl(scale, edges, seed, block, n_blocks, cuts, 0, 0, cfg, out, cost_model);
 }
 
 int ehyb_gen_rmat_rows(int scale, int64_t edges, uint64_t seed, int row0, int row1, const ehyb_config* cfg, matrixCOO* out)

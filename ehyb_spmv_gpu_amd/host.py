@@ -139,9 +139,10 @@ class Matrix:
             scale, edges, seed = args
             rc = m.lib.ehyb_gen_rmat(scale, edges, seed, cp, C.byref(m.c))
         elif kind == "rmat_block":
-            scale, edges, seed, block, n_blocks = args
+            scale, edges, seed, block, n_blocks = args[:5]
+            cost_model = int(args[5]) if len(args) > 5 else 0      # 1: cuts balanced for the "cover" exchange (ehyb_gen_rmat_block_cost)
             cuts = (C.c_int * (n_blocks + 1))()
-            rc = m.lib.ehyb_gen_rmat_block(scale, edges, seed, block, n_blocks, cuts, cp, C.byref(m.c))
+            rc = m.lib.ehyb_gen_rmat_block_cost(scale, edges, seed, block, n_blocks, cost_model, cuts, cp, C.byref(m.c))
             m.block_cuts = [int(c) for c in cuts]
         elif kind == "rmat_rows":
             scale, edges, seed, row0, row1 = args

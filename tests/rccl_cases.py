@@ -201,3 +201,42 @@ def test_cover_exchange_over_rccl(E, O, comm):
     torch.cuda.synchronize()
     for k, y in enumerate(ys):
         assert O.check_tolerance(L.y_from_plan(y.cpu().numpy()), y_ref * (-0.5) ** k, scale * 0.5 ** k)[0] == 0, k
+
+
+def test_gather_spmv_single_rank(E, O, comm):
+    """ehyb_gather_spmv (the all-gather arm as one call): x = [own segment | the segment of every rank as ncclAllGather delivers it].
+    One rank: the gathered part is a copy of the own segment -- a matrix whose off-diagonal half reads its columns THERE must
+    multiply like the original."""
+    import torch
+
+    from ehyb_spmv_gpu_amd import _lib
+
+    cfg = E.make_config(lds_doubles=4096)
+    m0 = E.Matrix.generate("fem3d", 24000, 3, 20, 20, 13500, 0, 3, cfg=cfg)
+    n = m0.n
+    I, J, V = m0.I.copy(), m0.J.copy(), m0.V.copy()
+    m0.free()
+    x = O.x_glibc(n)
+    y_ref = O.spmv_coo(n, I, J, V, x)
+    scale = O.abs_rowsum(n, I, J, V, x)
+    far = np.abs(I.astype(np.int64) - J) > 40              # these entries read x from the gathered copy
+    keep = ~far
+    indptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(np.bincount(I[keep], minlength=n), out=indptr[1:])
+    cfg1 = E.make_config(lds_doubles=4096, n_top=1)
+    m = E.Matrix.from_csr(indptr, J[keep], V[keep], cfg1)
+    m.reorder(cfg1)
+    perm = m.reorder_list[:n].copy()
+    seg = n                                                # one rank: its padded segment is the segment
+    m.append_ghosts(seg, perm[I[far]], perm[J[far]], V[far])   # ghost column g = place of x entry g in the gathered copy (owner's plan order)
+    plan = E.Plan(m, E.make_config(lds_doubles=4096, n_top=2), rows=(0, n))
+    dev = torch.device("cuda", 0)
+    xd = torch.zeros(2 * seg, dtype=torch.float64, device=dev)
+    xd[:n] = torch.from_numpy(E.vector_reorder(x, perm)).to(dev)
+    xd[seg:].fill_(float("nan"))                           # must come from the collective
+    yd = torch.full((n,), float("nan"), dtype=torch.float64, device=dev)
+    lib = _lib.load()
+    for _ in range(3):
+        assert lib.ehyb_gather_spmv(comm.h, plan.h, xd.data_ptr(), yd.data_ptr(), seg, torch.cuda.current_stream().cuda_stream) == 0, lib.ehyb_last_error()
+    torch.cuda.synchronize()
+    assert O.check_tolerance(E.vector_recover(yd.cpu().numpy(), perm), y_ref, scale)[0] == 0

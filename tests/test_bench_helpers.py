@@ -114,6 +114,18 @@ def test_rmat_row_blocks_are_the_rows_of_the_full_matrix(E):
         # balanced on COST: a row counts for its edge samples plus two (per-row bytes of x, y and the partial sums)
         cost = np.diff(np.asarray(full.row_idx)[cuts0]) + 2 * np.diff(cuts0)
         assert cost.max() <= 1.25 * cost.mean() + 5000                    # (hub rows are lumpy, duplicates merged)
+    # ehyb_gen_rmat_block_cost, cost model 1 (the "cover" exchange: an entry counts for the owner of its row if its column has the higher degree,
+    # else for the owner of its column): the same rows of the same matrix, cut elsewhere -- the block of the hub rows gets MORE rows
+    for world in (2, 8):
+        c0 = E.Matrix.generate("rmat_block", 15, 1 << 18, 5, 0, world).block_cuts
+        total = 0
+        for b in range(world):
+            m = E.Matrix.generate("rmat_block", 15, 1 << 18, 5, b, world, 1)
+            c1 = m.block_cuts
+            a, e = int(full.row_idx[c1[b]]), int(full.row_idx[c1[b + 1]])
+            assert np.array_equal(m.J, full.J[a:e]) and np.array_equal(m.V, full.V[a:e])
+            total += m.nnz
+        assert total == full.nnz and c1[0] == 0 and c1[-1] == full.n and all(np.diff(c1) > 0) and c1[1] > c0[1]
     # ehyb_gen_rmat_rows: a row range named by the caller
     for r0, r1 in ((0, 1), (1000, 9000), (32000, 32768)):
         m = E.Matrix.generate("rmat_rows", 15, 1 << 18, 5, r0, r1)

@@ -19,7 +19,7 @@ def test_rccl_native_step_over_a_loopback_communicator(gpu):
     tail = p.stdout[-4000:] + p.stderr[-2000:]
     assert p.returncode == 0, tail
     m = re.search(r"(\d+) passed", p.stdout)
-    assert m and int(m.group(1)) >= 9, tail
+    assert m and int(m.group(1)) >= 10, tail
     m = re.search(r"host_us_per_step \(C step, 2 chunks, world 1\): ([0-9.]+)", p.stdout)
     assert m, tail
     for line in p.stdout.splitlines():

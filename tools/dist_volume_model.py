@@ -186,6 +186,35 @@ def main():
         t, lb = t_two_sided(vol["cover"], cover_recv_entries)
         tl["cover (hub columns as x, the rest as partial sums, per block)"] = t
         arms["cover"]["compute_imbalance_max_over_mean"] = round(lb, 3)
+        # the same cover with the rows cut for ITS cost (ehyb_gen_rmat_block_cost, cost model 1: an entry counts for the owner of its row
+        # if its column has the higher degree of the two, else for the owner of its column) -- what bench.py does for --exchange cover
+        mb1 = E.Matrix.generate("rmat_block", args.scale, 1 << (args.scale + 3), 1, 0, N, 1, cfg=cfg)
+        cuts1 = np.asarray(mb1.block_cuts, dtype=np.int64)
+        mb1.free()
+        saved = (bn, nzc, nzr, off, rows_of, own, t_plan, pass2, ent_row)
+        bn, nzc, nzr, br1, bs1 = block_stats(I, J, cuts1)
+        rows_of = np.diff(cuts1)
+        ent_row = bn.sum(axis=1)
+        own = np.diag(bn)
+        t_plan = (B_ENTRY * ent_row + B_ROW * rows_of) / rate
+        pass2 = 0.12 * t_plan
+        blk1 = br1 * N + bs1
+        order1 = np.argsort(blk1, kind="stable")
+        first1 = np.concatenate(([0], np.cumsum(np.bincount(blk1, minlength=N * N))))
+        cover1 = np.zeros((N, N), dtype=np.int64)
+        cre1 = np.zeros((N, N), dtype=np.int64)
+        for r in range(N):
+            for s in range(N):
+                if r != s:
+                    size, ncol, nrow, ent = greedy_cover(I, J, order1[first1[r * N + s]:first1[r * N + s + 1]])
+                    cover1[r, s], cre1[r, s] = size, ent
+        t, lb = t_two_sided(cover1, cre1)
+        tl["cover, rows cut for the cover's own cost (what bench.py runs)"] = t
+        recv1 = cover1.sum(axis=1)
+        arms["cover, re-cut"] = {"rows_per_rank": [int(x) for x in rows_of], "doubles_received_per_rank": [int(x) for x in recv1], "MB_received_max": round(float(recv1.max()) * 8 / 1e6, 2),
+                                 "MB_over_the_busiest_link": round(float(cover1.max()) * 8 / 1e6, 2), "MB_total": round(float(cover1.sum()) * 8 / 1e6, 2),
+                                 "compute_imbalance_max_over_mean": round(lb, 3)}
+        bn, nzc, nzr, off, rows_of, own, t_plan, pass2, ent_row = saved
         tl["no exchange at all (the plans alone: the ceiling of any 1-D scheme)"] = float(t_plan.max())
         res = {"rows_per_rank": [int(x) for x in rows_of], "entries_per_rank": [int(x) for x in ent_row], "own_block_share": [round(float(own[r]) / max(1, ent_row[r]), 3) for r in range(N)],
                "volume": arms, "timeline_us": {k: round(v, 1) for k, v in tl.items()}, "speedup_vs_one_gpu": {k: round(single_us / v, 2) for k, v in tl.items()},
