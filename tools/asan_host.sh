@@ -10,12 +10,12 @@ SRC="$ROOT/ehyb_spmv_gpu_amd/csrc"
 OUT="$ROOT/_ab"
 TMP="$(mktemp -d)"
 mkdir -p "$OUT"
-make -C "$SRC" -j8 >/dev/null                      # the HIP objects (build/ehyb_hip.o, ehyb_cg.o, ehyb_fill.o, er_panel_dev.o)
+make -C "$SRC" -j8 >/dev/null                      # the HIP objects (build/ehyb_hip.o, ehyb_cg.o, ehyb_fill.o, er_panel_dev.o, ehyb_comm.o)
 for f in common partition reorder layout er_panel plan plan_io matrix_io; do
     g++ -O1 -g -fPIC -fopenmp -std=c++17 -fsanitize=address,undefined -fno-omit-frame-pointer \
         -I"$ROOT/include" -I"$SRC" -c "$SRC/$f.cpp" -o "$TMP/$f.o"
 done
-g++ -shared -o "$OUT/libehyb_asan.so" "$TMP"/*.o "$SRC/build/ehyb_hip.o" "$SRC/build/ehyb_cg.o" "$SRC/build/ehyb_fill.o" "$SRC/build/er_panel_dev.o" \
+g++ -shared -o "$OUT/libehyb_asan.so" "$TMP"/*.o "$SRC/build/ehyb_hip.o" "$SRC/build/ehyb_cg.o" "$SRC/build/ehyb_fill.o" "$SRC/build/er_panel_dev.o" "$SRC/build/ehyb_comm.o" \
     -fsanitize=address,undefined -fopenmp -L/opt/rocm/lib -lamdhip64 -ldl -lz -Wl,-rpath,/opt/rocm/lib
 rm -rf "$TMP"
 cd "$ROOT"
