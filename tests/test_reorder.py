@@ -217,3 +217,58 @@ def test_graded_mesh_asks_for_fewer_partitions(E, O):
     assert written[:m.n].min() == 1 and written[:m.n].max() == 1
     bad, worst = O.check_tolerance(E.vector_recover(y, m.reorder_list), y_ref, scale)
     assert bad == 0, worst
+
+
+def test_append_rows_gives_a_rank_its_foreign_rows(E):
+    """ehyb_matrix_append_rows (exchange "cover"): rows behind the last partition receive entries in the rank's own columns and
+    become partitions of their own; what it refuses."""
+    import ctypes as C
+
+    import numpy as np
+
+    from ehyb_spmv_gpu_amd import _lib
+
+    lib = _lib.load()
+    cfg = E.make_config(lds_doubles=1024)
+    m = E.Matrix.generate("stencil2d", 40, 40, 5, 200, 3, cfg=cfg)
+    m.reorder(cfg)
+    n0, nnz0, np0 = m.n, m.nnz, int(m.c.nParts)
+    assert int(m.part_boundary[np0]) == n0
+    m.append_ghosts(700, np.array([0, 1, 5], dtype=np.int32), np.array([3, 0, 699], dtype=np.int32), np.array([1.0, 2.0, 3.0]))
+    assert m.n == n0 + 700 and m.nnz == nnz0 + 3
+
+    def call(row0, n_rows, ri, cj, v, per=0):
+        ri, cj, v = (np.ascontiguousarray(a, dtype=t) for a, t in ((ri, np.int32), (cj, np.int32), (v, np.float64)))
+        return lib.ehyb_matrix_append_rows(C.byref(m.c), row0, n_rows, len(ri), ri.ctypes.data_as(C.POINTER(C.c_int)), cj.ctypes.data_as(C.POINTER(C.c_int)),
+                                           v.ctypes.data_as(C.POINTER(C.c_double)), per)
+
+    assert call(n0 - 1, 5, [0], [0], [1.0]) == 1 and b"inside the partitions" in lib.ehyb_last_error()
+    assert call(n0, 701, [0], [0], [1.0]) == 1                                    # beyond the dimension
+    assert call(n0, 10, [3, 2], [0, 0], [1.0, 1.0]) == 1                          # rows not ascending
+    assert call(n0, 10, [0], [m.n], [1.0]) == 1                                   # column out of range
+    assert m.nnz == nnz0 + 3 and int(m.c.nParts) == np0                           # nothing changed
+    ri = np.repeat(np.arange(600, dtype=np.int32), 2)
+    cj = (np.arange(1200, dtype=np.int32) * 7) % n0
+    assert call(n0, 600, ri, cj, np.ones(1200), 256) == 0
+    m.refresh() if hasattr(m, "refresh") else None
+    assert int(m.c.totalNum) == nnz0 + 3 + 1200 and int(m.c.nParts) == np0 + 3   # 256 + 256 + 88 rows
+    pb = np.ctypeslib.as_array(m.c.partBoundary, shape=(int(m.c.nParts) + 1,))
+    assert list(pb[np0:]) == [n0, n0 + 256, n0 + 512, n0 + 600]
+    rp = np.ctypeslib.as_array(m.c.rowIdx, shape=(m.n + 1,))
+    assert rp[n0 + 600] - rp[n0] == 1200 and rp[m.n] == nnz0 + 3 + 1200 and np.all(np.diff(rp[n0:n0 + 601]) == 2)
+    # a plan over own + foreign rows, row blocks split at the boundary, walked by the oracle
+    from oracle import oracle as O
+
+    plan = E.Plan(m, E.make_config(lds_doubles=1024, n_top=2, er_mode=2, prune_pct=1, fuse_er=2, direct=2, row_split=n0, er_panel_cols=256, er_block_rows=100),
+                  rows=(0, n0 + 600), upload=False)
+    st = plan.stats
+    assert st["nnz_ell"] == 0 and st["n_rows"] == n0 + 600 and st["er_partials"] > 0
+    u2 = plan.array("pb_units2").reshape(-1, 4)
+    assert not np.any((u2[:, 2] < n0) & (u2[:, 2] + np.abs(u2[:, 3]) > n0))
+    x = np.linspace(-1.0, 1.0, m.n)
+    y, w = O.walk_plan(plan, x)
+    J = np.ctypeslib.as_array(m.c.J, shape=(int(m.c.totalNum),))
+    V = np.ctypeslib.as_array(m.c.V, shape=(int(m.c.totalNum),))
+    want = np.add.reduceat(V * x[J], rp[:n0 + 600].astype(np.int64))
+    want[np.diff(rp[:n0 + 601]) == 0] = 0.0
+    assert np.allclose(np.asarray(y)[:n0 + 600], want, rtol=1e-13, atol=1e-13)
