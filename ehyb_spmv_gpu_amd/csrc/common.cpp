@@ -276,7 +276,7 @@ int ehyb_sizing(int dimension, const ehyb_config* cfg, int* nParts, int* vectorC
     // Plain storage, halo window, default sizing: a matrix of a few hundred thousand rows has fewer
     // full-size partitions than there are work items (256), so several items re-stage the same 160 KiB
     // window.  About 160 partitions are the better trade between restaging and halo columns
-    // (tools/part_rows_sweep.py, us per SpMV with 11,264-row partitions against the best size: 196 k rows
+    // (round 2 sweep, NOTEBOOK.md 2: us per SpMV with 11,264-row partitions against the best size: 196 k rows
     // 45.3 -> 30.0 at 2048 rows, 393 k rows 65.9 -> 53.2 at 2048, 943 k rows 148.5 -> 136.2 at 5632; from
     // 2.7 M rows on the full-size partitions are as good as any).
     if (c.sym_pairs != 1 && c.window_mode == EHYB_WINDOW_HALO && c.lds_doubles == EHYB_LDS_MAX_DOUBLES &&
@@ -284,7 +284,7 @@ int ehyb_sizing(int dimension, const ehyb_config* cfg, int* nParts, int* vectorC
         const int64_t want = ((int64_t)dimension / 160 + kSlabRows - 1) / kSlabRows * kSlabRows;
         cache = (int)std::min<int64_t>(cache, std::max<int64_t>(2048, want));
         // Below ~160 k rows 2048-row partitions are fewer than 80 and every one is cut into three to five work items
-        // that stage the same window: about 160 partitions of >= 768 rows there (round 3, tools/midsize_sweep.py, two
+        // that stage the same window: about 160 partitions of >= 768 rows there (round 3 sweep, profiles/r03_a_midsize_sweep.jsonl, two
         // generators: KKT 128 k rows 9.0 -> 6.6 us, FEM 120 k rows 22.0 -> 21.2 us; at 195 k rows both are as good or
         // better on the 2048-row partitions -- FEM 30.2 against 34.3 us, KKT 13.8 against 13.4 us -- which stay).
         if ((int64_t)dimension < 80 * (int64_t)cache) {

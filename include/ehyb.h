@@ -67,7 +67,7 @@ enum { EHYB_PART_AUTO = 0, EHYB_PART_CONTIGUOUS = 1, EHYB_PART_MULTILEVEL = 2, E
 #define EHYB_LDS_MAX_DOUBLES 20480   /* 160 KiB of LDS per workgroup on gfx950 */
 #define EHYB_SLAB_ROWS       64      /* one row per lane of a wave64           */
 
-/* Which shape for which size (tools/direct_crossover.py, fem3d with 3 unknowns per node, ~78 entries per
+/* Which shape for which size (round 2, NOTEBOOK.md 2: fem3d with 3 unknowns per node, ~78 entries per
  * row, microseconds per SpMV: direct / window with every entry stored / symmetric pair storage):
  *    24,576 rows   5.6 /  8.8 /  9.4        65,535 rows  14.8 / 16.5 / 13.1
  *    32,766 rows   7.2 /  9.3 /  9.7        81,918 rows  17.4 / 17.4 / 13.8
