@@ -148,11 +148,43 @@ def _setup_device(group=None):
     return torch.device("cuda", torch.cuda.current_device()) if dist.get_backend(group) == "nccl" else torch.device("cpu")
 
 
+class ThreadRanks:
+    """The ranks of a set-up as THREADS of one process (tools/rank_plans_one_gpu.py: every rank's plan of an N-rank decomposition built
+    and timed on ONE GPU, one after the other -- the box allows no more than six processes on its card, and no collective is needed to
+    time a rank's local multiply).  `ThreadRanks(world).group(rank)` stands in for a torch.distributed group in RankLocalMatrix: alltoallv
+    then goes through a mailbox and two barriers.  numpy releases the GIL in its heavy calls, libehyb.so in all of them."""
+
+    def __init__(self, world):
+        import threading
+
+        self.world = int(world)
+        self.barrier = threading.Barrier(self.world)
+        self.box = [None] * self.world
+
+    class Group:
+        def __init__(self, ranks, rank):
+            self.ranks, self.rank = ranks, int(rank)
+
+    def group(self, rank):
+        return ThreadRanks.Group(self, rank)
+
+
 def alltoallv(send, send_counts, group=None):
     """Uneven all-to-all of a 1-D numpy array with TENSOR collectives (the counts first, then the payload in one
     all_to_all_single): what the ranks tell each other while the send lists are built.  -> (received, recv_counts)"""
     if len(send_counts) == 1:      # one rank (the loop-back test of the RCCL step): what I send is what I receive
         return np.ascontiguousarray(send).copy(), np.asarray([int(send_counts[0])], dtype=np.int64)
+    if isinstance(group, ThreadRanks.Group):
+        tr, me = group.ranks, group.rank
+        send = np.ascontiguousarray(send)
+        first = np.concatenate(([0], np.cumsum([int(c) for c in send_counts])))
+        tr.box[me] = (send, first)
+        tr.barrier.wait()
+        parts = [tr.box[s][0][int(tr.box[s][1][me]):int(tr.box[s][1][me + 1])] for s in range(tr.world)]
+        out = np.concatenate(parts) if parts else send[:0]
+        counts = np.asarray([len(p) for p in parts], dtype=np.int64)
+        tr.barrier.wait()          # everybody has read the mailbox: it may be overwritten
+        return out, counts
     import torch
     import torch.distributed as dist
 
