@@ -40,8 +40,10 @@ def random_config_kwargs(rng):
                 er_block_rows=int(rng.choice([64, 1000, 8192])), direct=int(rng.choice([0, 0, 1, 2])),
                 ell_prune=int(rng.choice([1, 1, 2])),
                 # round 3: row order, how pass 1 of the panel form adds up, finds its work and is launched
-                partitioner=int(rng.choice([0, 0, 1, 4])), er_sums=int(rng.choice([1, 1, 2])), er_queue=int(rng.choice([1, 2])),
-                xcd_map=int(rng.choice([1, 2])), er_panel_threads=int(rng.choice([0, 512, 1024])), er_units1=int(rng.choice([0, 1, 7, 300])),
+                partitioner=int(rng.choice([0, 0, 1, 4])), er_sums=int(rng.choice([1, 1, 2])), er_queue=int(rng.choice([0, 1, 1, 2])),
+                # (3000 items and more: more than the resident workgroups, so that the per-XCD queues, their walk from the far end and the skip of a
+                # panel already staged really run -- round 4)
+                xcd_map=int(rng.choice([1, 2])), er_panel_threads=int(rng.choice([0, 512, 1024])), er_units1=int(rng.choice([0, 1, 7, 300, 3000, 4000])),
                 er_units2=int(rng.choice([0, 5])), graph_compress=int(rng.choice([0, 1, 2])),
                 # where the panel form is built when the plan is created and uploaded in one call (1 host, 2 device)
                 symbolic=int(rng.choice([1, 2])),
