@@ -112,6 +112,7 @@ struct ehyb_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1, device = 0;
     hipStream_t stream = nullptr;  // the exchanges run here, beside the caller's compute stream
+    hipEvent_t ev_gather[2] = {nullptr, nullptr};  // ehyb_gather_spmv: x ready / segments gathered
 };
 
 // One rank's halo exchange + multiply, everything the step needs resident: the send list, the packed send buffer, who
@@ -194,6 +195,11 @@ int ehyb_comm_create(const void* id_in, int rank, int world, ehyb_comm** out)
         delete c;
         EHYB_FAIL(EHYB_ERR_HIP, "ehyb_comm_create: hipStreamCreateWithPriority failed");
     }
+    for (auto& e : c->ev_gather)
+        if (hipEventCreateWithFlags(&e, hipEventDisableTiming) != hipSuccess) {
+            ehyb_comm_destroy(c);
+            EHYB_FAIL(EHYB_ERR_HIP, "ehyb_comm_create: hipEventCreate failed");
+        }
     *out = c;
     return EHYB_OK;
 }
@@ -205,6 +211,8 @@ void ehyb_comm_destroy(ehyb_comm* c)
         (void)hipStreamSynchronize(c->stream);
         (void)hipStreamDestroy(c->stream);
     }
+    for (auto e : c->ev_gather)
+        if (e) (void)hipEventDestroy(e);
     if (c->comm && g_rccl.handle) (void)g_rccl.CommDestroy(c->comm);
     delete c;
 }
@@ -243,15 +251,7 @@ int ehyb_gather_spmv(ehyb_comm* c, ehyb_plan* plan, double* x_dev, double* y_dev
 {
     if (!c || !plan || !x_dev || !y_dev || seg_len < 1) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_gather_spmv: bad arguments");
     hipStream_t cs = (hipStream_t)compute_stream;
-    static thread_local hipEvent_t ev[2] = {nullptr, nullptr};
-    static thread_local int ev_dev = -1;
-    if (ev_dev != c->device) {
-        for (auto& e : ev) {
-            if (e) (void)hipEventDestroy(e);
-            HIP_TRY(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-        }
-        ev_dev = c->device;
-    }
+    hipEvent_t* ev = c->ev_gather;
     HIP_TRY(hipEventRecord(ev[0], cs));              // x of this step is ready (and last step's reads of the gathered part are done)
     HIP_TRY(hipStreamWaitEvent(c->stream, ev[0], 0));
     NCCL_TRY(g_rccl.AllGather(x_dev, x_dev + seg_len, (size_t)seg_len, ncclFloat64, c->comm, c->stream));
