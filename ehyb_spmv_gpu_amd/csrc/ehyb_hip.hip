@@ -149,6 +149,10 @@ struct EllArgs {
     // what the previous launch streamed LAST is what still sits in the 256 MB Infinity Cache, and this launch reads it FIRST.
     int reverse;
     int reverse_items;  // with reverse, and more items than resident workgroups: workgroup b takes the items from the far end too
+    // diagnostic launches only (stamps != null; ehyb_debug_ell_stamps_probe): > 0 = every window entry is staged from THREE vectors instead of
+    // one (x and two shifted copies of it, `probe_n` entries long) -- what folding CG's direction update p = z + beta p into the staging
+    // would gather (r, the old p, 1 / diag): how much longer the launch gets is the price of that fold
+    int probe_n;
 };
 
 // Workgroups are handed to the 8 XCDs round robin (b mod 8).  With this map XCD k gets the k-th
@@ -282,7 +286,7 @@ __device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restr
 // SYM (symmetric pair storage): the segment is a whole partition; its rows' accumulators sit in LDS
 // right behind the x image, take the lanes' own sums and the scattered mirror products, and are
 // written to y in one coalesced sweep at the end.
-template <int THREADS, bool DYN, bool INLINE_ER, bool SYM>
+template <int THREADS, bool DYN, bool INLINE_ER, bool SYM, bool STAMP = false>
 __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict__ win, int* __restrict__ next_slab,
                                             int g, int lane, int wave, double& xy)
 {
@@ -306,8 +310,20 @@ __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict
     double* yacc = win + cnt + hn;
     // (SYM: batching all of a thread's staging loads -- indices, then x, stores last -- measured no
     // faster than these loops: 6.1 vs 6.5 us of staging; the halo gathers set the pace)
-    for (int i = threadIdx.x; i < cnt; i += THREADS) win[i] = A.x[base + i];
-    for (int i = threadIdx.x; i < hn; i += THREADS) win[cnt + i] = A.x[A.halo_cols[hb + i]];
+    if (STAMP && A.probe_n > 0) {   // (diagnostic instantiation only: compiled out of the product's kernels)
+        const int n = A.probe_n, o1 = n / 3, o2 = 2 * (n / 3);
+        for (int i = threadIdx.x; i < cnt; i += THREADS) {
+            const int c = min(base + i, n - 1);
+            win[i] = A.x[c] + 1e-300 * (A.x[(c + o1) % n] + A.x[(c + o2) % n]);
+        }
+        for (int i = threadIdx.x; i < hn; i += THREADS) {
+            const int c = A.halo_cols[hb + i];
+            win[cnt + i] = A.x[c] + 1e-300 * (A.x[(c + o1) % n] + A.x[(c + o2) % n]);
+        }
+    } else {
+        for (int i = threadIdx.x; i < cnt; i += THREADS) win[i] = A.x[base + i];
+        for (int i = threadIdx.x; i < hn; i += THREADS) win[cnt + i] = A.x[A.halo_cols[hb + i]];
+    }
     if (SYM)
         for (int i = threadIdx.x; i < cnt; i += THREADS) yacc[i] = 0.0;
     if (DYN && threadIdx.x == 0) *next_slab = sb + WAVES;  // slabs sb..sb+WAVES-1 are pre-assigned
@@ -358,7 +374,7 @@ __global__ __launch_bounds__(THREADS) __attribute__((amdgpu_waves_per_eu(SYM ? 4
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     double xy = 0.0;
     for (int sg = it.x; sg < it.y; ++sg) {
-        ell_segment<THREADS, DYN, INLINE_ER, SYM>(A, win, next_slab, sg, lane, wave, xy);
+        ell_segment<THREADS, DYN, INLINE_ER, SYM, STAMP>(A, win, next_slab, sg, lane, wave, xy);
     }
     if (A.xy_out != nullptr) {  // (wave-uniform: a kernel argument)
 #pragma unroll
@@ -793,6 +809,7 @@ __global__ __launch_bounds__(256) void ehyb_read_kernel(const double2* __restric
 static size_t ell_lds_bytes(const HostLayout& H) { return ((size_t)H.lds_doubles + 1) / 2 * 16 + 16; }
 static int ell_win_cap(const HostLayout& H) { return (H.lds_doubles + 1) / 2 * 2; }
 
+static thread_local int t_probe_n = 0;   // ehyb_debug_ell_stamps_probe: the stamped launch stages every window entry from three vectors
 static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long long* stamps, double* xy_out = nullptr)
 {
     EllArgs A;
@@ -811,6 +828,7 @@ static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long 
     A.xy_out = xy_out;
     A.reverse = 0;
     A.reverse_items = 0;
+    A.probe_n = stamps ? t_probe_n : 0;
     // on by default: plain storage 143 -> 134 us on the audikw_1-like matrix; cfg.xcd_map = 2 for the A/B
     A.xcd_map = P->host.sym ? 0 : (P->cfg.xcd_map != 2 ? 1 : 0);
     A.item_map = P->d_item_map;  // symmetric pairs: items are sorted heaviest first, dispatched in that order
@@ -1142,6 +1160,15 @@ int ehyb_measure_read_bw(size_t bytes, int iters, double* gbps)
 
 // Diagnostic (tools/stamps.py): one launch of the stamped instantiation of the ELL kernel.
 // out[4*i + {0,1,2,3}] = entry / staged / exit wall-clock ticks (100 MHz) and XCC id of item i.
+int ehyb_debug_ell_stamps(ehyb_plan* P, const double* x, double* y, unsigned long long* out_host);
+int ehyb_debug_ell_stamps_probe(ehyb_plan* P, const double* x, double* y, unsigned long long* out_host, int triple_gather)
+{
+    t_probe_n = (triple_gather && P) ? P->host.n_cols : 0;
+    const int rc = ehyb_debug_ell_stamps(P, x, y, out_host);
+    t_probe_n = 0;
+    return rc;
+}
+
 int ehyb_debug_ell_stamps(ehyb_plan* P, const double* x, double* y, unsigned long long* out_host)
 {
     if (!P || !P->uploaded || !out_host) EHYB_FAIL(EHYB_ERR_ARG, "ehyb_debug_ell_stamps: bad arguments");

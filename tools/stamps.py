@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--items", type=int, default=2)
     ap.add_argument("--variant", type=int, default=0, help="0/1 LDS slab counter, 3 static round-robin")
     ap.add_argument("--xcd-map", type=int, default=1, help="1 = every XCD takes one contiguous run of items (default), 2 = blockIdx order")
+    ap.add_argument("--triple-gather", type=int, default=0, help="1 = the stamped launch stages every window entry from THREE vectors (what folding CG's direction "
+                                                                 "update into the staging would gather): the price of that fold")
     args = ap.parse_args()
     import numpy as np
 
@@ -52,11 +54,11 @@ def main():
         plan.spmv(dx.ptr, dy.ptr)
     n_items = st["n_items"]
     out = np.zeros(n_items * 4, dtype=np.uint64)
-    fn = lib.ehyb_debug_ell_stamps
+    fn = lib.ehyb_debug_ell_stamps_probe
     fn.restype = C.c_int
-    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int]
     for rep in range(3):
-        rc = fn(plan.h, C.c_void_p(dx.ptr), C.c_void_p(dy.ptr), out.ctypes.data_as(C.c_void_p))
+        rc = fn(plan.h, C.c_void_p(dx.ptr), C.c_void_p(dy.ptr), out.ctypes.data_as(C.c_void_p), args.triple_gather)
         assert rc == 0, lib.ehyb_last_error()
     s = out.reshape(-1, 4).astype(np.int64)
     t0 = s[:, 0].min()
