@@ -118,30 +118,62 @@ void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64
             if (owner[oe.second] == g) keeps[g].push_back(oe.first);
         std::sort(keeps[g].begin(), keeps[g].end());
     }
-    // in-partition entries of every row sorted by column, to find partners
+    // The partner (j, i) of an entry (i, j) is looked for in row j by column.  Rows of a reader or a generator arrive column-sorted (mirrored
+    // symmetric files almost): those are searched in place, in J itself; a row that is not sorted gets a sorted copy of its in-partition
+    // entries (column, entry) -- round 4: building that copy for EVERY row was a quarter of this function.
+    std::vector<uint8_t> row_sorted(own, 1);
     std::vector<int> ip_ptr(own + 1, 0);
     for (int r = s; r < e; ++r) {
+        bool sorted = true;
+        for (int k = rp[r] + 1; k < rp[r + 1] && sorted; ++k) sorted = J[k - 1] <= J[k];
+        row_sorted[r - s] = sorted ? 1 : 0;
         int c = 0;
-        for (int k = rp[r]; k < rp[r + 1]; ++k) c += J[k] >= s && J[k] < e;
+        if (!sorted)
+            for (int k = rp[r]; k < rp[r + 1]; ++k) c += J[k] >= s && J[k] < e;
         ip_ptr[r - s + 1] = ip_ptr[r - s] + c;
     }
-    std::vector<std::pair<int, int>> ip(ip_ptr[own]);  // (column, entry)
+    std::vector<std::pair<int, int>> ip(ip_ptr[own]);  // (column, entry) of the unsorted rows' in-partition entries
     for (int r = s; r < e; ++r) {
+        if (row_sorted[r - s]) continue;
         int q = ip_ptr[r - s];
         for (int k = rp[r]; k < rp[r + 1]; ++k)
             if (J[k] >= s && J[k] < e) ip[q++] = {J[k], k};
-        // (rows of a reader or generator arrive column-sorted, mirrored symmetric files almost: test first)
-        if (!std::is_sorted(ip.begin() + ip_ptr[r - s], ip.begin() + ip_ptr[r - s + 1])) std::sort(ip.begin() + ip_ptr[r - s], ip.begin() + ip_ptr[r - s + 1]);
+        std::sort(ip.begin() + ip_ptr[r - s], ip.begin() + ip_ptr[r - s + 1]);
     }
+    // (the groups whose pairs the current row's group keeps are MARKED -- a look-up instead of a search per entry --, and every row j remembers
+    // where the partner of the previous row was found: the rows of a group are consecutive, so the next one's sits right behind it)
+    std::vector<int> mark(G, -1), cursor(own, -1);
+    int marked = -1;
     for (int i = s; i < e; ++i) {
         const int g = grp[i - s];
         if (keeps[g].empty()) continue;
+        if (marked != g) {
+            for (int h : keeps[g]) mark[h] = g;
+            marked = g;
+        }
         for (int k = rp[i]; k < rp[i + 1]; ++k) {
             const int j = J[k];
             if (j < s || j >= e || state[k - k0] != 0) continue;
             const int h = grp[j - s];
-            if (h == g || !std::binary_search(keeps[g].begin(), keeps[g].end(), h)) continue;
-            // the partner (j, i): first unclaimed entry of row j in column i with the same value
+            if (h == g || mark[h] != g) continue;
+            // the partner (j, i): first unclaimed entry of row j in column i with the same value (entries of one column in stored order)
+            if (row_sorted[j - s]) {
+                const int* jb = J + rp[j];
+                const int* je = J + rp[j + 1];
+                const int* lo = jb + (cursor[j - s] + 1);   // right behind the partner of row i - 1, if that is where column i starts
+                if (!(cursor[j - s] >= 0 && lo < je && *lo == i && lo[-1] < i)) lo = std::lower_bound(jb, je, i);
+                if (lo != je && *lo == i) cursor[j - s] = (int)(lo - jb);
+                for (; lo != je && *lo == i; ++lo) {
+                    const int64_t kp = lo - J;
+                    if (state[kp - k0] == 0 && V[kp] == V[k]) {
+                        state[k - k0] = 1;
+                        state[kp - k0] = 2;
+                        if (partner) partner[k - k0] = (int32_t)kp;
+                        break;
+                    }
+                }
+                continue;
+            }
             auto lo = std::lower_bound(ip.begin() + ip_ptr[j - s], ip.begin() + ip_ptr[j - s + 1], std::make_pair(i, -1));
             for (; lo != ip.begin() + ip_ptr[j - s + 1] && lo->first == i; ++lo)
                 if (state[lo->second - k0] == 0 && V[lo->second] == V[k]) {
