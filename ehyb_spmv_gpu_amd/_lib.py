@@ -78,7 +78,8 @@ class Config(C.Structure):
         ("cg_fused_dot", C.c_int32),
         ("ell_alternate", C.c_int32),
         ("row_split", C.c_int32),
-        ("reserved", C.c_int32 * 24),
+        ("col_map", C.c_int32),
+        ("reserved", C.c_int32 * 23),
     ]
 
 

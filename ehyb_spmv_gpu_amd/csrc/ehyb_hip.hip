@@ -1019,8 +1019,8 @@ static int launch_er(ehyb_plan* P, const double* x, double* y, hipStream_t st)
 // the entries.  Multi-GPU plans keep the phases apart (phase 1 reads only the rank's x segment).
 static bool fuse_residual(const ehyb_plan* P) { return P->host.inline_er; }
 
-template <class T>
-static int upload(T** dst, const std::vector<T>& src)
+template <class T, class A>
+static int upload(T** dst, const std::vector<T, A>& src)
 {
     *dst = nullptr;
     size_t bytes = std::max<size_t>(src.size(), 1) * sizeof(T) + 4096;  // slack: clamped prefetches

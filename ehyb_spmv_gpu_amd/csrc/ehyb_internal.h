@@ -7,11 +7,37 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <memory>
 #include <string>
+#include <utility>
 #include <vector>
 #include "ehyb.h"
 
 namespace ehyb {
+
+// The big arrays of a layout (hundreds of MB each): a vector whose resize() does NOT write the new elements -- the builder
+// fills every element itself, partition by partition on all host threads; a value-initialising resize was one more pass
+// over the array on ONE thread (audikw_1-like: 1.2 GB of such fills, a quarter of the plan's build time).
+template <class T>
+struct NoInitAlloc : std::allocator<T> {
+    template <class U>
+    struct rebind {
+        using other = NoInitAlloc<U>;
+    };
+    NoInitAlloc() = default;
+    template <class U>
+    NoInitAlloc(const NoInitAlloc<U>&) {}
+    template <class U, class... A>
+    void construct(U* p, A&&... a)
+    {
+        if constexpr (sizeof...(A) == 0)
+            ::new ((void*)p) U;  // default-initialised: left as it is for arithmetic types
+        else
+            ::new ((void*)p) U(std::forward<A>(a)...);
+    }
+};
+template <class T>
+using BigVec = std::vector<T, NoInitAlloc<T>>;
 
 // ---------------------------------------------------------------- errors
 void set_error(const char* fmt, ...);
@@ -67,6 +93,7 @@ struct Config {
     int cg_fused_dot;       // 1 on (default), 2 off
     int ell_alternate;      // 0 automatic (streams that do not fit the Infinity Cache), 1 on, 2 off
     int row_split;          // panel form: no row block of pass 2 straddles this row (0 = none)
+    int col_map;            // host builder: 1 per-thread column look-up arrays where they fit (default), 2 sorted lists + binary search
 };
 Config resolve_config(const ehyb_config* cfg);
 
@@ -98,8 +125,8 @@ struct HostLayout {
     // ELL payload: element (pair p, lane l, half h) at ((pair_ptr[s]+p)*64 + l)*2 + h
     // Column indices are stored once per *group* of lanes with identical column lists:
     // word (pair p, group g) at slab_col_ptr[s] + p*G_s + g holds two 16-bit window-local columns.
-    std::vector<double> ell_val;
-    std::vector<uint32_t> ell_col;
+    BigVec<double> ell_val;
+    BigVec<uint32_t> ell_col;
     std::vector<uint32_t> slab_col_ptr;  // [n_slabs+1] prefix of pairs*groups
     std::vector<uint8_t> lane_group;     // [n_slabs*64]
     std::vector<uint32_t> slab_meta;     // [n_slabs*4] {pair_ptr, col_ptr, first row, pairs<<16 | er_pairs<<8 | groups-1}
@@ -159,8 +186,8 @@ struct HostLayout {
     std::vector<uint32_t> pb_jump;    // per jump: slot - pieces before it in its chunk
 
     // slot maps (cfg.value_map): entry of the source matrix every slot of a value stream was filled from, -1 = padding
-    std::vector<int32_t> ell_src;     // like ell_val
-    std::vector<int32_t> ell_src2;    // like ell_val, sym only: the mirror entry the slot also stands for, else -1
+    BigVec<int32_t> ell_src;          // like ell_val
+    BigVec<int32_t> ell_src2;            // like ell_val, sym only: the mirror entry the slot also stands for, else -1
     std::vector<int32_t> er_src;      // like er_val
     std::vector<int32_t> pb_src;      // like pb_val
     int64_t src_entries = 0;          // entries of the source matrix (length ehyb_plan_set_values expects)
@@ -232,8 +259,8 @@ int mtmetis_partition(int n, const int64_t* xadj, const int* adjncy, int nparts,
 // ---------------------------------------------------------------- misc
 double wall_seconds();
 void prefault(void* p, size_t bytes);  // fresh pages of an array about to be filled, mapped in one sweep instead of a trap per page
-template <class T>
-inline void prefault_vector(std::vector<T>& v, size_t n)  // reserve + prefault: the resize / push_backs that follow touch mapped pages
+template <class T, class A>
+inline void prefault_vector(std::vector<T, A>& v, size_t n)  // reserve + prefault: the resize / push_backs that follow touch mapped pages
 {
     v.reserve(n);
     prefault((void*)v.data(), n * sizeof(T));

@@ -62,12 +62,20 @@ inline int halo_lookup(const std::vector<int32_t>& halo, int col)
 //   * Entries inside a group (the diagonal blocks) stay as they are.
 // state is indexed by entry number minus k0.
 // partner (may be null): for every kept entry (state 1) the entry it also stands for, indexed like state.
-void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64_t k0, uint8_t* state, int32_t* partner)
+// (Everything lives in flat arrays that a host thread keeps from one partition to the next: one vector per group, and fresh megabyte
+// arrays per partition -- mmap, page faults, munmap -- made this function spend more time in the allocator than in its loops.)
+struct OrientScratch {
+    std::vector<int> grp, gfirst, nb_ptr, nb, seen, inc_ptr, inc_to, inc_id, fill_at, owner, left, at, cptr, crow, cent, cfill, mark, hint;
+    std::vector<uint8_t> mutual;
+};
+void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64_t k0, uint8_t* state, int32_t* partner, OrientScratch& W)
 {
     const int own = e - s;
     const int* J = m->J;
     const double* V = m->V;
-    std::vector<int> grp(own), gfirst;
+    std::vector<int>&grp = W.grp, &gfirst = W.gfirst;
+    grp.resize(own);
+    gfirst.clear();
     for (int r = s; r < e; ++r) {
         const int len = rp[r + 1] - rp[r];
         const bool same = r > s && len == rp[r] - rp[r - 1] && (len == 0 || memcmp(J + rp[r], J + rp[r - 1], sizeof(int) * (size_t)len) == 0);
@@ -75,33 +83,57 @@ void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64
         grp[r - s] = (int)gfirst.size() - 1;
     }
     const int G = (int)gfirst.size();
-    // neighbour groups of every group (from its first row), sorted
-    std::vector<std::vector<int>> nb(G);
+    // neighbour groups of every group (from its first row), each list sorted and without repeats
+    std::vector<int>&nb_ptr = W.nb_ptr, &nb = W.nb, &seen = W.seen;
+    nb_ptr.assign(G + 1, 0);
+    nb.clear();
+    seen.assign(G, -1);
     for (int g = 0; g < G; ++g) {
         const int r = gfirst[g];
-        for (int k = rp[r]; k < rp[r + 1]; ++k)
-            if (J[k] >= s && J[k] < e && grp[J[k] - s] != g) nb[g].push_back(grp[J[k] - s]);
-        std::sort(nb[g].begin(), nb[g].end());
-        nb[g].erase(std::unique(nb[g].begin(), nb[g].end()), nb[g].end());
+        for (int k = rp[r]; k < rp[r + 1]; ++k) {
+            if (J[k] < s || J[k] >= e) continue;
+            const int h = grp[J[k] - s];
+            if (h == g || seen[h] == g) continue;
+            seen[h] = g;
+            nb.push_back(h);
+        }
+        std::sort(nb.begin() + nb_ptr[g], nb.end());
+        nb_ptr[g + 1] = (int)nb.size();
     }
-    // edges = pairs that see each other; incidence lists (other end, edge)
-    std::vector<std::vector<std::pair<int, int>>> inc(G);
-    int n_edges = 0;
+    auto sees = [&](int h, int g) { return std::binary_search(nb.begin() + nb_ptr[h], nb.begin() + nb_ptr[h + 1], g); };
+    // edges = pairs of groups that see each other, numbered in the order (lower group, higher group); incidence lists
+    // (other end, edge) sorted by the other end
+    std::vector<int>&inc_ptr = W.inc_ptr, &inc_to = W.inc_to, &inc_id = W.inc_id, &fill_at = W.fill_at;
+    std::vector<uint8_t>& mutual = W.mutual;  // per neighbour entry (g, h) with h > g: h sees g as well
+    inc_ptr.assign(G + 1, 0);
+    mutual.assign(nb.size(), 0);
     for (int g = 0; g < G; ++g)
-        for (int h : nb[g])
-            if (h > g && std::binary_search(nb[h].begin(), nb[h].end(), g)) {
-                inc[g].push_back({h, n_edges});
-                inc[h].push_back({g, n_edges});
+        for (int q = nb_ptr[g]; q < nb_ptr[g + 1]; ++q)
+            if (nb[q] > g && sees(nb[q], g)) mutual[q] = 1, ++inc_ptr[g + 1], ++inc_ptr[nb[q] + 1];
+    for (int g = 0; g < G; ++g) inc_ptr[g + 1] += inc_ptr[g];
+    inc_to.resize(inc_ptr[G]);
+    inc_id.resize(inc_ptr[G]);
+    fill_at.assign(inc_ptr.begin(), inc_ptr.end() - 1);
+    int n_edges = 0;
+    for (int g = 0; g < G; ++g)  // (ascending g: the lower neighbours of a group are in place before its own higher ones)
+        for (int q = nb_ptr[g]; q < nb_ptr[g + 1]; ++q) {
+            const int h = nb[q];
+            if (mutual[q]) {
+                inc_to[fill_at[g]] = h, inc_id[fill_at[g]++] = n_edges;
+                inc_to[fill_at[h]] = g, inc_id[fill_at[h]++] = n_edges;
                 ++n_edges;
             }
-    std::vector<int> owner(n_edges, -1), left(G);
-    std::vector<size_t> at(G, 0);
-    for (int g = 0; g < G; ++g) left[g] = (int)inc[g].size();
+        }
+    std::vector<int>&owner = W.owner, &left = W.left, &at = W.at;
+    owner.assign(n_edges, -1);
+    left.resize(G);
+    at.assign(inc_ptr.begin(), inc_ptr.end() - 1);
+    for (int g = 0; g < G; ++g) left[g] = inc_ptr[g + 1] - inc_ptr[g];
     auto walk = [&](int v) {
         for (;;) {
-            while (at[v] < inc[v].size() && owner[inc[v][at[v]].second] >= 0) ++at[v];
-            if (at[v] == inc[v].size()) return;
-            const int u = inc[v][at[v]].first, id = inc[v][at[v]].second;
+            while (at[v] < inc_ptr[v + 1] && owner[inc_id[at[v]]] >= 0) ++at[v];
+            if (at[v] == inc_ptr[v + 1]) return;
+            const int u = inc_to[at[v]], id = inc_id[at[v]];
             owner[id] = v;
             --left[v];
             --left[u];
@@ -112,76 +144,59 @@ void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64
         if (left[g] & 1) walk(g);  // open trails first: they start and end at odd vertices
     for (int g = 0; g < G; ++g)
         while (left[g] > 0) walk(g);  // what is left is Eulerian: closed trails
-    std::vector<std::vector<int>> keeps(G);  // groups whose pairs group g keeps, sorted
-    for (int g = 0; g < G; ++g) {
-        for (const auto& oe : inc[g])
-            if (owner[oe.second] == g) keeps[g].push_back(oe.first);
-        std::sort(keeps[g].begin(), keeps[g].end());
-    }
-    // The partner (j, i) of an entry (i, j) is looked for in row j by column.  Rows of a reader or a generator arrive column-sorted (mirrored
-    // symmetric files almost): those are searched in place, in J itself; a row that is not sorted gets a sorted copy of its in-partition
-    // entries (column, entry) -- round 4: building that copy for EVERY row was a quarter of this function.
-    std::vector<uint8_t> row_sorted(own, 1);
-    std::vector<int> ip_ptr(own + 1, 0);
-    for (int r = s; r < e; ++r) {
-        bool sorted = true;
-        for (int k = rp[r] + 1; k < rp[r + 1] && sorted; ++k) sorted = J[k - 1] <= J[k];
-        row_sorted[r - s] = sorted ? 1 : 0;
-        int c = 0;
-        if (!sorted)
-            for (int k = rp[r]; k < rp[r + 1]; ++k) c += J[k] >= s && J[k] < e;
-        ip_ptr[r - s + 1] = ip_ptr[r - s] + c;
-    }
-    std::vector<std::pair<int, int>> ip(ip_ptr[own]);  // (column, entry) of the unsorted rows' in-partition entries
-    for (int r = s; r < e; ++r) {
-        if (row_sorted[r - s]) continue;
-        int q = ip_ptr[r - s];
+    // The partner (j, i) of an entry (i, j) is looked for by COLUMN: the in-partition entries of the partition dealt out by column, rows
+    // ascending inside a column (entries of one row and column in stored order).  All partners of row i then sit in one short contiguous
+    // list -- until round 4 every one of them was searched for in a different row, after a sort of every row's entries by column (the rows of
+    // a permuted matrix are not column-sorted): three quarters of this function.
+    std::vector<int>&cptr = W.cptr, &crow = W.crow, &cent = W.cent, &cfill = W.cfill;
+    cptr.assign(own + 1, 0);
+    for (int64_t k = rp[s]; k < rp[e]; ++k)
+        if (J[k] >= s && J[k] < e) ++cptr[J[k] - s + 1];
+    for (int c = 0; c < own; ++c) cptr[c + 1] += cptr[c];
+    crow.resize(cptr[own]);
+    cent.resize(cptr[own]);
+    cfill.assign(cptr.begin(), cptr.end() - 1);
+    for (int r = s; r < e; ++r)
         for (int k = rp[r]; k < rp[r + 1]; ++k)
-            if (J[k] >= s && J[k] < e) ip[q++] = {J[k], k};
-        std::sort(ip.begin() + ip_ptr[r - s], ip.begin() + ip_ptr[r - s + 1]);
-    }
-    // (the groups whose pairs the current row's group keeps are MARKED -- a look-up instead of a search per entry --, and every row j remembers
-    // where the partner of the previous row was found: the rows of a group are consecutive, so the next one's sits right behind it)
-    std::vector<int> mark(G, -1), cursor(own, -1);
+            if (J[k] >= s && J[k] < e) {
+                const int q = cfill[J[k] - s]++;
+                crow[q] = r;
+                cent[q] = k;
+            }
+    // (the groups whose pairs the current row's group keeps are MARKED: a look-up instead of a search per entry)
+    // and the rows of a group have one column list: entry t of the row above had its partner at hint[t] of that row's column -- with a
+    // symmetric pattern the same place in this row's column, checked before any search)
+    std::vector<int>&mark = W.mark, &hint = W.hint;
+    mark.assign(G, -1);
     int marked = -1;
     for (int i = s; i < e; ++i) {
         const int g = grp[i - s];
-        if (keeps[g].empty()) continue;
         if (marked != g) {
-            for (int h : keeps[g]) mark[h] = g;
+            for (int q = inc_ptr[g]; q < inc_ptr[g + 1]; ++q)
+                if (owner[inc_id[q]] == g) mark[inc_to[q]] = g;
             marked = g;
         }
+        const int* cb = crow.data() + cptr[i - s];
+        const int* ce = crow.data() + cptr[i - s + 1];
+        if (hint.size() < (size_t)(rp[i + 1] - rp[i])) hint.resize((size_t)(rp[i + 1] - rp[i]), 0);
         for (int k = rp[i]; k < rp[i + 1]; ++k) {
             const int j = J[k];
             if (j < s || j >= e || state[k - k0] != 0) continue;
             const int h = grp[j - s];
             if (h == g || mark[h] != g) continue;
-            // the partner (j, i): first unclaimed entry of row j in column i with the same value (entries of one column in stored order)
-            if (row_sorted[j - s]) {
-                const int* jb = J + rp[j];
-                const int* je = J + rp[j + 1];
-                const int* lo = jb + (cursor[j - s] + 1);   // right behind the partner of row i - 1, if that is where column i starts
-                if (!(cursor[j - s] >= 0 && lo < je && *lo == i && lo[-1] < i)) lo = std::lower_bound(jb, je, i);
-                if (lo != je && *lo == i) cursor[j - s] = (int)(lo - jb);
-                for (; lo != je && *lo == i; ++lo) {
-                    const int64_t kp = lo - J;
-                    if (state[kp - k0] == 0 && V[kp] == V[k]) {
-                        state[k - k0] = 1;
-                        state[kp - k0] = 2;
-                        if (partner) partner[k - k0] = (int32_t)kp;
-                        break;
-                    }
-                }
-                continue;
-            }
-            auto lo = std::lower_bound(ip.begin() + ip_ptr[j - s], ip.begin() + ip_ptr[j - s + 1], std::make_pair(i, -1));
-            for (; lo != ip.begin() + ip_ptr[j - s + 1] && lo->first == i; ++lo)
-                if (state[lo->second - k0] == 0 && V[lo->second] == V[k]) {
+            // the partner (j, i): first unclaimed entry of row j in column i with the same value
+            const int* lo = cb + hint[k - rp[i]];
+            if (!(lo < ce && *lo == j && (lo == cb || lo[-1] != j))) lo = std::lower_bound(cb, ce, j);
+            hint[k - rp[i]] = (int)(lo - cb);
+            for (; lo != ce && *lo == j; ++lo) {
+                const int64_t kp = cent[lo - crow.data()];
+                if (state[kp - k0] == 0 && V[kp] == V[k]) {
                     state[k - k0] = 1;
-                    state[lo->second - k0] = 2;
-                    if (partner) partner[k - k0] = (int32_t)lo->second;
+                    state[kp - k0] = 2;
+                    if (partner) partner[k - k0] = (int32_t)kp;
                     break;
                 }
+            }
         }
     }
 }
@@ -284,23 +299,31 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     lap("partitions");
     // ---- symmetric pair storage (cfg.sym_pairs): which entries carry their partner, which are dropped
     const int64_t k0 = rp[row_begin];
-    std::vector<uint8_t> state;       // per entry: 0 as it is, 1 kept + scatter, 2 dropped
+    BigVec<uint8_t> state;            // per entry: 0 as it is, 1 kept + scatter, 2 dropped
     std::vector<int32_t> dropped;     // per row
-    std::vector<int32_t> partner;     // per kept entry: the dropped entry it also stands for (value map only)
+    BigVec<int32_t> partner;          // per kept entry (state 1 only): the dropped entry it also stands for (value map only)
     const bool vmap = cfg.value_map == 1;
+    int64_t sym_kept = 0;
     if (sym) {
+        // (neither array is written here: every partition zeroes its own stretch of `state` on its own thread, and `partner` is
+        // read for kept entries only, which always have one)
         prefault_vector(state, (size_t)(rp[row_end] - k0));
-        state.assign((size_t)(rp[row_end] - k0), 0);
+        state.resize((size_t)(rp[row_end] - k0));
         if (vmap) prefault_vector(partner, state.size());
-        if (vmap) partner.assign(state.size(), -1);
+        if (vmap) partner.resize(state.size());
         dropped.assign(nrows, 0);
-#pragma omp parallel for schedule(dynamic, 2)
-        for (int p = 0; p < np; ++p) {
-            sym_orient_partition(m, rp, pb[p], pb[p + 1], k0, state.data(), vmap ? partner.data() : nullptr);
-            for (int r = pb[p]; r < pb[p + 1]; ++r) {
-                int d = 0;
-                for (int k = rp[r]; k < rp[r + 1]; ++k) d += state[k - k0] == 2;
-                dropped[r - row_begin] = d;
+#pragma omp parallel reduction(+ : sym_kept)
+        {
+            OrientScratch scratch;
+#pragma omp for schedule(dynamic, 2)
+            for (int p = 0; p < np; ++p) {
+                memset(state.data() + (rp[pb[p]] - k0), 0, (size_t)(rp[pb[p + 1]] - rp[pb[p]]));
+                sym_orient_partition(m, rp, pb[p], pb[p + 1], k0, state.data(), vmap ? partner.data() : nullptr, scratch);
+                for (int r = pb[p]; r < pb[p + 1]; ++r) {
+                    int d = 0;
+                    for (int k = rp[r]; k < rp[r + 1]; ++k) d += state[k - k0] == 2, sym_kept += state[k - k0] == 1;
+                    dropped[r - row_begin] = d;
+                }
             }
         }
     }
@@ -326,16 +349,23 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         for (uint8_t f : *part_to_er) any_windowless |= f != 0;
     const bool assign_mode = any_windowless && !direct && cfg.er_mode != 1;
     int bad_col = 0, bad_row = 0;
+    // cfg.col_map: every host thread keeps ONE array over the columns -- first the count of a partition's outside columns (which of them
+    // the window takes), then the mark of the chosen ones -- and puts back what it touched.  Sorting the candidates of every partition
+    // and a binary search per outside entry in both passes were a third of the build (audikw_1-like: 60 k candidates, 3,200 chosen, per
+    // partition).  The lists below stay for inputs whose column arrays would not fit.
+    const bool col_map = halo_mode && cfg.col_map != 2 && (int64_t)n * 4 * omp_get_max_threads() <= (int64_t(2) << 30);
 #pragma omp parallel
     {
         std::vector<int32_t> cand;
         std::vector<std::pair<int32_t, int32_t>> uniq;  // (count, col)
-        std::vector<int32_t> dense;                       // by column, hub partitions only
+        std::vector<int32_t> dense;                       // by column, hub partitions only (without col_map)
+        std::vector<int32_t> cmap;                        // by column, every partition (col_map): all zero between partitions
 #pragma omp for schedule(dynamic, 4)
         for (int p = 0; p < np; ++p) {
             const int s = pb[p], e = pb[p + 1];
             const int own = e - s;
             std::vector<int32_t>().swap(dense);
+            if (col_map && cmap.empty()) cmap.assign((size_t)n, 0);
             int wlen;
             PartScratch& S = ps[p];
             const bool whole_to_er = part_to_er && (size_t)p < part_to_er->size() && (*part_to_er)[p] != 0 && !sym;
@@ -358,11 +388,26 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                         }
                         if (j >= s && j < e) continue;
                         if (cfg.n_top > 1 && (j < local_lo || j >= local_hi)) continue;  // remote column
-                        cand.push_back(j);
+                        if (!col_map)
+                            cand.push_back(j);
+                        else if (cmap[(size_t)j]++ == 0)
+                            cand.push_back(j);  // (col_map: every candidate once, its count in the array)
                     }
+                if (col_map) {
+                    if (hcap > 0 && !cand.empty()) {
+                        std::sort(cand.begin(), cand.end());
+                        uniq.resize(cand.size());
+                        for (size_t a = 0; a < cand.size(); ++a) uniq[a] = {cmap[(size_t)cand[a]], cand[a]};
+                    } else {
+                        uniq.clear();
+                    }
+                    for (int32_t j : cand) cmap[(size_t)j] = 0;
+                }
                 if (hcap > 0 && !cand.empty()) {
-                    uniq.clear();
-                    if (cand.size() > (size_t)n / 4) {
+                    if (!col_map) uniq.clear();
+                    if (col_map) {
+                        // (counted above)
+                    } else if (cand.size() > (size_t)n / 4) {
                         // a hub partition (millions of candidates): counted in a dense array instead of sorted -- the same
                         // (count, column) list, columns ascending (R-MAT 2^24: 25 M candidates, 2 s of sort on one thread)
                         dense.assign((size_t)n, 0);
@@ -395,6 +440,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                     // (the count below asks 25 M times whether a column was chosen: flags in the same array, where it exists)
                     if (!dense.empty())
                         for (int32_t j : S.halo) dense[(size_t)j] = 1;
+                    if (col_map)
+                        for (int32_t j : S.halo) cmap[(size_t)j] = 1;
                 }
             }
             L->win_len[p] = wlen;
@@ -413,7 +460,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                     if (sym && state[k - k0] == 2) continue;  // its partner carries it
                     if (j >= s && j < s + wlen)
                         ++c;
-                    else if (halo_mode && !S.halo.empty() && (dense.empty() ? halo_lookup(S.halo, j) >= 0 : dense[(size_t)j] != 0))
+                    else if (halo_mode && !S.halo.empty() &&
+                             (col_map ? cmap[(size_t)j] != 0 : dense.empty() ? halo_lookup(S.halo, j) >= 0 : dense[(size_t)j] != 0))
                         ++c;
                 }
                 // A slab is walked by ONE wave, four pairs per memory round trip: a slab of rows with
@@ -427,6 +475,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 }
                 cnt_ell[r - row_begin] = c;
             }
+            if (col_map)
+                for (int32_t j : S.halo) cmap[(size_t)j] = 0;
             // Lane order.  Normally slot t of the partition is row s + t.  With symmetric pairs the
             // lanes add their sums into the LDS accumulators by row index, so the rows of a
             // partition may sit in the slabs in any order: longest stored row first, which makes
@@ -542,10 +592,8 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
         for (int r = pb[p]; r < pb[p + 1]; ++r) L->part_nnz_ell[p] += cnt_ell[r - row_begin];
     const int64_t nnz = (int64_t)rp[row_end] - rp[row_begin];
     const int64_t nnz_ell = nnz - nnz_er;  // entries the ELL part stands for (a kept pair entry counts twice)
-    int64_t stored_ell = 0, sym_kept = 0;
+    int64_t stored_ell = 0;
     for (int r = 0; r < nrows; ++r) stored_ell += cnt_ell[r];
-    if (sym)
-        for (uint8_t st8 : state) sym_kept += st8 == 1;
 
     lap("pass 1 (windows, widths)");
     // ---- inline form of a tiny residual.  The residual entries of a slab's rows are stored as
@@ -654,9 +702,10 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
 
     lap("inline form + prefix sums");
     // ---- pass 3: fill
-    prefault_vector(L->ell_val, (size_t)size_stream), prefault_vector(L->ell_col, (size_t)col_words);   // (fresh pages in one sweep: common.cpp)
-    L->ell_val.assign((size_t)size_stream, 0.0);
-    L->ell_col.assign((size_t)col_words, 0);
+    // (fresh pages in one sweep: common.cpp; resize() of these does not write -- every partition clears its own stretch below)
+    prefault_vector(L->ell_val, (size_t)size_stream), prefault_vector(L->ell_col, (size_t)col_words);
+    L->ell_val.resize((size_t)size_stream);
+    L->ell_col.resize((size_t)col_words);
     L->lane_group.assign((size_t)nslabs * kSlabRows, 0);
     // symmetric pairs: which row (place in the partition's LDS image) a lane works on; 0xFFFF = none
     L->slab_lrow.assign(sym ? (size_t)nslabs * kSlabRows : 0, (uint16_t)0xFFFF);
@@ -667,17 +716,32 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     std::vector<int32_t> tsrc(vmap && !view_m ? (size_t)nnz_er : 0);
     if (vmap) prefault_vector(L->ell_src, (size_t)size_stream);
     if (vmap && sym) prefault_vector(L->ell_src2, (size_t)size_stream);
-    L->ell_src.assign(vmap ? (size_t)size_stream : 0, -1);
-    L->ell_src2.assign(vmap && sym ? (size_t)size_stream : 0, -1);
+    L->ell_src.resize(vmap ? (size_t)size_stream : 0);
+    L->ell_src2.resize(vmap && sym ? (size_t)size_stream : 0);
     L->er_src.clear();
     L->pb_src.clear();
     L->src_entries = m->totalNum;
     int overflow = 0;
-#pragma omp parallel for schedule(dynamic, 4)
+#pragma omp parallel
+    {
+    std::vector<int32_t> hmap;  // cfg.col_map: place + 1 of every outside column of the current partition's window, else 0
+#pragma omp for schedule(dynamic, 4)
     for (int p = 0; p < np; ++p) {
         const int s = pb[p], e = pb[p + 1];
         const int wlen = L->win_len[p];
         const PartScratch& S = ps[p];
+        if (col_map && !S.halo.empty()) {
+            if (hmap.empty()) hmap.assign((size_t)n, 0);
+            for (size_t a = 0; a < S.halo.size(); ++a) hmap[(size_t)S.halo[a]] = (int32_t)a + 1;
+        }
+        {
+            const size_t v0 = (size_t)L->slab_pair_ptr[slab_base[p]] * 2 * kSlabRows, v1 = (size_t)L->slab_pair_ptr[slab_base[p + 1]] * 2 * kSlabRows;
+            const size_t c0 = L->slab_col_ptr[slab_base[p]], c1 = L->slab_col_ptr[slab_base[p + 1]];
+            std::fill(L->ell_val.begin() + v0, L->ell_val.begin() + v1, 0.0);
+            std::fill(L->ell_col.begin() + c0, L->ell_col.begin() + c1, 0u);
+            if (vmap) std::fill(L->ell_src.begin() + v0, L->ell_src.begin() + v1, -1);
+            if (vmap && sym) std::fill(L->ell_src2.begin() + v0, L->ell_src2.begin() + v1, -1);
+        }
         int gid = 0;
         for (int t = 0; t < e - s; ++t) {
             const int r = row_at[s - row_begin + t];
@@ -709,7 +773,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 else if (j >= s && j < s + wlen)
                     local = j - (s & ~1);
                 else if (halo_mode && !S.halo.empty()) {
-                    int h = halo_lookup(S.halo, j);
+                    const int h = col_map ? hmap[(size_t)j] - 1 : halo_lookup(S.halo, j);
                     if (h >= 0) local = (s & 1) + wlen + h;
                 }
                 if (local >= 0) {
@@ -772,6 +836,9 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 }
             }
         }
+        if (col_map)
+            for (int32_t j : S.halo) hmap[(size_t)j] = 0;
+    }
     }
     if (overflow) EHYB_FAIL(EHYB_ERR_INTERNAL, "build_layout: entry counts changed between passes");
 

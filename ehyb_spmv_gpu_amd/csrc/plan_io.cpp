@@ -39,14 +39,14 @@ bool get(FILE* f, T& v)
 {
     return fread(&v, sizeof(T), 1, f) == 1;
 }
-template <class T>
-bool put_vec(FILE* f, const std::vector<T>& v)
+template <class T, class A>
+bool put_vec(FILE* f, const std::vector<T, A>& v)
 {
     const uint64_t n = v.size();
     return put(f, n) && (n == 0 || fwrite(v.data(), sizeof(T), n, f) == n);
 }
-template <class T>
-bool get_vec(FILE* f, std::vector<T>& v, uint64_t limit)
+template <class T, class A>
+bool get_vec(FILE* f, std::vector<T, A>& v, uint64_t limit)
 {
     uint64_t n = 0;
     if (!get(f, n) || n > limit) return false;

@@ -134,12 +134,23 @@ static int partition_compressed(const matrixCOO* m, const std::vector<int64_t>& 
     const int n = m->dimension;
     const int* rp = m->rowIdx;
     *used = false;
+    // (no adjacency built -- ehyb_matrix_reorder_blocks leaves it out where this function is tried first: with a symmetric pattern the
+    // neighbours of a row are its columns, and the diagonal falls out below as "same group")
+    const bool from_rows = adj.empty();
+    const int* nbr = from_rows ? m->J : adj.data();
+    auto nb_begin = [&](int r) { return from_rows ? (int64_t)rp[r] : xadj[(size_t)r]; };
+    auto nb_end = [&](int r) { return from_rows ? (int64_t)rp[r + 1] : xadj[(size_t)r + 1]; };
     std::vector<int> group(n);
     std::vector<int> first;  // first row of every group
+    std::vector<uint8_t> same(n, 0);  // the row has the column list of the row above it
+#pragma omp parallel for schedule(static, 4096)
+    for (int v = 1; v < n; ++v) {
+        const int len = rp[v + 1] - rp[v];
+        same[v] = len > 0 && len == rp[v] - rp[v - 1] && memcmp(m->J + rp[v], m->J + rp[v - 1], sizeof(int) * (size_t)len) == 0;
+    }
     int run = 0;
     for (int v = 0; v < n; ++v) {
-        const int len = rp[v + 1] - rp[v];
-        const bool twin = v > 0 && run < 16 && len > 0 && len == rp[v] - rp[v - 1] && memcmp(m->J + rp[v], m->J + rp[v - 1], sizeof(int) * (size_t)len) == 0;
+        const bool twin = v > 0 && run < 16 && same[v];
         if (!twin) {
             first.push_back(v);
             run = 0;
@@ -159,8 +170,8 @@ static int partition_compressed(const matrixCOO* m, const std::vector<int64_t>& 
         for (int g = 0; g < ng; ++g) {
             const int r = first[g];
             int64_t deg = 0;
-            for (int64_t e = xadj[r]; e < xadj[r + 1]; ++e) {
-                const int h = group[adj[e]];
+            for (int64_t e = nb_begin(r); e < nb_end(r); ++e) {
+                const int h = group[nbr[e]];
                 if (h != g && seen[h] != g) {
                     seen[h] = g;
                     ++deg;
@@ -178,8 +189,8 @@ static int partition_compressed(const matrixCOO* m, const std::vector<int64_t>& 
         for (int g = 0; g < ng; ++g) {
             const int r = first[g];
             int64_t at = cx[g];
-            for (int64_t e = xadj[r]; e < xadj[r + 1]; ++e) {
-                const int h = group[adj[e]];
+            for (int64_t e = nb_begin(r); e < nb_end(r); ++e) {
+                const int h = group[nbr[e]];
                 if (h != g && seen[h] != g) {
                     seen[h] = g;
                     ca[(size_t)at++] = h;
@@ -187,7 +198,7 @@ static int partition_compressed(const matrixCOO* m, const std::vector<int64_t>& 
             }
         }
     }
-    if (c.verbose) printf("compressed graph: %d vertices for %d rows, %lld of %lld edges\n", ng, n, (long long)cx[ng], (long long)xadj[n]);
+    if (c.verbose) printf("compressed graph: %d vertices for %d rows, %lld of %lld edges\n", ng, n, (long long)cx[ng], (long long)(from_rows ? m->totalNum - n : xadj[n]));
     std::vector<int> cpart((size_t)ng, 0);
     const int rc = partition_graph(ng, cx.data(), ca.data(), cw.data(), nparts, cap, c, cpart.data(), cut);
     if (rc != EHYB_OK) return rc;
@@ -242,6 +253,8 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
         EHYB_FAIL(EHYB_ERR_ARG, "ehyb_matrix_reorder: partBoundary holds %lld ints, nParts = %d needs %d", (long long)pb_cap, nparts, nparts + 1);
     std::vector<int> top_first;  // n_top > 1: first partition of every top-level block
 
+    // cfg.col_map (as in build_layout): one array over the columns per host thread where that fits, instead of sorted lists / hash tables
+    const bool col_map = c.col_map != 2 && (int64_t)n * 4 * omp_get_max_threads() <= (int64_t(2) << 30);
     int cache = m->vectorCacheSize > 0 ? (int)m->vectorCacheSize : c.part_rows;
     int cap = std::max<int64_t>(cache, ((int64_t)n + nparts - 1) / nparts);
 
@@ -255,7 +268,20 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
         // EHYB_PART_DEGREE needs the DEGREES only (entries in the row + entries in the column, the diagonal left out):
         // no adjacency lists -- on R-MAT 2^24 building them was a third of the whole reorder
         const bool degrees_only = c.partitioner == EHYB_PART_DEGREE && c.n_top <= 1;
-        if (degrees_only) {
+        // the multilevel scheme on the compressed graph where the rows come in groups with one column list
+        // Automatic = with symmetric pair storage only: the partitions of the compressed graph cost the bench matrix with
+        // EVERY entry stored 4 % (same-box A/B at equal format bytes, round 2: 1098-1101 against 1123-1166 GFLOP/s;
+        // bench.py's plain_storage arm fell from 1094 to 1049) while symmetric pairs gain from them (fewer halo columns).
+        const bool compress = (c.graph_compress == 1 || (c.graph_compress == 0 && c.sym_pairs == 1)) && symmetric_pattern != 0 && (c.partitioner == EHYB_PART_AUTO || c.partitioner == EHYB_PART_MULTILEVEL) && n >= 4096;
+        // ... and then the compressed graph is made from the rows themselves (symmetric pattern: the columns of a row ARE its neighbours);
+        // the adjacency lists -- a copy of J without the diagonal, 311 MB for the bench matrix -- are built only if that attempt declines
+        const bool defer_adj = compress && c.n_top <= 1;
+        const auto need_adjacency = [&]() {
+            if (adj.empty() && xadj.empty()) build_adjacency(m, symmetric_pattern != 0, &xadj, &adj);
+        };
+        if (defer_adj) {
+            // nothing yet
+        } else if (degrees_only) {
             xadj.assign((size_t)n + 1, 0);
             std::vector<int> colcnt(n, 0);
             if (!symmetric_pattern) {
@@ -349,11 +375,6 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
             std::vector<int> rowlen;
             std::vector<int> twin_group;  // compressed graph used: the group (node) of every row
             bool weighted = false, by_degree = false;
-            // the multilevel scheme on the compressed graph where the rows come in groups with one column list
-            // Automatic = with symmetric pair storage only: the partitions of the compressed graph cost the bench matrix with
-            // EVERY entry stored 4 % (same-box A/B at equal format bytes, round 2: 1098-1101 against 1123-1166 GFLOP/s;
-            // bench.py's plain_storage arm fell from 1094 to 1049) while symmetric pairs gain from them (fewer halo columns).
-            const bool compress = (c.graph_compress == 1 || (c.graph_compress == 0 && c.sym_pairs == 1)) && symmetric_pattern != 0 && (c.partitioner == EHYB_PART_AUTO || c.partitioner == EHYB_PART_MULTILEVEL) && n >= 4096;
             if (c.sym_pairs == 1 && n >= 4 * nparts) {
                 rowlen.resize(n);
                 double sum = 0, sq = 0;
@@ -396,15 +417,20 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                     bool done = false;
                     rc = EHYB_OK;
                     if (compress) rc = partition_compressed(m, xadj, adj, rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut, &done, &twin_group);
-                    if (rc == EHYB_OK && !done)
+                    if (rc == EHYB_OK && !done) {
+                        if (defer_adj) need_adjacency();
                         rc = partition_graph(n, xadj.data(), adj.empty() ? nullptr : adj.data(), rowlen.data(), nparts, (int)std::min<int64_t>(wcap, 0x7FFFFFFF), c, part.data(), &cut, &by_degree);
+                    }
                 }
             }
             if (!weighted) {
                 bool done = false;
                 rc = EHYB_OK;
                 if (compress) rc = partition_compressed(m, xadj, adj, nullptr, nparts, cap, c, part.data(), &cut, &done, &twin_group);
-                if (rc == EHYB_OK && !done) rc = partition_graph(n, xadj.data(), adj.empty() ? nullptr : adj.data(), nullptr, nparts, cap, c, part.data(), &cut, &by_degree);
+                if (rc == EHYB_OK && !done) {
+                    if (defer_adj) need_adjacency();
+                    rc = partition_graph(n, xadj.data(), adj.empty() ? nullptr : adj.data(), nullptr, nparts, cap, c, part.data(), &cut, &by_degree);
+                }
             }
             if (rc == EHYB_OK && by_degree) degree_order(n, xadj.data(), &row_order);
             if (c.verbose) printf("k-way partition time is %ld us\n", (long)((wall_seconds() - t0) * 1e6));
@@ -428,15 +454,27 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
 #pragma omp parallel
                     {
                         std::vector<int> o;
+                        std::vector<int> last;  // cfg.col_map: per column, the last partition of this thread that referenced it
+                        if (col_map) last.assign((size_t)n, -1);
 #pragma omp for schedule(dynamic, 2)
                         for (int p = 0; p < nparts; ++p) {
-                            o.clear();
-                            for (int i : members[p])
-                                for (int k = rp0[i]; k < rp0[i + 1]; ++k)
-                                    if (part[m->J[k]] != p) o.push_back(m->J[k]);
-                            std::sort(o.begin(), o.end());
+                            int distinct = 0;
+                            if (col_map) {
+                                for (int i : members[p])
+                                    for (int k = rp0[i]; k < rp0[i + 1]; ++k) {
+                                        const int j = m->J[k];
+                                        if (part[j] != p && last[(size_t)j] != p) last[(size_t)j] = p, ++distinct;
+                                    }
+                            } else {
+                                o.clear();
+                                for (int i : members[p])
+                                    for (int k = rp0[i]; k < rp0[i + 1]; ++k)
+                                        if (part[m->J[k]] != p) o.push_back(m->J[k]);
+                                std::sort(o.begin(), o.end());
+                                distinct = (int)(std::unique(o.begin(), o.end()) - o.begin());
+                            }
                             // own rows (twice with symmetric pair storage: x and the y accumulators) + halo
-                            demand[p] = (int)members[p].size() * (c.sym_pairs == 1 ? 2 : 1) + 2 + (int)(std::unique(o.begin(), o.end()) - o.begin());
+                            demand[p] = (int)members[p].size() * (c.sym_pairs == 1 ? 2 : 1) + 2 + distinct;
                         }
                     }
                     std::vector<int> offenders;
@@ -466,8 +504,13 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                             sa.clear();
                             for (int q = 0; q < nb; ++q) {
                                 int v = verts[q];
-                                for (int64_t e = xadj[v]; e < xadj[v + 1]; ++e)
-                                    if (part[adj[e]] == p) sa.push_back(local[adj[e]]);
+                                if (adj.empty()) {  // (adjacency never built: symmetric pattern, the row without its diagonal)
+                                    for (int k = rp0[v]; k < rp0[v + 1]; ++k)
+                                        if (m->J[k] != v && part[m->J[k]] == p) sa.push_back(local[m->J[k]]);
+                                } else {
+                                    for (int64_t e = xadj[v]; e < xadj[v + 1]; ++e)
+                                        if (part[adj[e]] == p) sa.push_back(local[adj[e]]);
+                                }
                                 sx[q + 1] = (int64_t)sa.size();
                             }
                             halves[oi].assign(nb, 0);
@@ -595,6 +638,7 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
             std::vector<int> cand;
             std::vector<std::pair<int, int>> uniq;
             std::vector<int> hkey, hcnt;
+            std::vector<int> cmap;  // cfg.col_map: reference count by column, then -1 = chosen; all zero between partitions
 #pragma omp for schedule(dynamic, 1)
             for (int p = 0; p < nparts; ++p) {
                 if (done[(size_t)p]) continue;
@@ -603,6 +647,34 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
                 const int hcap = c.lds_doubles - 2 - (own + (pb[p] & 1)) * (c.sym_pairs == 1 ? 2 : 1);
                 if (hcap <= 0) continue;
                 cand.clear();
+                if (col_map) {
+                    if (cmap.empty()) cmap.assign((size_t)n, 0);
+                    for (int q = pb[p]; q < pb[p + 1]; ++q) {
+                        const int i = rows_of[q];
+                        for (int k = m->rowIdx[i]; k < m->rowIdx[i + 1]; ++k)
+                            if (part[m->J[k]] != p && cmap[(size_t)m->J[k]]++ == 0) cand.push_back(m->J[k]);  // every candidate once (I[k] == i: checked on entry)
+                    }
+                    if (cand.empty()) continue;
+                    uniq.resize(cand.size());
+                    for (size_t a = 0; a < cand.size(); ++a) uniq[a] = {cmap[(size_t)cand[a]], cand[a]};
+                    for (int j : cand) cmap[(size_t)j] = 0;
+                    if ((int)uniq.size() > hcap) {
+                        std::nth_element(uniq.begin(), uniq.begin() + hcap, uniq.end(),
+                                         [](const std::pair<int, int>& x, const std::pair<int, int>& y) {
+                                             return x.first != y.first ? x.first > y.first : x.second < y.second;
+                                         });
+                        uniq.resize(hcap);
+                    }
+                    for (const auto& u : uniq) cmap[(size_t)u.second] = -1;  // chosen
+                    for (int q = pb[p]; q < pb[p + 1]; ++q) {
+                        const int i = rows_of[q];
+                        int add = 0;
+                        for (int k = m->rowIdx[i]; k < m->rowIdx[i + 1]; ++k) add += cmap[(size_t)m->J[k]] < 0;  // (only outside columns are ever marked)
+                        inpart[i] += add;
+                    }
+                    for (const auto& u : uniq) cmap[(size_t)u.second] = 0;
+                    continue;
+                }
                 for (int q = pb[p]; q < pb[p + 1]; ++q) {
                     int i = rows_of[q];
                     for (int k = m->rowIdx[i]; k < m->rowIdx[i + 1]; ++k)
@@ -671,18 +743,26 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
         rp[pos + 1] = rp[pos] + num[pos];
         maxcol = std::max(maxcol, num[pos]);
     }
-    int* nI = (int*)malloc(sizeof(int) * (size_t)std::max<int64_t>(nnz, 1));
-    int* nJ = (int*)malloc(sizeof(int) * (size_t)std::max<int64_t>(nnz, 1));
+    // Fresh memory is what this step costs (a first touch of 1.24 GB for the bench matrix takes longer than the gather itself, common.cpp:
+    // prefault), so only the values get a new array; the new column array is the OLD value array cut down to size (its pages are mapped
+    // already, and the old values are not needed any more once the new ones are in place), the new row array is the old column array.
+    // The arrays of a matrixCOO are malloc()ed by contract (they are freed with free(), here and by the reference's driver).
     double* nV = (double*)malloc(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1));
-    if (!nI || !nJ || !nV) {
-        free(nI);
-        free(nJ);
-        free(nV);
-        EHYB_FAIL(EHYB_ERR_ALLOC, "ehyb_matrix_reorder: out of memory for %lld entries", (long long)nnz);
-    }
+    if (!nV) EHYB_FAIL(EHYB_ERR_ALLOC, "ehyb_matrix_reorder: out of memory for %lld entries", (long long)nnz);
     const double tp0 = wall_seconds();
-    prefault(nI, sizeof(int) * (size_t)nnz), prefault(nJ, sizeof(int) * (size_t)nnz), prefault(nV, sizeof(double) * (size_t)nnz);
+    prefault(nV, sizeof(double) * (size_t)nnz);
     const double tp1 = wall_seconds();
+#pragma omp parallel for schedule(dynamic, 1024)
+    for (int ti = 0; ti < n; ++ti) {
+        const int oi = rows_of[ti];
+        memcpy(nV + rp[ti], m->V + old_rp[oi], sizeof(double) * (size_t)(old_rp[oi + 1] - old_rp[oi]));
+    }
+    int* nJ = (int*)realloc(m->V, sizeof(int) * (size_t)std::max<int64_t>(nnz, 1));
+    m->V = nV;   // (from here on the matrix owns the new values: an error below leaves it consistent but for I and J)
+    if (!nJ) {
+        nJ = (int*)malloc(sizeof(int) * (size_t)std::max<int64_t>(nnz, 1));
+        if (!nJ) EHYB_FAIL(EHYB_ERR_ALLOC, "ehyb_matrix_reorder: out of memory for %lld entries", (long long)nnz);
+    }
 #pragma omp parallel for schedule(dynamic, 1024)
     for (int ti = 0; ti < n; ++ti) {
         const int oi = rows_of[ti];
@@ -691,21 +771,20 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
         int in_window = 0;
         for (int k = old_rp[oi]; k < old_rp[oi + 1]; ++k, ++dst) {
             const int tj = list[m->J[k]];
-            nI[dst] = ti;
             nJ[dst] = tj;
-            nV[dst] = m->V[k];
             in_window += tj >= ps && tj < ps + cache;
         }
         num2[ti] = in_window;
     }
+    int* nI = m->J;  // same length, not needed any more
+    m->J = nJ;
+#pragma omp parallel for schedule(static)
+    for (int ti = 0; ti < n; ++ti)
+        for (int64_t dst = rp[ti]; dst < rp[ti + 1]; ++dst) nI[dst] = ti;
     const double tp2 = wall_seconds();
     free(m->I);
-    free(m->J);
-    free(m->V);
-    if (c.verbose > 1) printf("  permute: setup %.3f prefault %.3f gather %.3f free %.3f s\n", tp0 - t_perm, tp1 - tp0, tp2 - tp1, wall_seconds() - tp2);
     m->I = nI;
-    m->J = nJ;
-    m->V = nV;
+    if (c.verbose > 1) printf("  permute: setup %.3f prefault %.3f gather %.3f free %.3f s\n", tp0 - t_perm, tp1 - tp0, tp2 - tp1, wall_seconds() - tp2);
     m->maxCol = maxcol;
     if (c.verbose) printf("permute time is %ld us\n", (long)((wall_seconds() - t_perm) * 1e6));
     if (block_first) {

@@ -386,3 +386,27 @@ def test_symmetric_pair_storage(E, O, case):
         yp, written = O.walk_plan(plan, c.xp)
         A = c.m.to_scipy()
         assert np.allclose(yp, A @ c.xp, rtol=1e-12, atol=1e-12)
+
+
+@pytest.mark.parametrize("kind,args,kw", [
+    ("fem3d", (24000, 3, 20, 20, 13500, 1, 3), dict(sym_pairs=1, value_map=1, lds_doubles=4096)),
+    ("fem3d", (24000, 3, 20, 20, 13500, 1, 3), dict(lds_doubles=2048)),
+    ("fem3d_graded", (30000, 3, 20, 20, 100000, 705000, 1, 1), dict(sym_pairs=1, lds_doubles=4096)),
+    ("rmat", (13, 1 << 16, 1), dict(lds_doubles=2048)),
+], ids=["fem-sym", "fem-plain", "graded-sym", "rmat"])
+def test_column_maps_and_sorted_lists_build_the_same_plan(E, O, kind, args, kw):
+    """cfg.col_map: the host builder finds a window's outside columns through one look-up array per thread (default) or through
+    sorted lists / hash tables and binary searches (col_map = 2, the only route for inputs whose arrays would not fit): the
+    permutation and every array of the plan are the same."""
+    from ehyb_spmv_gpu_amd.host import ARRAYS
+    got = []
+    for col_map in (1, 2):
+        cfg = E.make_config(col_map=col_map, **kw)
+        m = E.Matrix.generate(kind, *args, cfg=cfg)
+        m.reorder(cfg)
+        plan = E.Plan(m, cfg, upload=False)
+        got.append((m.reorder_list.copy(), {name: plan.array(name) for name in ARRAYS}, plan.stats))
+    assert np.array_equal(got[0][0], got[1][0])
+    assert got[0][2] == got[1][2]
+    for name in got[0][1]:
+        assert np.array_equal(got[0][1][name], got[1][1][name]), name
