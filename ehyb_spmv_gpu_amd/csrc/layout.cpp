@@ -65,7 +65,7 @@ inline int halo_lookup(const std::vector<int32_t>& halo, int col)
 // (Everything lives in flat arrays that a host thread keeps from one partition to the next: one vector per group, and fresh megabyte
 // arrays per partition -- mmap, page faults, munmap -- made this function spend more time in the allocator than in its loops.)
 struct OrientScratch {
-    std::vector<int> grp, gfirst, nb_ptr, nb, seen, inc_ptr, inc_to, inc_id, fill_at, owner, left, at, cptr, crow, cent, cfill, mark, hint;
+    std::vector<int> grp, gfirst, nb_ptr, nb, seen, inc_ptr, inc_to, inc_id, fill_at, owner, left, at, cptr, crow, cent, cfill, mark, hint, ck, cpos, coff;
     std::vector<uint8_t> mutual;
 };
 void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64_t k0, uint8_t* state, int32_t* partner, OrientScratch& W)
@@ -166,7 +166,7 @@ void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64
     // (the groups whose pairs the current row's group keeps are MARKED: a look-up instead of a search per entry)
     // and the rows of a group have one column list: entry t of the row above had its partner at hint[t] of that row's column -- with a
     // symmetric pattern the same place in this row's column, checked before any search)
-    std::vector<int>&mark = W.mark, &hint = W.hint;
+    std::vector<int>&mark = W.mark, &hint = W.hint, &ck = W.ck, &cpos = W.cpos, &coff = W.coff;
     mark.assign(G, -1);
     int marked = -1;
     for (int i = s; i < e; ++i) {
@@ -178,18 +178,42 @@ void sym_orient_partition(const matrixCOO* m, const int* rp, int s, int e, int64
         }
         const int* cb = crow.data() + cptr[i - s];
         const int* ce = crow.data() + cptr[i - s + 1];
-        if (hint.size() < (size_t)(rp[i + 1] - rp[i])) hint.resize((size_t)(rp[i + 1] - rp[i]), 0);
-        for (int k = rp[i]; k < rp[i + 1]; ++k) {
-            const int j = J[k];
-            if (j < s || j >= e || state[k - k0] != 0) continue;
-            const int h = grp[j - s];
-            if (h == g || mark[h] != g) continue;
+        const int len = rp[i + 1] - rp[i], clen = (int)(ce - cb);
+        if (hint.size() < (size_t)len) hint.resize((size_t)len, 0);
+        if (ck.size() < (size_t)len) ck.resize((size_t)len), cpos.resize((size_t)len);
+        // first where every candidate's partner would sit -- and a prefetch of its value and state: they are anywhere in the partition's
+        // 2-4 MB, one miss after the other was half of this loop --, then the comparisons
+        // (which entries of the row are candidates -- in the partition, in a group whose pairs this group keeps -- is the same for every row
+        // of a group: found for its first row, kept for the others)
+        if (i == gfirst[g]) {
+            coff.clear();
+            for (int k = rp[i]; k < rp[i + 1]; ++k) {
+                const int j = J[k];
+                if (j < s || j >= e) continue;
+                const int h = grp[j - s];
+                if (h != g && mark[h] == g) coff.push_back(k - rp[i]);
+            }
+        }
+        int nc = 0;
+        for (const int t : coff) {
+            const int k = rp[i] + t, j = J[k];
+            if (state[k - k0] != 0) continue;  // (the state of this row's entries changes below only for the entry at hand)
+            int o = hint[k - rp[i]];
+            if (!(o < clen && cb[o] == j && (o == 0 || cb[o - 1] != j))) o = (int)(std::lower_bound(cb, ce, j) - cb);
+            hint[k - rp[i]] = o;
+            if (o < clen && cb[o] == j) {
+                const int64_t kp = cent[cptr[i - s] + o];
+                __builtin_prefetch(V + kp);
+                __builtin_prefetch(state + (kp - k0), 1);
+                ck[nc] = k;
+                cpos[nc++] = o;
+            }
+        }
+        for (int q = 0; q < nc; ++q) {
+            const int k = ck[q], j = J[k];
             // the partner (j, i): first unclaimed entry of row j in column i with the same value
-            const int* lo = cb + hint[k - rp[i]];
-            if (!(lo < ce && *lo == j && (lo == cb || lo[-1] != j))) lo = std::lower_bound(cb, ce, j);
-            hint[k - rp[i]] = (int)(lo - cb);
-            for (; lo != ce && *lo == j; ++lo) {
-                const int64_t kp = cent[lo - crow.data()];
+            for (int o = cpos[q]; o < clen && cb[o] == j; ++o) {
+                const int64_t kp = cent[cptr[i - s] + o];
                 if (state[kp - k0] == 0 && V[kp] == V[k]) {
                     state[k - k0] = 1;
                     state[kp - k0] = 2;
@@ -734,14 +758,15 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             if (hmap.empty()) hmap.assign((size_t)n, 0);
             for (size_t a = 0; a < S.halo.size(); ++a) hmap[(size_t)S.halo[a]] = (int32_t)a + 1;
         }
-        {
-            const size_t v0 = (size_t)L->slab_pair_ptr[slab_base[p]] * 2 * kSlabRows, v1 = (size_t)L->slab_pair_ptr[slab_base[p + 1]] * 2 * kSlabRows;
-            const size_t c0 = L->slab_col_ptr[slab_base[p]], c1 = L->slab_col_ptr[slab_base[p + 1]];
-            std::fill(L->ell_val.begin() + v0, L->ell_val.begin() + v1, 0.0);
-            std::fill(L->ell_col.begin() + c0, L->ell_col.begin() + c1, 0u);
-            if (vmap) std::fill(L->ell_src.begin() + v0, L->ell_src.begin() + v1, -1);
-            if (vmap && sym) std::fill(L->ell_src2.begin() + v0, L->ell_src2.begin() + v1, -1);
-        }
+        // (the column words are OR-ed together: cleared first.  The value stream and its slot maps are written slot by slot -- the entries,
+        // then every lane's padding: a fill in advance was half of the bytes this pass wrote)
+        std::fill(L->ell_col.begin() + L->slab_col_ptr[slab_base[p]], L->ell_col.begin() + L->slab_col_ptr[slab_base[p + 1]], 0u);
+        const bool vmap2 = vmap && sym;
+        auto pad_slot = [&](size_t at) {
+            L->ell_val[at] = 0.0;
+            if (vmap) L->ell_src[at] = -1;
+            if (vmap2) L->ell_src2[at] = -1;
+        };
         int gid = 0;
         for (int t = 0; t < e - s; ++t) {
             const int r = row_at[s - row_begin + t];
@@ -785,7 +810,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                     L->ell_val[at] = m->V[k];
                     if (vmap) {
                         L->ell_src[at] = k;
-                        if (st8 == 1) L->ell_src2[at] = partner[k - k0];
+                        if (vmap2) L->ell_src2[at] = st8 == 1 ? partner[k - k0] : -1;
                     }
                     if (st8 == 1) {
                         if (local >= 0x8000 || j < s || j >= e) {  // only own rows have an accumulator
@@ -808,14 +833,23 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                             overflow = 1;
                             continue;
                         }
-                        L->ell_val[(size_t)(((pp + w2 + ke / 2) * kSlabRows + lane) * 2 + (ke & 1))] = m->V[k];
-                        if (vmap) L->ell_src[(size_t)(((pp + w2 + ke / 2) * kSlabRows + lane) * 2 + (ke & 1))] = k;
+                        const size_t at = (size_t)(((pp + w2 + ke / 2) * kSlabRows + lane) * 2 + (ke & 1));
+                        L->ell_val[at] = m->V[k];
+                        if (vmap) L->ell_src[at] = k;
+                        if (vmap2) L->ell_src2[at] = -1;
                         L->ell_col[(size_t)(cp + (uint64_t)w2 * G + (uint64_t)(ke / 2) * 2 * kSlabRows + (ke & 1) * kSlabRows + lane)] = (uint32_t)j;
                     }
                     ++k_er;
                 }
             }
             if (k_er != er_rp[r - row_begin + 1] || (int)k_ell != cnt_ell[r - row_begin]) overflow = 1;
+            // the lane's padding: the ELL slots behind its last entry, the inline-residual slots behind its last residual entry
+            for (uint32_t q = std::min(k_ell, 2 * w2); q < 2 * w2; ++q) pad_slot((size_t)(((pp + q / 2) * kSlabRows + lane) * 2 + (q & 1)));
+            for (uint32_t q = ner ? (uint32_t)std::min<int64_t>(k_er - er_rp[r - row_begin], 2 * ner) : 0; q < 2 * ner; ++q)
+                pad_slot((size_t)(((pp + w2 + q / 2) * kSlabRows + lane) * 2 + (q & 1)));
+            if (t + 1 == e - s)  // the lanes past the last row of the partition: nothing but padding
+                for (int l2 = lane + 1; l2 < kSlabRows; ++l2)
+                    for (uint32_t q = 0; q < 2 * (w2 + ner); ++q) pad_slot((size_t)(((pp + q / 2) * kSlabRows + l2) * 2 + (q & 1)));
         }
         if (sym) {
             // Lanes of a group read the same column word, so their mirror products go to the same

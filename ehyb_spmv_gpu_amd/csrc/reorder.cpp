@@ -744,46 +744,40 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
         maxcol = std::max(maxcol, num[pos]);
     }
     // Fresh memory is what this step costs (a first touch of 1.24 GB for the bench matrix takes longer than the gather itself, common.cpp:
-    // prefault), so only the values get a new array; the new column array is the OLD value array cut down to size (its pages are mapped
-    // already, and the old values are not needed any more once the new ones are in place), the new row array is the old column array.
-    // The arrays of a matrixCOO are malloc()ed by contract (they are freed with free(), here and by the reference's driver).
+    // prefault), so only the values get a new array.  The new COLUMN array is the old row array (the rows are known from rowIdx: nothing
+    // reads I here), the new ROW array is the old column array once the columns have been dealt out of it: both are mapped already and
+    // exactly as long as needed.  (The arrays of a matrixCOO are malloc()ed by contract -- freed with free(), here and by the
+    // reference's driver -- and the caller gets three valid arrays back as before.)
     double* nV = (double*)malloc(sizeof(double) * (size_t)std::max<int64_t>(nnz, 1));
     if (!nV) EHYB_FAIL(EHYB_ERR_ALLOC, "ehyb_matrix_reorder: out of memory for %lld entries", (long long)nnz);
     const double tp0 = wall_seconds();
     prefault(nV, sizeof(double) * (size_t)nnz);
     const double tp1 = wall_seconds();
-#pragma omp parallel for schedule(dynamic, 1024)
-    for (int ti = 0; ti < n; ++ti) {
-        const int oi = rows_of[ti];
-        memcpy(nV + rp[ti], m->V + old_rp[oi], sizeof(double) * (size_t)(old_rp[oi + 1] - old_rp[oi]));
-    }
-    int* nJ = (int*)realloc(m->V, sizeof(int) * (size_t)std::max<int64_t>(nnz, 1));
-    m->V = nV;   // (from here on the matrix owns the new values: an error below leaves it consistent but for I and J)
-    if (!nJ) {
-        nJ = (int*)malloc(sizeof(int) * (size_t)std::max<int64_t>(nnz, 1));
-        if (!nJ) EHYB_FAIL(EHYB_ERR_ALLOC, "ehyb_matrix_reorder: out of memory for %lld entries", (long long)nnz);
-    }
+    int* nJ = m->I;
+    const int* oJ = m->J;
 #pragma omp parallel for schedule(dynamic, 1024)
     for (int ti = 0; ti < n; ++ti) {
         const int oi = rows_of[ti];
         const int ps = pb[part[oi]];
         int64_t dst = rp[ti];
         int in_window = 0;
+        memcpy(nV + dst, m->V + old_rp[oi], sizeof(double) * (size_t)(old_rp[oi + 1] - old_rp[oi]));
         for (int k = old_rp[oi]; k < old_rp[oi + 1]; ++k, ++dst) {
-            const int tj = list[m->J[k]];
+            const int tj = list[oJ[k]];
             nJ[dst] = tj;
             in_window += tj >= ps && tj < ps + cache;
         }
         num2[ti] = in_window;
     }
-    int* nI = m->J;  // same length, not needed any more
-    m->J = nJ;
+    int* nI = m->J;
 #pragma omp parallel for schedule(static)
     for (int ti = 0; ti < n; ++ti)
         for (int64_t dst = rp[ti]; dst < rp[ti + 1]; ++dst) nI[dst] = ti;
     const double tp2 = wall_seconds();
-    free(m->I);
+    free(m->V);
     m->I = nI;
+    m->J = nJ;
+    m->V = nV;
     if (c.verbose > 1) printf("  permute: setup %.3f prefault %.3f gather %.3f free %.3f s\n", tp0 - t_perm, tp1 - tp0, tp2 - tp1, wall_seconds() - tp2);
     m->maxCol = maxcol;
     if (c.verbose) printf("permute time is %ld us\n", (long)((wall_seconds() - t_perm) * 1e6));
