@@ -320,6 +320,9 @@ __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict
             const int c = A.halo_cols[hb + i];
             win[cnt + i] = A.x[c] + 1e-300 * (A.x[(c + o1) % n] + A.x[(c + o2) % n]);
         }
+    } else if (STAMP && A.probe_n < 0) {   // (diagnostic: no halo gather at all -- results wrong, the launch span is what hiding the gather could reach at best)
+        for (int i = threadIdx.x; i < cnt; i += THREADS) win[i] = A.x[base + i];
+        for (int i = threadIdx.x; i < hn; i += THREADS) win[cnt + i] = 1.0;
     } else {
         for (int i = threadIdx.x; i < cnt; i += THREADS) win[i] = A.x[base + i];
         for (int i = threadIdx.x; i < hn; i += THREADS) win[cnt + i] = A.x[A.halo_cols[hb + i]];
@@ -1163,7 +1166,7 @@ int ehyb_measure_read_bw(size_t bytes, int iters, double* gbps)
 int ehyb_debug_ell_stamps(ehyb_plan* P, const double* x, double* y, unsigned long long* out_host);
 int ehyb_debug_ell_stamps_probe(ehyb_plan* P, const double* x, double* y, unsigned long long* out_host, int triple_gather)
 {
-    t_probe_n = (triple_gather && P) ? P->host.n_cols : 0;
+    t_probe_n = (triple_gather == 2) ? -1 : (triple_gather && P) ? P->host.n_cols : 0;   // 2: no halo gather (diagnostic)
     const int rc = ehyb_debug_ell_stamps(P, x, y, out_host);
     t_probe_n = 0;
     return rc;
