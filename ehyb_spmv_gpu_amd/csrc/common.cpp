@@ -8,6 +8,7 @@
 
 #include <algorithm>
 #include <chrono>
+#include <thread>
 #include <cmath>
 
 namespace ehyb {
@@ -68,6 +69,20 @@ double wall_seconds()
 // the reorder step, nearly all of it these traps.  (Transparent huge pages were tried first -- MADV_HUGEPAGE -- and made it WORSE,
 // 0.74 -> 1.99 s: with defrag = madvise every huge-page fault compacts memory synchronously.)  A hint: an older kernel answers
 // EINVAL and the first touch pays as before.
+void release_big(void* p, size_t bytes)
+{
+    if (!p) return;
+    if (bytes >= (size_t(64) << 20)) {
+        try {
+            std::thread(free, p).detach();   // (the helper outlives nothing it needs: free() of a block nobody refers to any more)
+            return;
+        } catch (...) {
+            // no thread to be had: in line, as below
+        }
+    }
+    free(p);
+}
+
 void prefault(void* p, size_t bytes)
 {
 #ifndef MADV_POPULATE_WRITE

@@ -7,7 +7,9 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <algorithm>
 #include <memory>
+#include <new>
 #include <string>
 #include <utility>
 #include <vector>
@@ -18,8 +20,12 @@ namespace ehyb {
 // The big arrays of a layout (hundreds of MB each): a vector whose resize() does NOT write the new elements -- the builder
 // fills every element itself, partition by partition on all host threads; a value-initialising resize was one more pass
 // over the array on ONE thread (audikw_1-like: 1.2 GB of such fills, a quarter of the plan's build time).
+// release_big: free() of a malloc()ed block; a block of 64 MiB or more is handed to a helper thread -- giving 600 MB of touched pages back to the
+// kernel takes 70-75 ms on the GPU box's host (more than gathering them took), and nothing the caller does next has to wait for it.
+void release_big(void* p, size_t bytes);
 template <class T>
-struct NoInitAlloc : std::allocator<T> {
+struct NoInitAlloc {
+    using value_type = T;
     template <class U>
     struct rebind {
         using other = NoInitAlloc<U>;
@@ -27,6 +33,17 @@ struct NoInitAlloc : std::allocator<T> {
     NoInitAlloc() = default;
     template <class U>
     NoInitAlloc(const NoInitAlloc<U>&) {}
+    T* allocate(size_t n)
+    {
+        void* p = malloc(std::max<size_t>(n * sizeof(T), 1));
+        if (!p) throw std::bad_alloc();
+        return static_cast<T*>(p);
+    }
+    void deallocate(T* p, size_t) { free(p); }
+    template <class U>
+    bool operator==(const NoInitAlloc<U>&) const { return true; }
+    template <class U>
+    bool operator!=(const NoInitAlloc<U>&) const { return false; }
     template <class U, class... A>
     void construct(U* p, A&&... a)
     {
@@ -258,6 +275,11 @@ int mtmetis_partition(int n, const int64_t* xadj, const int* adjncy, int nparts,
 
 // ---------------------------------------------------------------- misc
 double wall_seconds();
+// cfg.col_map: the host builders look columns up in ONE array over all columns per host thread where that array is small enough to be
+// looked into at random cheaply -- 16 MiB, 4 M columns (the bench matrix: 3.7 MB) -- and fall back to sorted lists / hash tables of a
+// partition's own candidates beyond (R-MAT 2^24: 64 MiB per thread, first touched and zeroed per thread and per window sample, cost the
+// plan 0.36 s, and a partition's 10^5 candidates scattered over it miss the caches and the TLB every time).
+inline bool col_map_fits(const Config& cfg, int n_cols) { return cfg.col_map != 2 && (int64_t)n_cols * 4 <= (int64_t(16) << 20); }
 void prefault(void* p, size_t bytes);  // fresh pages of an array about to be filled, mapped in one sweep instead of a trap per page
 template <class T, class A>
 inline void prefault_vector(std::vector<T, A>& v, size_t n)  // reserve + prefault: the resize / push_backs that follow touch mapped pages

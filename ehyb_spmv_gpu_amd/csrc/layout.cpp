@@ -377,7 +377,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
     // the window takes), then the mark of the chosen ones -- and puts back what it touched.  Sorting the candidates of every partition
     // and a binary search per outside entry in both passes were a third of the build (audikw_1-like: 60 k candidates, 3,200 chosen, per
     // partition).  The lists below stay for inputs whose column arrays would not fit.
-    const bool col_map = halo_mode && cfg.col_map != 2 && (int64_t)n * 4 * omp_get_max_threads() <= (int64_t(2) << 30);
+    const bool col_map = halo_mode && col_map_fits(cfg, n);
 #pragma omp parallel
     {
         std::vector<int32_t> cand;
@@ -389,7 +389,6 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
             const int s = pb[p], e = pb[p + 1];
             const int own = e - s;
             std::vector<int32_t>().swap(dense);
-            if (col_map && cmap.empty()) cmap.assign((size_t)n, 0);
             int wlen;
             PartScratch& S = ps[p];
             const bool whole_to_er = part_to_er && (size_t)p < part_to_er->size() && (*part_to_er)[p] != 0 && !sym;
@@ -403,6 +402,7 @@ int build_layout(const matrixCOO* m, int row_begin, int row_end, const Config& c
                 // by one accumulator per image row
                 int hcap = lds - (own + (s & 1)) * (sym ? 2 : 1);
                 cand.clear();
+                if (col_map && cmap.empty()) cmap.assign((size_t)n, 0);
                 for (int r = s; r < e; ++r)
                     for (int k = rp[r]; k < rp[r + 1]; ++k) {
                         int j = m->J[k];

@@ -254,7 +254,7 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
     std::vector<int> top_first;  // n_top > 1: first partition of every top-level block
 
     // cfg.col_map (as in build_layout): one array over the columns per host thread where that fits, instead of sorted lists / hash tables
-    const bool col_map = c.col_map != 2 && (int64_t)n * 4 * omp_get_max_threads() <= (int64_t(2) << 30);
+    const bool col_map = col_map_fits(c, n);
     int cache = m->vectorCacheSize > 0 ? (int)m->vectorCacheSize : c.part_rows;
     int cap = std::max<int64_t>(cache, ((int64_t)n + nparts - 1) / nparts);
 
@@ -774,7 +774,7 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
     for (int ti = 0; ti < n; ++ti)
         for (int64_t dst = rp[ti]; dst < rp[ti + 1]; ++dst) nI[dst] = ti;
     const double tp2 = wall_seconds();
-    free(m->V);
+    release_big(m->V, sizeof(double) * (size_t)nnz);   // (on a helper thread: 74 ms of munmap on the box otherwise, common.cpp)
     m->I = nI;
     m->J = nJ;
     m->V = nV;

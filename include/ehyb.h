@@ -202,8 +202,8 @@ typedef struct ehyb_config {
                               (dist.py: exchange "cover") -- and ehyb_spmv_part can close them early (EHYB_PART_LAST_FOREIGN), so
                               that they travel while the rank's own rows are still being multiplied                       */
     int32_t col_map;       /* host builder, how a partition finds the window place of an outside column: 0/1 = in a look-up array over the
-                              columns, one per host thread (where columns x 4 B x threads is at most 2 GiB), 2 = in the sorted list of
-                              the window's outside columns by binary search (A/B; the only way for larger inputs).  The layouts are
+                              columns, one per host thread (matrices of up to 4 M columns: 16 MiB per thread), 2 = in the sorted list
+                              of the window's outside columns by binary search (A/B; the way for larger inputs).  The layouts are
                               the same array for array                                                                  */
     int32_t reserved[23];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
 } ehyb_config;

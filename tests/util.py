@@ -1,5 +1,30 @@
 """Shared helpers for the parity tests: the harness flow of solver_test.c:350-389."""
+import socket
+import subprocess
+import sys
+
 import numpy as np
+
+
+def free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def torchrun(world, script, script_args=(), timeout=600, env=None, cwd=None):
+    """`python -m torch.distributed.run` of `script` with `world` ranks on 127.0.0.1.  The rendezvous port is picked by binding port 0
+    and letting go of it: another test process (pytest -n) can be handed the same port in between -- seen once in a few dozen runs --, so a
+    launch that dies on the rendezvous address is repeated once on a new port."""
+    p = None
+    for attempt in range(2):
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={world}",
+               "--master-addr", "127.0.0.1", "--master-port", str(free_port()), script, *script_args]
+        p = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, env=env, cwd=cwd)
+        taken = any(w in (p.stderr + p.stdout) for w in ("Address already in use", "EADDRINUSE", "address already in use"))
+        if p.returncode == 0 or not taken:
+            break
+    return p
 
 
 class Case:
