@@ -171,7 +171,7 @@ Config resolve_config(const ehyb_config* in)
     c.prune_pct = z.prune_pct > 0 ? z.prune_pct : 110;
     c.er_units1 = z.er_units1 > 0 ? z.er_units1 : 0;  // 0: from the residual's size (er_panel.cpp)
     c.er_units2 = z.er_units2 > 0 ? z.er_units2 : 2048;
-    c.graph_compress = (z.graph_compress == 1 || z.graph_compress == 2) ? z.graph_compress : 0;
+    c.graph_compress = (z.graph_compress >= 1 && z.graph_compress <= 3) ? z.graph_compress : 0;
     c.balance = (z.balance == 1 || z.balance == 2) ? z.balance : 0;
     c.req_margin = z.req_margin;
     c.sym_slack_permille = z.sym_slack_permille > 0 ? z.sym_slack_permille : 30;

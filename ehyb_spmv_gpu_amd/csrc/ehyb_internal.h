@@ -97,7 +97,7 @@ struct Config {
     int prune_pct;          // ell_prune threshold in per cent of the panel form's cost (110)
     int er_units1;          // panel form: work units aimed at, pass 1 / pass 2 (2048)
     int er_units2;
-    int graph_compress;     // 0 automatic (on with symmetric pair storage), 1 on, 2 off
+    int graph_compress;     // 0 automatic (on with symmetric pair storage), 1 on, 2 off, 3 on + a refinement on the rows themselves (twins may part)
     int balance;            // 0 automatic, 1 entries, 2 rows
     int req_margin;         // 0 default, -1 none, > 0 as given
     int sym_slack_permille; // 30
@@ -266,6 +266,10 @@ int windows_that_do_not_pay(const HostLayout& H, int pct, std::vector<uint8_t>* 
 int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vwgt, int nparts,
                     int max_part_w, const Config& cfg, int* part, int64_t* edgecut, bool* by_degree = nullptr);
 void degree_order(int n, const int64_t* xadj, std::vector<int>* order);
+// the finest-level refinement of partition_graph alone, on a partition that exists: greedy boundary refinement, the hard cap, a polish
+// (adjncy may hold self loops: they are skipped)
+int refine_partition(int n, const int64_t* xadj, const int* adjncy, const int* vwgt, int nparts, int max_part_w, const Config& cfg, int* part,
+                     int64_t* edgecut);
 
 // Optional mt-metis backend: resolved at run time from the process image (weak symbol) --
 // see INTEGRATION.md.  Returns false when not linked.

@@ -774,6 +774,33 @@ int partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vw
     return EHYB_OK;
 }
 
+int refine_partition(int n, const int64_t* xadj, const int* adjncy, const int* vwgt, int nparts, int max_part_w, const Config& cfg, int* part,
+                     int64_t* edgecut)
+{
+    GView fine;
+    fine.n = n;
+    fine.xadj = xadj;
+    fine.adj = adjncy;
+    fine.ew = nullptr;
+    fine.vw = vwgt;
+    std::vector<int> p(part, part + n);
+    std::vector<int64_t> pw((size_t)nparts, 0);
+    for (int v = 0; v < n; ++v) pw[(size_t)p[v]] += fine.wv(v);
+    uint64_t rng = 0x1234ABCDull + (uint64_t)cfg.seed * 0x9E3779B97F4A7C15ull + 77;
+    const int64_t cap = max_part_w;
+    const double t0 = wall_seconds();
+    const int mv = refine_kway(fine, nparts, cap, 4, p, pw, rng);
+    enforce_cap(fine, nparts, cap, p, pw);
+    refine_kway(fine, nparts, cap, 2, p, pw, rng);
+    for (int q = 0; q < nparts; ++q)
+        if (pw[(size_t)q] > cap) EHYB_FAIL(EHYB_ERR_INTERNAL, "refine_partition: part %d has weight %lld > cap %lld", q, (long long)pw[(size_t)q], (long long)cap);
+    std::copy(p.begin(), p.end(), part);
+    const int64_t cut = edge_cut(fine, part);
+    if (edgecut) *edgecut = cut;
+    if (cfg.verbose) printf("refinement on the rows themselves: %d moves, cut %lld, %.2fs\n", mv, (long long)cut, wall_seconds() - t0);
+    return EHYB_OK;
+}
+
 }  // namespace ehyb
 
 extern "C" int ehyb_partition_graph(int n, const int64_t* xadj, const int* adjncy, const int* vwgt,

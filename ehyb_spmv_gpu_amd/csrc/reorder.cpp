@@ -204,6 +204,18 @@ static int partition_compressed(const matrixCOO* m, const std::vector<int64_t>& 
     if (rc != EHYB_OK) return rc;
 #pragma omp parallel for schedule(static)
     for (int v = 0; v < n; ++v) part[v] = cpart[group[v]];
+    if (c.graph_compress == 3) {
+        // the compressed graph as the first coarsening level only: one refinement on the rows themselves, where the unknowns of a node may part
+        std::vector<int64_t> rx;
+        const int64_t* fx = xadj.data();
+        if (from_rows) {
+            rx.assign(rp, rp + n + 1);
+            fx = rx.data();
+        }
+        const int rc2 = refine_partition(n, fx, nbr, row_w, nparts, cap, c, part, cut);
+        if (rc2 != EHYB_OK) return rc2;
+        group.clear();   // (the groups are no longer units of the partition)
+    }
     if (group_out) group_out->swap(group);
     *used = true;
     return EHYB_OK;
@@ -272,7 +284,7 @@ extern "C" int ehyb_matrix_reorder_blocks(matrixCOO* m, int symmetric_pattern, c
         // Automatic = with symmetric pair storage only: the partitions of the compressed graph cost the bench matrix with
         // EVERY entry stored 4 % (same-box A/B at equal format bytes, round 2: 1098-1101 against 1123-1166 GFLOP/s;
         // bench.py's plain_storage arm fell from 1094 to 1049) while symmetric pairs gain from them (fewer halo columns).
-        const bool compress = (c.graph_compress == 1 || (c.graph_compress == 0 && c.sym_pairs == 1)) && symmetric_pattern != 0 && (c.partitioner == EHYB_PART_AUTO || c.partitioner == EHYB_PART_MULTILEVEL) && n >= 4096;
+        const bool compress = (c.graph_compress == 1 || c.graph_compress == 3 || (c.graph_compress == 0 && c.sym_pairs == 1)) && symmetric_pattern != 0 && (c.partitioner == EHYB_PART_AUTO || c.partitioner == EHYB_PART_MULTILEVEL) && n >= 4096;
         // ... and then the compressed graph is made from the rows themselves (symmetric pattern: the columns of a row ARE its neighbours);
         // the adjacency lists -- a copy of J without the diagonal, 311 MB for the bench matrix -- are built only if that attempt declines
         const bool defer_adj = compress && c.n_top <= 1;

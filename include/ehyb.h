@@ -162,7 +162,8 @@ typedef struct ehyb_config {
     int32_t er_units2;     /* panel form: row blocks pass 2 aims at (0 = 2048)                                 */
     int32_t graph_compress;/* the k-way partitioner works on the compressed graph where rows come in groups with one column
                               list (the unknowns of a node): 0 = with symmetric pair storage only (plain storage runs 4 %
-                              slower on such partitions, reorder.cpp), 1 = always, 2 = never                      */
+                              slower on such partitions, reorder.cpp), 1 = always, 2 = never, 3 = always, followed by one
+                              refinement on the rows themselves (the groups may then be cut)                      */
     int32_t balance;       /* symmetric pair storage, what the partitions are balanced on: 0 = rows unless the row lengths
                               vary by more than 30 % (sigma/mean), 1 = entries, 2 = rows                         */
     int32_t req_margin;    /* entry-balanced partitions of a graded mesh: partitions asked for = nParts - margin; 0 =

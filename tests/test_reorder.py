@@ -194,6 +194,28 @@ def test_unknowns_of_a_node_stay_together(E):
     assert np.array_equal(m2.reorder_list, lst)
 
 
+def test_compressed_graph_with_a_refinement_on_the_rows(E, O):
+    """cfg.graph_compress = 3: the compressed graph is the first coarsening level only -- the partition it gives is refined once
+    on the rows themselves, where the unknowns of a node may part.  Partitions under the cap, every row in one, deterministic, and
+    the plan built on them multiplies like the oracle."""
+    from util import Case
+    cfg = E.make_config(lds_doubles=4096, partitioner=E.EHYB_PART_MULTILEVEL, graph_compress=3)
+    c = Case(E, O, "fem3d", (30000, 3, 22, 22, 13500, 1, 1), cfg)
+    m = c.m
+    n = m.n
+    pb = m.part_boundary[:m.c.nParts + 1]
+    assert pb[0] == 0 and pb[-1] == n and np.all(np.diff(pb) >= 0)
+    assert np.diff(pb).max() <= max(int(m.c.vectorCacheSize), -(-n // m.c.nParts))
+    assert np.array_equal(np.sort(m.reorder_list), np.arange(n))
+    plan = E.Plan(m, cfg, upload=False)
+    yp, written = O.walk_plan(plan, c.xp)
+    bad, worst = c.check(yp)
+    assert bad == 0, worst
+    m2 = E.Matrix.generate("fem3d", 30000, 3, 22, 22, 13500, 1, 1, cfg=cfg)
+    m2.reorder(cfg)
+    assert np.array_equal(m2.reorder_list, c.perm)
+
+
 def test_graded_mesh_asks_for_fewer_partitions(E, O):
     """Symmetric pair storage on a matrix whose rows differ a lot in length: entry-balanced partitions, the
     row-limited ones bisected -- and fewer asked for up front, so that the launch ends at one round of 256
