@@ -20,6 +20,7 @@ def main():
     ap.add_argument("--mtx", default="", help="a Matrix Market file instead of a generator workload (bench.py --mtx): storage from its banner as bench.py chooses it")
     ap.add_argument("--iters", type=int, default=10)
     ap.add_argument("--plain", action="store_true", help="every entry stored even for a symmetric workload")
+    ap.add_argument("--graph-compress", type=int, default=0, help="cfg.graph_compress (A/B of the partitions the k-way partitioner gives)")
     ap.add_argument("--layout-out", default="", help="write the plan's layout fingerprint (bench.layout_fingerprint) here: pmc_parse.py stores it with the entry")
     args = ap.parse_args()
     import bench as B
@@ -39,7 +40,7 @@ def main():
     else:
         gen, gargs, _ = B.WORKLOADS[args.workload]
         sym = B.symmetric_storage_pays(gen, gargs) and not args.plain  # as bench.py does
-        cfg = E.make_config(sym_pairs=1 if sym else 0, partitioner=B.partitioner_for(E, gen))
+        cfg = E.make_config(sym_pairs=1 if sym else 0, partitioner=B.partitioner_for(E, gen), graph_compress=args.graph_compress)
         m = E.Matrix.generate(gen, *gargs, cfg=cfg)
     x = E.x_glibc(m.n)
     m.reorder(cfg)
