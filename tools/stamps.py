@@ -23,6 +23,8 @@ def main():
     ap.add_argument("--items", type=int, default=2)
     ap.add_argument("--variant", type=int, default=0, help="0/1 LDS slab counter, 3 static round-robin")
     ap.add_argument("--xcd-map", type=int, default=1, help="1 = every XCD takes one contiguous run of items (default), 2 = blockIdx order")
+    ap.add_argument("--dump", default="", help="write every item's duration, slab range and placement to this .npz (offline analysis)")
+    ap.add_argument("--graph-compress", type=int, default=0, help="cfg.graph_compress (A/B of the partitions)")
     ap.add_argument("--triple-gather", type=int, default=0, help="1 = the stamped launch stages every window entry from THREE vectors (what folding CG's direction "
                                                                  "update into the staging would gather): the price of that fold")
     args = ap.parse_args()
@@ -39,7 +41,7 @@ def main():
         print(f"streaming read of {mb} MiB: {bw.value:.0f} GB/s")
 
     gen, gargs, _ = B.WORKLOADS[args.workload]
-    kw = dict(lds_doubles=args.lds, threads=args.threads, items_per_cu=args.items, ell_variant=args.variant, sym_pairs=args.sym, xcd_map=args.xcd_map)
+    kw = dict(lds_doubles=args.lds, threads=args.threads, items_per_cu=args.items, ell_variant=args.variant, sym_pairs=args.sym, xcd_map=args.xcd_map, graph_compress=args.graph_compress)
     if args.part_rows:
         kw["part_rows"] = args.part_rows
     cfg = E.make_config(**kw)
@@ -92,6 +94,14 @@ def main():
         sel = xcc == xc
         if sel.any():
             print(f"  xcc {xc}: {sel.sum():4d} WGs, end med {np.median(end[sel]):.1f} max {end[sel].max():.1f} us, bytes {pairs[sel].sum() * 64 * 20 / 1e6:.1f} MB")
+    if args.dump:
+        np.savez(args.dump, dur=dur, start=start, staged=staged, end=end, xcc=xcc, slab_begin=items[:, 2], slab_end=items[:, 3], pairs=pairs, rows=rows, halo=halo)
+    meta3 = plan.array("slab_meta").reshape(-1, 4)[:, 3].astype(np.int64)
+    for i in np.argsort(-dur)[:8]:
+        w2 = meta3[items[i, 2]:items[i, 3]] >> 16
+        g = (meta3[items[i, 2]:items[i, 3]] & 0x3F) + 1
+        print(f"  slow item {i}: duration {dur[i]:.1f} us (staging {staged[i] - start[i]:.1f}) segments {items[i, 1] - items[i, 0]} slabs {items[i, 3] - items[i, 2]} pairs {pairs[i]} "
+              f"widest slab {w2.max()} pairs, mean groups {g.mean():.1f}, rows {rows[i]} halo {halo[i]} xcc {xcc[i]}")
     late = np.argsort(-end)[:8]
     for i in late:
         print(f"  late item {i}: segments {items[i, 1] - items[i, 0]} slabs {items[i, 3] - items[i, 2]} pairs {pairs[i]} start {start[i]:.1f} staged {staged[i]:.1f} end {end[i]:.1f} xcc {xcc[i]}")
