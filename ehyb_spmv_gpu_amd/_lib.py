@@ -79,7 +79,8 @@ class Config(C.Structure):
         ("ell_alternate", C.c_int32),
         ("row_split", C.c_int32),
         ("col_map", C.c_int32),
-        ("reserved", C.c_int32 * 23),
+        ("er_nt", C.c_int32),
+        ("reserved", C.c_int32 * 22),
     ]
 
 

@@ -184,6 +184,7 @@ Config resolve_config(const ehyb_config* in)
     c.ell_alternate = (z.ell_alternate == 1 || z.ell_alternate == 2) ? z.ell_alternate : 0;  // 0: by the size of the stream (launch_ell)
     c.row_split = z.row_split > 0 ? z.row_split : 0;
     c.col_map = z.col_map == 2 ? 2 : 1;
+    c.er_nt = (z.er_nt == 1 || z.er_nt == 2) ? z.er_nt : 0;
     c.er_queue = (z.er_queue == 1 || z.er_queue == 2) ? z.er_queue : 0;  // 0: by the number of items per resident workgroup (launch_panel)
     // the automatic choice of the direct shape is for callers that left the window sizing alone: a caller
     // that names a window (lds_doubles / part_rows other than the defaults) gets that window
@@ -259,6 +260,7 @@ void ehyb_config_resolve(const ehyb_config* in, ehyb_config* out)
     r.ell_alternate = c.ell_alternate;
     r.row_split = c.row_split;
     r.col_map = c.col_map;
+    r.er_nt = c.er_nt;
     *out = r;
 }
 

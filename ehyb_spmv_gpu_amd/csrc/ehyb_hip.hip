@@ -622,8 +622,10 @@ __device__ __forceinline__ void pb_scale_body(const int2* __restrict__ items, co
         for (int j = 0; j < K; ++j) {
             const int cj = c + j < c1 ? c + j : c;  // wave-uniform
             const size_t pos = (size_t)cj * 64 + lane;
-            v[j] = val[pos];
-            cw[j] = colf[pos];
+            // (streamed past the caches: every entry is read once per multiply, and what the caches hold instead -- the x panels the units of a
+            // hub panel stage again and again, the partial sums pass 2 is about to read -- is read again.  R-MAT 2^22: 128.0 -> 124.0 us)
+            v[j] = __builtin_nontemporal_load(&val[pos]);
+            cw[j] = __builtin_nontemporal_load(&colf[pos]);
             jv[j] = (uint32_t)lane < fn[j] ? jump[f0[j] + lane] : 0u;  // lane l: the chunk's l-th jump entry
         }
         uint32_t g0[K], gn[K];  // the records of the next step
@@ -705,7 +707,10 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_scale_kernel(const int2* __re
 // y[row] += accumulator for the rows that received something (the ELL launch has written y before) -- or,
 // for a block of rows whose partitions have no window (rows < 0 in the unit), y[row] = accumulator for
 // every row: the ELL launch leaves those rows alone.
-template <int THREADS>
+// NT: the partial sums and their row words are streamed past the caches -- where they are more than the Infinity Cache can hold between the
+// passes anyway (R-MAT 2^24: 460 MB; 520 -> 487 us with it, because the next multiply then finds more of the entry stream's tail there);
+// where they fit (2^22: 89 MB) pass 2 reads them from that cache and the hint costs 3 us.
+template <int THREADS, bool NT>
 __global__ __launch_bounds__(THREADS) void ehyb_pb_reduce_kernel(const int4* __restrict__ units,
                                                                  const double* __restrict__ partial,
                                                                  const uint16_t* __restrict__ row,
@@ -728,8 +733,13 @@ __global__ __launch_bounds__(THREADS) void ehyb_pb_reduce_kernel(const int4* __r
         for (int j = 0; j < K; ++j) {
             const int i = base + j * THREADS + (int)threadIdx.x;
             const bool in = i < u.y;
-            v[j] = in ? partial[i] : 0.0;
-            r[j] = in ? (uint32_t)row[i] : 0xFFFFFFFFu;
+            if (NT) {
+                v[j] = in ? __builtin_nontemporal_load(&partial[i]) : 0.0;
+                r[j] = in ? (uint32_t)__builtin_nontemporal_load(&row[i]) : 0xFFFFFFFFu;
+            } else {
+                v[j] = in ? partial[i] : 0.0;
+                r[j] = in ? (uint32_t)row[i] : 0xFFFFFFFFu;
+            }
         }
 #pragma unroll
         for (int j = 0; j < K; ++j) {
@@ -988,9 +998,16 @@ static int launch_panel(ehyb_plan* P, const double* x, double* y, hipStream_t st
 #undef PB_SCALE
 #undef PB_SCALE_P
     }
-    if ((which & 2) && u2 > 0)
-        hipLaunchKernelGGL(ehyb_pb_reduce_kernel<512>, dim3(u2), dim3(512), (size_t)H.pb_rows_max * 8, st, (const int4*)P->d_pb_units2 + u2_first,
-                           P->d_pb_partial, P->d_pb_row, y, probe);
+    if ((which & 2) && u2 > 0) {
+        // (cfg.er_nt: 0 = by the size of what pass 2 reads -- 10 B per partial sum -- against half the 256 MB Infinity Cache, 1 / 2 = always / never)
+        const bool nt = P->cfg.er_nt == 1 || (P->cfg.er_nt == 0 && H.pb_partials * 10 > (128ll << 20));
+        if (nt)
+            hipLaunchKernelGGL((ehyb_pb_reduce_kernel<512, true>), dim3(u2), dim3(512), (size_t)H.pb_rows_max * 8, st, (const int4*)P->d_pb_units2 + u2_first,
+                               P->d_pb_partial, P->d_pb_row, y, probe);
+        else
+            hipLaunchKernelGGL((ehyb_pb_reduce_kernel<512, false>), dim3(u2), dim3(512), (size_t)H.pb_rows_max * 8, st, (const int4*)P->d_pb_units2 + u2_first,
+                               P->d_pb_partial, P->d_pb_row, y, probe);
+    }
     HIP_TRY(hipGetLastError());
     return EHYB_OK;
 }
@@ -1417,7 +1434,8 @@ int ehyb_plan_upload(ehyb_plan* P)
     LDS_ATTR((ehyb_pb_scale_kernel<512, false, true>))
     LDS_ATTR((ehyb_pb_scale_kernel<1024, true, true>))
     LDS_ATTR((ehyb_pb_scale_kernel<1024, false, true>))
-    LDS_ATTR(ehyb_pb_reduce_kernel<512>)
+    LDS_ATTR((ehyb_pb_reduce_kernel<512, true>))
+    LDS_ATTR((ehyb_pb_reduce_kernel<512, false>))
 #undef LDS_ATTR_T
 #undef LDS_ATTR_S
 #undef LDS_ATTR

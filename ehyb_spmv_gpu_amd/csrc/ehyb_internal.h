@@ -111,6 +111,7 @@ struct Config {
     int ell_alternate;      // 0 automatic (streams that do not fit the Infinity Cache), 1 on, 2 off
     int row_split;          // panel form: no row block of pass 2 straddles this row (0 = none)
     int col_map;            // host builder: 1 per-thread column look-up arrays where they fit (default), 2 sorted lists + binary search
+    int er_nt;              // panel form, pass 2 reads past the caches: 0 by size, 1 always, 2 never
 };
 Config resolve_config(const ehyb_config* cfg);
 

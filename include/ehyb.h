@@ -206,7 +206,9 @@ typedef struct ehyb_config {
                               columns, one per host thread (matrices of up to 4 M columns: 16 MiB per thread), 2 = in the sorted list
                               of the window's outside columns by binary search (A/B; the way for larger inputs).  The layouts are
                               the same array for array                                                                  */
-    int32_t reserved[23];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
+    int32_t er_nt;         /* panel form, pass 2: the partial sums and their row words are read with the non-temporal hint (past the caches):
+                              0 = where they are more than half the 256 MB Infinity Cache (10 B per partial sum), 1 = always, 2 = never (A/B) */
+    int32_t reserved[22];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);
