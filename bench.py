@@ -713,6 +713,7 @@ def main():
     ap.add_argument("--items-per-cu", type=int, default=0)
     ap.add_argument("--window-mode", type=int, default=0)
     ap.add_argument("--er-mode", type=int, default=0, help="residual form: 0/1 CSR segments, 2 panel form (cfg.er_mode)")
+    ap.add_argument("--ell-nt", type=int, default=0, help="cfg.ell_nt (A/B: 1 the whole value stream past the caches, 2 plain loads as in rounds 1-3; default: plain loads for the end of an alternating walk only)")
     ap.add_argument("--balance", type=int, default=0, help="cfg.balance (symmetric pairs, A/B: 1 = partitions balanced on entries, 2 = on rows)")
     ap.add_argument("--graph-compress", type=int, default=0, help="cfg.graph_compress of the k-way partitioner (A/B: 1 on, 2 off, 3 on + refinement on the rows)")
     ap.add_argument("--no-cpu-baseline", action="store_true", help="skip the TIMED CPU legs (the parity check stays)")
@@ -798,7 +799,7 @@ def main():
     kw = {}
     for k, v in (("lds_doubles", args.lds_doubles), ("part_rows", args.part_rows), ("threads", args.threads),
                  ("items_per_cu", args.items_per_cu), ("window_mode", args.window_mode), ("er_mode", args.er_mode),
-                 ("ell_alternate", args.ell_alternate), ("graph_compress", args.graph_compress), ("balance", args.balance)):
+                 ("ell_alternate", args.ell_alternate), ("graph_compress", args.graph_compress), ("balance", args.balance), ("ell_nt", args.ell_nt)):
         if v:
             kw[k] = v
     if world > 1 and os.environ.get("OMP_NUM_THREADS") == "1":

@@ -80,7 +80,8 @@ class Config(C.Structure):
         ("row_split", C.c_int32),
         ("col_map", C.c_int32),
         ("er_nt", C.c_int32),
-        ("reserved", C.c_int32 * 22),
+        ("ell_nt", C.c_int32),
+        ("reserved", C.c_int32 * 21),
     ]
 
 

@@ -185,6 +185,7 @@ Config resolve_config(const ehyb_config* in)
     c.row_split = z.row_split > 0 ? z.row_split : 0;
     c.col_map = z.col_map == 2 ? 2 : 1;
     c.er_nt = (z.er_nt == 1 || z.er_nt == 2) ? z.er_nt : 0;
+    c.ell_nt = (z.ell_nt == 1 || z.ell_nt == 2) ? z.ell_nt : 3;
     c.er_queue = (z.er_queue == 1 || z.er_queue == 2) ? z.er_queue : 0;  // 0: by the number of items per resident workgroup (launch_panel)
     // the automatic choice of the direct shape is for callers that left the window sizing alone: a caller
     // that names a window (lds_doubles / part_rows other than the defaults) gets that window
@@ -261,6 +262,7 @@ void ehyb_config_resolve(const ehyb_config* in, ehyb_config* out)
     r.row_split = c.row_split;
     r.col_map = c.col_map;
     r.er_nt = c.er_nt;
+    r.ell_nt = c.ell_nt;
     *out = r;
 }
 

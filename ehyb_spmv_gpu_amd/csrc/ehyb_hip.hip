@@ -153,6 +153,11 @@ struct EllArgs {
     // one (x and two shifted copies of it, `probe_n` entries long) -- what folding CG's direction update p = z + beta p into the staging
     // would gather (r, the old p, 1 / diag): how much longer the launch gets is the price of that fold
     int probe_n;
+    // The value stream is read ONCE per multiply: loaded with the non-temporal hint it streams past the caches, which then hold what is read
+    // again (column words shared by lanes, lane maps, x) -- 0.69 -> 0.78 of the peak for a launch that walks first to last, every entry stored
+    // 1126 -> 1290 GFLOP/s (profiles/r04_nt_hints_ab.txt).  nt_slabs: the slabs at walk positions below nt_slabs/1024 of a segment are read
+    // that way; the rest, the END of the walk, with plain loads -- what an alternating walk wants the Infinity Cache to keep for the next launch.
+    int nt_slabs;
 };
 
 // Workgroups are handed to the 8 XCDs round robin (b mod 8).  With this map XCD k gets the k-th
@@ -209,7 +214,20 @@ __device__ __forceinline__ void ell_entry(double v, uint32_t col16, const double
     }
 }
 
-template <bool INLINE_ER, bool SYM>
+// the (value, value) pair of one lane: plain, or past the caches
+template <bool NT>
+__device__ __forceinline__ double2 ell_load_pair(const double2* __restrict__ p)
+{
+    if (NT) {
+        double2 r;
+        r.x = __builtin_nontemporal_load(&p->x);
+        r.y = __builtin_nontemporal_load(&p->y);
+        return r;
+    }
+    return *p;
+}
+
+template <bool INLINE_ER, bool SYM, bool NT>
 __device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restrict__ win, double* yacc, int s, int base,
                                          int pe, int lane, double& xy)
 {
@@ -253,7 +271,7 @@ __device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restr
     int k = 0;
     // (an 8-pair step for SYM, 128 VGPRs at 16 waves per CU, measured 1 % slower than this one)
     for (; k + 4 <= np; k += 4) {
-        const double2 v0 = v[(k + 0) * 64], v1 = v[(k + 1) * 64], v2 = v[(k + 2) * 64], v3 = v[(k + 3) * 64];
+        const double2 v0 = ell_load_pair<NT>(v + (k + 0) * 64), v1 = ell_load_pair<NT>(v + (k + 1) * 64), v2 = ell_load_pair<NT>(v + (k + 2) * 64), v3 = ell_load_pair<NT>(v + (k + 3) * 64);
         const uint32_t c0 = c[(k + 0) * G], c1 = c[(k + 1) * G], c2 = c[(k + 2) * G], c3 = c[(k + 3) * G];
         ell_entry<SYM>(v0.x, ELL_COL_LO(c0), win, yacc, xi, code, acc0);
         ell_entry<SYM>(v0.y, ELL_COL_HI(c0), win, yacc, xi, code, acc1);
@@ -265,7 +283,7 @@ __device__ __forceinline__ void ell_slab(const EllArgs& A, const double* __restr
         ell_entry<SYM>(v3.y, ELL_COL_HI(c3), win, yacc, xi, code, acc1);
     }
     for (; k < np; ++k) {
-        const double2 v0 = v[k * 64];
+        const double2 v0 = ell_load_pair<NT>(v + k * 64);
         const uint32_t c0 = c[k * G];
         ell_entry<SYM>(v0.x, ELL_COL_LO(c0), win, yacc, xi, code, acc0);
         ell_entry<SYM>(v0.y, ELL_COL_HI(c0), win, yacc, xi, code, acc1);
@@ -336,8 +354,12 @@ __device__ __forceinline__ void ell_segment(const EllArgs& A, double* __restrict
         g == A.items[2 * item_of_block(A.item_map, A.xcd_map)].x)
         A.stamps[4 * blockIdx.x + 1] = wall_clock64();
     int s = sb + wave;  // (logical position in the segment's walk; the slab it stands for depends on the direction)
+    const int nt_end = sb + (int)(((long long)(se - sb) * A.nt_slabs + 1023) >> 10);   // walk positions below it: value stream past the caches
     while (s < se) {
-        ell_slab<INLINE_ER, SYM>(A, win, yacc, A.reverse ? se - 1 - (s - sb) : s, base, pe, lane, xy);
+        if (s < nt_end)
+            ell_slab<INLINE_ER, SYM, true>(A, win, yacc, A.reverse ? se - 1 - (s - sb) : s, base, pe, lane, xy);
+        else
+            ell_slab<INLINE_ER, SYM, false>(A, win, yacc, A.reverse ? se - 1 - (s - sb) : s, base, pe, lane, xy);
         if (DYN) {
             int nx = 0;
             if (lane == 0) nx = atomicAdd(next_slab, 1);
@@ -842,6 +864,7 @@ static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long 
     A.reverse = 0;
     A.reverse_items = 0;
     A.probe_n = stamps ? t_probe_n : 0;
+    A.nt_slabs = P->cfg.ell_nt == 2 ? 0 : 1024;   // (launch_ell_impl lowers it for an alternating walk with cfg.ell_nt = 3)
     // on by default: plain storage 143 -> 134 us on the audikw_1-like matrix; cfg.xcd_map = 2 for the A/B
     A.xcd_map = P->host.sym ? 0 : (P->cfg.xcd_map != 2 ? 1 : 0);
     A.item_map = P->d_item_map;  // symmetric pairs: items are sorted heaviest first, dispatched in that order
@@ -881,6 +904,13 @@ static int launch_ell_impl(ehyb_plan* P, const double* x, double* y, hipStream_t
         A.reverse = t_walk >= 0 ? (t_walk & 1) : (P->launch_parity.fetch_xor(1, std::memory_order_relaxed) & 1);
         // more than one round of workgroups: what ran in the last round is what the cache holds, so it runs first now
         A.reverse_items = (A.reverse && n_items > kNumCU * (lds > 80 * 1024 ? 1 : 2)) ? 1 : 0;
+        // cfg.ell_nt = 3: the END of every walk -- the share of the stream the 256 MB Infinity Cache can hold -- is read with plain loads,
+        // so that it is still there when the next launch starts from that end
+        // (half, three quarters and five quarters of that share measured level: profiles/r04_nt_hints_ab.txt)
+        if (P->cfg.ell_nt == 3 && !STAMP) {
+            const double keep = std::min(1.0, (double)(256ll << 20) / (double)std::max<long long>(1, H.stats.bytes_format_ell));
+            A.nt_slabs = (int)(1024.0 * (1.0 - keep));
+        }
     }
     const bool sym = H.sym;
 #define ELL_GO(T, M, I, S)                                                                                  \

@@ -112,6 +112,7 @@ struct Config {
     int row_split;          // panel form: no row block of pass 2 straddles this row (0 = none)
     int col_map;            // host builder: 1 per-thread column look-up arrays where they fit (default), 2 sorted lists + binary search
     int er_nt;              // panel form, pass 2 reads past the caches: 0 by size, 1 always, 2 never
+    int ell_nt;             // window kernel, value stream past the caches: 3 all but the end of an alternating walk (default), 1 every slab, 2 never
 };
 Config resolve_config(const ehyb_config* cfg);
 

@@ -208,7 +208,11 @@ typedef struct ehyb_config {
                               the same array for array                                                                  */
     int32_t er_nt;         /* panel form, pass 2: the partial sums and their row words are read with the non-temporal hint (past the caches):
                               0 = where they are more than half the 256 MB Infinity Cache (10 B per partial sum), 1 = always, 2 = never (A/B) */
-    int32_t reserved[22];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
+    int32_t ell_nt;        /* the window kernel reads its value stream (read once per multiply) with the non-temporal hint, past the caches:
+                              0/3 = every slab but the END of an alternating walk (the share of the stream the Infinity Cache can hold
+                              is read with plain loads, to be found there by the next launch; every slab where the walk does not
+                              alternate), 1 = every slab, 2 = never (rounds 1-3)                                                   */
+    int32_t reserved[21];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
 } ehyb_config;
 
 void ehyb_config_default(ehyb_config* cfg);
