@@ -864,7 +864,9 @@ static EllArgs ell_args(ehyb_plan* P, const double* x, double* y, unsigned long 
     A.reverse = 0;
     A.reverse_items = 0;
     A.probe_n = stamps ? t_probe_n : 0;
-    A.nt_slabs = P->cfg.ell_nt == 2 ? 0 : 1024;   // (launch_ell_impl lowers it for an alternating walk with cfg.ell_nt = 3)
+    // a stream the 256 MB Infinity Cache holds whole stays there from one multiply to the next: plain loads (120 k rows, 65 MB: 15.4 us, with the hint
+    // 16.2); cfg.ell_nt = 1 forces the hint.  (launch_ell_impl lowers nt_slabs for an alternating walk with cfg.ell_nt = 3)
+    A.nt_slabs = (P->cfg.ell_nt == 2 || (P->cfg.ell_nt != 1 && P->host.stats.bytes_format_ell <= (256ll << 20))) ? 0 : 1024;
     // on by default: plain storage 143 -> 134 us on the audikw_1-like matrix; cfg.xcd_map = 2 for the A/B
     A.xcd_map = P->host.sym ? 0 : (P->cfg.xcd_map != 2 ? 1 : 0);
     A.item_map = P->d_item_map;  // symmetric pairs: items are sorted heaviest first, dispatched in that order

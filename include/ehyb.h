@@ -211,7 +211,7 @@ typedef struct ehyb_config {
     int32_t ell_nt;        /* the window kernel reads its value stream (read once per multiply) with the non-temporal hint, past the caches:
                               0/3 = every slab but the END of an alternating walk (the share of the stream the Infinity Cache can hold
                               is read with plain loads, to be found there by the next launch; every slab where the walk does not
-                              alternate), 1 = every slab, 2 = never (rounds 1-3)                                                   */
+                              alternate; none where the whole stream fits that cache), 1 = every slab, 2 = never (rounds 1-3)      */
     int32_t reserved[21];  /* zero; keeps sizeof(ehyb_config) = 260 bytes when knobs are added                  */
 } ehyb_config;
 
